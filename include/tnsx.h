@@ -1,0 +1,166 @@
+/*
+ * tnsx.h -- C ABI of the MI355X-native fixed-radius neighbour-search engine.
+ *
+ * This is the drop-in boundary for the `tns::TreeNSearch` hot path of
+ * InteractiveComputerGraphics/TreeNSearch.  Every entry point replaces one member of the reference's
+ * public class (reference paths relative to the upstream repository root):
+ *
+ *   TreeNSearch/source/TreeNSearch.h:28-427     class tns::TreeNSearch            (API surface)
+ *   TreeNSearch/source/TreeNSearch.cpp:20-261   thin setters / getters
+ *   TreeNSearch/source/TreeNSearch.cpp:138-149  run()  -> tnsx_run
+ *   TreeNSearch/source/TreeNSearch.cpp:2571     prepare_zsort() -> tnsx_prepare_zsort
+ *   TreeNSearch/source/NeighborList.h:8-39      handle layout [count, j0, j1, ...] -> tnsx_csr_view
+ *
+ * The header-only C++ shim include/tns/TreeNSearch.h re-creates the reference class verbatim on top of
+ * this ABI; treensearch_amd/api.py is the ctypes mirror used by the tests.
+ *
+ * Conventions: plain pointers and sizes only; every function returns a tnsx_status (0 = ok) unless it
+ * returns an id or a count (then negative = -status); tnsx_last_error() gives the message.  The engine
+ * NEVER falls back to a CPU path: without a usable gfx950 device tnsx_create fails.
+ */
+#ifndef TNSX_H
+#define TNSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TNSX_VERSION 100
+
+typedef struct tnsx_context tnsx_context;
+
+typedef enum tnsx_status {
+	TNSX_OK = 0,
+	TNSX_ERR_INVALID = 1,      /* bad argument / API misuse (the reference prints + exit(-1), e.g. TreeNSearch.cpp:22-25) */
+	TNSX_ERR_NO_DEVICE = 2,    /* no usable HIP device */
+	TNSX_ERR_HIP = 3,          /* a HIP runtime call failed */
+	TNSX_ERR_CONFIG = 4,       /* _check() failures, TreeNSearch.cpp:366-392 */
+	TNSX_ERR_GRID_TOO_LARGE = 5, /* > 32768 cells per dimension, TreeNSearch.cpp:510-515 */
+	TNSX_ERR_LIST_TOO_LONG = 6,
+	TNSX_ERR_STATE = 7         /* e.g. view requested before run(), pair inactive */
+} tnsx_status;
+
+/* Distance arithmetic (both are bit-exact restatements of a reference build):
+ *   STRICT      d2 = ((dx*dx + dy*dy) + dz*dz), every op rounded -- TreeNSearch.cpp:2478-2483 /
+ *               BruteforceNSearch.cpp:88 as written (reference compiled with -ffp-contract=off)
+ *   CONTRACTED  d2 = fma(dz,dz, fma(dx,dx, dy*dy)) -- what GCC emits for the same lines under the
+ *               reference's own flags (-O3 -march=native, default -ffp-contract=fast) */
+typedef enum tnsx_arith {
+	TNSX_ARITH_STRICT = 0,
+	TNSX_ARITH_CONTRACTED = 1
+} tnsx_arith;
+
+/* flags of tnsx_add_point_set / tnsx_resize_point_set */
+#define TNSX_F32        0u   /* const float*  xyzxyz.. (+ const float* radii)   TreeNSearch.h:50,112 */
+#define TNSX_F64        1u   /* const double* xyzxyz.. (+ const double* radii)  TreeNSearch.h:63,126 */
+#define TNSX_HOST       0u   /* pointers are host memory; re-read (H2D) at every tnsx_run, TreeNSearch.h:375-378 */
+#define TNSX_DEVICE     2u   /* pointers are device (HBM) memory; read in place at every tnsx_run */
+#define TNSX_VARIABLE   4u   /* variable-radius set even though radii == NULL (legal only with n_points == 0;
+                                the reference's tests hand null pointers for empty sets, tests.cpp:453) */
+
+typedef struct tnsx_options {
+	int device_id;            /* HIP device ordinal; -1 = current device */
+	void* stream;             /* hipStream_t to launch on; NULL = the engine creates its own */
+	int arith;                /* tnsx_arith; default STRICT */
+	int mirror_to_host;       /* 1: tnsx_run also mirrors every active pair's lists into pinned host memory
+	                             (what get_neighborlist needs for CPU consumers); 0: lists stay in HBM */
+	int collect_stage_times;  /* 1: record hipEvents around every stage (tnsx_get_stats) */
+	uint64_t max_dense_cells; /* upper bound of the dense cell table; 0 = default (2^26) */
+	int reserved[8];
+} tnsx_options;
+
+/* Neighbour lists of one active (set_i -> set_j) pair.  Record layout == the reference's chunk storage
+ * (vectors_internals.h:152-174, TreeNSearch.cpp:2494-2500): records[offsets[p]] = n, followed by the n
+ * set-local indices into set_j, so `tns::NeighborList(records + offsets[p])` works unchanged. */
+typedef struct tnsx_csr_view {
+	int n_points;                    /* points in set_i */
+	uint64_t n_records;              /* ints in `records` = total neighbours + n_points */
+	uint64_t n_neighbors;            /* total neighbour indices */
+	const uint64_t* offsets_device;  /* [n_points] by ORIGINAL point index, HBM */
+	const int* records_device;       /* [n_records], HBM */
+	const uint64_t* offsets_host;    /* pinned host mirrors, NULL unless mirrored */
+	const int* records_host;
+} tnsx_csr_view;
+
+typedef struct tnsx_stats {
+	/* last tnsx_run */
+	int n_sets;
+	uint64_t n_points;            /* all sets */
+	uint64_t n_queries;           /* Q: sum over active pairs of n_i */
+	uint64_t n_neighbors;         /* E: total emitted indices */
+	uint64_t n_occupied_cells;    /* C: summed over sets */
+	uint64_t n_grid_cells;        /* cells of the search grid */
+	int grid_dims[3];
+	float grid_cell_size;
+	int key_bits, radix_passes;
+	/* algorithmic HBM bytes of the last run (SURVEY.md section 8d formula, evaluated with measured Q,E,C) */
+	uint64_t bytes_build, bytes_query;
+	/* stage times in ms (0 unless collect_stage_times) */
+	float ms_total, ms_upload, ms_bounds, ms_keys, ms_sort, ms_gather, ms_cells, ms_count, ms_scan, ms_fill, ms_mirror;
+	/* world box of the reference semantics (TreeNSearch.cpp:415-522) */
+	float world_bottom[3], world_top[3];
+	int world_cells_pow2;
+} tnsx_stats;
+
+/* ---- lifetime ---------------------------------------------------------------------------------- */
+tnsx_status tnsx_default_options(tnsx_options* opt);
+tnsx_status tnsx_create(const tnsx_options* opt /* may be NULL */, tnsx_context** out);   /* TreeNSearch.h:36 */
+void        tnsx_destroy(tnsx_context* ctx);                                               /* TreeNSearch.h:37 */
+const char* tnsx_last_error(const tnsx_context* ctx /* NULL: creation errors */);
+int         tnsx_version(void);
+
+/* ---- point sets (TreeNSearch.cpp:35-133, 346-365) ---------------------------------------------- */
+/* returns the set id (>= 0) or -status.  radii == NULL => fixed-radius mode set. */
+int         tnsx_add_point_set(tnsx_context* ctx, const void* xyz, const void* radii, int n_points, unsigned flags);
+tnsx_status tnsx_resize_point_set(tnsx_context* ctx, int set_id, const void* xyz, const void* radii, int n_points,
+                                  unsigned flags);
+
+/* ---- configuration ------------------------------------------------------------------------------ */
+tnsx_status tnsx_set_search_radius(tnsx_context* ctx, float r);          /* TreeNSearch.cpp:20-34 */
+tnsx_status tnsx_set_cell_size(tnsx_context* ctx, float cell_size);      /* TreeNSearch.cpp:173-182 (write-once) */
+tnsx_status tnsx_set_symmetric_search(tnsx_context* ctx, int active);    /* TreeNSearch.cpp:169 */
+tnsx_status tnsx_set_active_search(tnsx_context* ctx, int set_i, int set_j, int active);            /* :219-222 */
+tnsx_status tnsx_set_active_search_all(tnsx_context* ctx, int set_i, int search_in_all, int be_found_by_all); /* :223-232 */
+tnsx_status tnsx_set_all_searches(tnsx_context* ctx, int active);        /* TreeNSearch.cpp:233-240 */
+tnsx_status tnsx_set_arithmetic(tnsx_context* ctx, int arith);           /* tnsx_arith */
+
+/* ---- getters (TreeNSearch.cpp:191-218) ---------------------------------------------------------- */
+int         tnsx_get_n_sets(const tnsx_context* ctx);
+int         tnsx_get_n_points_in_set(const tnsx_context* ctx, int set_i);
+int64_t     tnsx_get_total_n_points(const tnsx_context* ctx);
+int         tnsx_is_search_active(const tnsx_context* ctx, int set_i, int set_j);
+int         tnsx_does_set_exist(const tnsx_context* ctx, int set_i);
+uint64_t    tnsx_get_neighborlist_n_bytes(const tnsx_context* ctx);      /* TreeNSearch.cpp:254-261 */
+
+/* ---- the hot path ------------------------------------------------------------------------------- */
+/* run(): _set_up, _check, world box, build + query of every active pair (TreeNSearch.cpp:138-149).
+ * Synchronous like the reference: when it returns the lists are complete (in HBM, and in pinned host
+ * memory when mirror_to_host). */
+tnsx_status tnsx_run(tnsx_context* ctx);
+/* get_neighborlist() backing store (TreeNSearch.cpp:241-249).  Views stay valid until the next tnsx_run. */
+tnsx_status tnsx_get_pair_view(tnsx_context* ctx, int set_i, int set_j, tnsx_csr_view* out);
+/* mirrors one pair to pinned host memory on demand (no-op when already mirrored) */
+tnsx_status tnsx_mirror_pair_to_host(tnsx_context* ctx, int set_i, int set_j);
+/* copies one pair's offsets / records into caller memory (host or device pointers, either may be NULL) */
+tnsx_status tnsx_copy_pair(tnsx_context* ctx, int set_i, int set_j, uint64_t* offsets_dst, int* records_dst,
+                           int dst_on_device);
+
+/* ---- z-sort (TreeNSearch.cpp:2571-2716, TreeNSearch.h:443-481) ---------------------------------- */
+tnsx_status tnsx_prepare_zsort(tnsx_context* ctx);
+/* new -> old map of one set (TreeNSearch.cpp:250-253); host copy and device copy, valid until the next prepare */
+tnsx_status tnsx_get_zsort_order(tnsx_context* ctx, int set_i, const int** new_to_old_host,
+                                 const int** new_to_old_device, int* n);
+/* data[new*stride + s] = old_data[old*stride + s] for elements of elem_bytes bytes, in place
+ * (apply_zsort<T>, TreeNSearch.h:443-481); data may be host or device memory */
+tnsx_status tnsx_apply_zsort(tnsx_context* ctx, int set_i, void* data, size_t elem_bytes, int stride, int on_device);
+
+/* ---- introspection ------------------------------------------------------------------------------- */
+tnsx_status tnsx_get_stats(const tnsx_context* ctx, tnsx_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TNSX_H */

@@ -1,0 +1,215 @@
+"""GPU tests of the drop-in API semantics.  Each test mirrors a scenario of the reference's own test program
+(/root/reference/tests/tests.cpp) or a documented behaviour of tns::TreeNSearch, driven through the C ABI."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases as CS
+import parity as P
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_pair(orc, pts_i, pts_j, same, radius=None, ri=None, rj=None, symmetric=True):
+    if ri is None:
+        return orc.pair_search(pts_i, pts_j, radius=radius, same_set=same, mode=0)
+    return orc.pair_search(pts_i, pts_j, ra=ri, rb=rj, symmetric=symmetric, same_set=same, mode=0)
+
+
+@pytest.mark.parametrize("n_points", [1, 100, 10000])
+def test_one_set_fixed_radius_with_zsort_roundtrip(n_points, oracle):
+    """tests.cpp:91-112 + the common body :34-48: run, compare with brute force, zsort, apply, run again, compare."""
+    import treensearch_amd as T
+    case = CS.one_set_fixed_radius(n_points)
+    pts = case.points[0].copy()
+    ns = T.TreeNSearch()
+    ns.set_search_radius(case.radius)
+    s = ns.add_point_set(pts)
+    ns.set_active_search(s, s, True)
+    ns.run()
+    P.assert_same_csr(ns.neighbor_csr(s, s), _oracle_pair(oracle, pts, pts, True, radius=case.radius), "before zsort")
+    ns.prepare_zsort()
+    order = ns.get_zsort_order(s)
+    assert sorted(order.tolist()) == list(range(len(pts)))
+    before = pts.copy()
+    ns.apply_zsort(s, pts, 3)            # permutes the user array in place; the engine re-reads it at run()
+    assert np.array_equal(pts, before[order])
+    ns.run()
+    P.assert_same_csr(ns.neighbor_csr(s, s), _oracle_pair(oracle, pts, pts, True, radius=case.radius), "after zsort")
+    # the order is Morton ordered w.r.t. the reference grid (cell-level key on the world box)
+    st = ns.get_stats()
+    cell = np.float32(1.5) * np.float32(case.radius)
+    keys = oracle.zsort_keys(before, np.array(st["world_bottom"], np.float32), np.float32(1.0) / cell)
+    assert oracle.check_zsort(keys, order) == 0
+
+
+@pytest.mark.parametrize("n_points", [100, 10000])
+def test_two_dynamic_sets_variable_radius(n_points, oracle):
+    """tests.cpp:114-145."""
+    case = CS.two_sets_variable_radius(n_points)
+    res, ns = P.run_engine_case(case, 0)
+    for (i, j) in case.active:
+        ref = _oracle_pair(oracle, case.points[i], case.points[j], i == j, ri=case.radii[i], rj=case.radii[j])
+        P.assert_same_csr(res[(i, j)], ref, f"{i}->{j}")
+    assert not ns.is_search_active(1, 1)
+    with pytest.raises(Exception):
+        ns.neighbor_csr(1, 1)          # inactive pair (undefined behaviour in the reference, an error here)
+
+
+def test_mixed_float_double_point_sets(oracle):
+    """tests.cpp:147-186: one set float, the other double; doubles are cast with (float) on the device."""
+    case = CS.mixed_float_double(10000)
+    assert case.points[1].dtype == np.float64
+    res, _ = P.run_engine_case(case, 0)
+    ora = P.run_oracle_case(case, 0, oracle)
+    for pr in case.active:
+        P.assert_same_csr(res[pr], ora[pr], f"{pr}")
+
+
+def test_resize_variable_radius(oracle):
+    """tests.cpp:188-237: n/2 -> n -> n/3 through resize_point_set."""
+    import treensearch_amd as T
+    c = CS.two_sets_variable_radius(10000)
+    p0, p1, r0, r1 = c.points[0], c.points[1], c.radii[0], c.radii[1]
+    ns = T.TreeNSearch()
+    ns.add_point_set(p0, r0, n_points=len(p0) // 2)
+    ns.add_point_set(p1, r1, n_points=len(p1) // 2)
+    for (i, j) in c.active:
+        ns.set_active_search(i, j, True)
+
+    def check(n0, n1, what):
+        ns.run()
+        sub = [p0[:n0], p1[:n1]]
+        rad = [r0[:n0], r1[:n1]]
+        for (i, j) in c.active:
+            ref = _oracle_pair(oracle, sub[i], sub[j], i == j, ri=rad[i], rj=rad[j])
+            P.assert_same_csr(ns.neighbor_csr(i, j), ref, f"{what} {i}->{j}")
+
+    check(len(p0) // 2, len(p1) // 2, "original")
+    ns.resize_point_set(0, p0, r0, n_points=len(p0))
+    ns.resize_point_set(1, p1, r1, n_points=len(p1))
+    check(len(p0), len(p1), "resize x2")
+    ns.resize_point_set(0, p0, r0, n_points=len(p0) // 3)
+    ns.resize_point_set(1, p1, r1, n_points=len(p1) // 3)
+    check(len(p0) // 3, len(p1) // 3, "resize x0.33")
+
+
+def test_moving_points_are_reread_every_run(oracle):
+    """The library keeps the user's pointer and re-reads it at every run() (TreeNSearch.h:375-378)."""
+    import treensearch_amd as T
+    pts = CS.uniform_fixed(100000).points[0][:20000].copy()
+    r = np.float32(0.06)
+    ns = T.TreeNSearch()
+    ns.set_search_radius(r)
+    ns.add_point_set(pts)
+    ns.set_active_search(0, 0, True)
+    ns.run()
+    P.assert_same_csr(ns.neighbor_csr(0, 0), oracle.pair_search(pts, pts, radius=r, same_set=True), "step 0")
+    pts += (np.random.default_rng(0).random(pts.shape, dtype=np.float32) - np.float32(0.5)) * np.float32(0.01)
+    ns.run()
+    P.assert_same_csr(ns.neighbor_csr(0, 0), oracle.pair_search(pts, pts, radius=r, same_set=True), "step 1")
+
+
+def test_defaults_and_getters():
+    """All searches inactive by default (TreeNSearch.cpp:357-361); set_active_search(int,bool,bool) writes the
+    column first, then the row (TreeNSearch.cpp:223-232)."""
+    import treensearch_amd as T
+    ns = T.TreeNSearch()
+    ns.set_search_radius(0.1)
+    a = np.zeros((4, 3), np.float32)
+    for _ in range(3):
+        ns.add_point_set(a)
+    assert ns.get_n_sets() == 3 and ns.get_total_n_points() == 12 and ns.get_n_points_in_set(1) == 4
+    assert not any(ns.is_search_active(i, j) for i in range(3) for j in range(3))
+    ns.set_active_search(1, True, False)     # search in all, be found by none
+    assert [ns.is_search_active(1, j) for j in range(3)] == [True, True, True]
+    assert [ns.is_search_active(j, 1) for j in range(3)] == [False, True, False]
+    ns.set_active_search(1, False, True)
+    assert [ns.is_search_active(1, j) for j in range(3)] == [False, False, False]
+    assert [ns.is_search_active(j, 1) for j in range(3)] == [True, False, True]
+    ns.set_all_searches(True)
+    assert all(ns.is_search_active(i, j) for i in range(3) for j in range(3))
+    ns.set_active_search(0, 2, False)
+    assert not ns.is_search_active(0, 2)
+    assert ns.does_set_exist(2) and not ns.does_set_exist(3)
+
+
+def test_error_behaviour_matches_reference_messages():
+    import treensearch_amd as T
+    ns = T.TreeNSearch()
+    a = np.zeros((4, 3), np.float32)
+    ns.add_point_set(a, np.ones(4, np.float32))
+    with pytest.raises(T.TnsxError, match="Cannot set a global search radius"):     # TreeNSearch.cpp:22-25
+        ns.set_search_radius(0.1)
+    ns.set_cell_size(0.5)
+    with pytest.raises(T.TnsxError, match="Cell size already set"):                  # TreeNSearch.cpp:175-178
+        ns.set_cell_size(0.7)
+    ns2 = T.TreeNSearch()
+    ns2.add_point_set(a)                         # fixed-radius set but no radius given, plus a variable set
+    ns2.add_point_set(a, np.ones(4, np.float32))
+    with pytest.raises(T.TnsxError, match="not all point sets have per-point search radius"):   # :388-391
+        ns2.run()
+    ns3 = T.TreeNSearch()
+    ns3.set_search_radius(0.001)
+    ns3.add_point_set(np.array([[0, 0, 0], [100, 0, 0]], np.float32))
+    ns3.set_active_search(0, 0)
+    with pytest.raises(T.TnsxError, match="Max allowed cells per dimension is 32768"):          # :510-515
+        ns3.run()
+    with pytest.raises(T.TnsxError):
+        ns3.resize_point_set(5, a)               # TreeNSearch.cpp:69-72
+
+
+def test_get_neighborlist_and_for_each_neighbor(oracle):
+    case = CS.one_set_fixed_radius(100)
+    _, ns = P.run_engine_case(case, 0, mirror_to_host=True)
+    offs, idx = P.run_oracle_case(case, 0, oracle)[(0, 0)]
+    v = ns.pair_view(0, 0)
+    assert v.records_host and v.offsets_host and v.n_neighbors == offs[-1]
+    for p in (0, 7, len(offs) - 2):
+        nl = ns.get_neighborlist(0, 0, p)
+        assert nl.size() == offs[p + 1] - offs[p]
+        assert sorted(nl[k] for k in range(nl.size())) == idx[offs[p]:offs[p + 1]].tolist()
+        got = []
+        ns.for_each_neighbor(0, 0, p, got.append)
+        assert sorted(got) == idx[offs[p]:offs[p + 1]].tolist()
+    assert ns.get_neighborlist_n_bytes() == 4 * (int(offs[-1]) + len(offs) - 1)
+
+
+def test_apply_zsort_on_device_and_other_dtypes(oracle):
+    import torch
+    import treensearch_amd as T
+    case = CS.dam_break(100000)
+    pts, rad = case.points[0].copy(), case.radii[0].copy()
+    ns = T.TreeNSearch()
+    ns.add_point_set(pts, rad)
+    ns.set_active_search(0, 0)
+    ns.prepare_zsort()
+    order = ns.get_zsort_order(0)
+    ids = np.arange(len(pts), dtype=np.int64)
+    vel = np.random.default_rng(0).random((len(pts), 3)).astype(np.float64)
+    d_pts = torch.from_numpy(pts.copy()).cuda()
+    d_u8 = torch.arange(len(pts), dtype=torch.int64).cuda().to(torch.uint8)
+    ns.apply_zsort(0, ids)
+    ns.apply_zsort(0, vel, 3)
+    ns.apply_zsort(0, d_pts, 3)
+    ns.apply_zsort(0, d_u8, 1)
+    assert np.array_equal(ids, order)
+    assert np.array_equal(vel, np.random.default_rng(0).random((len(pts), 3)).astype(np.float64)[order])
+    assert np.array_equal(d_pts.cpu().numpy(), pts[order])
+    assert np.array_equal(d_u8.cpu().numpy(), (np.arange(len(pts)) % 256).astype(np.uint8)[order])
+
+
+def test_cpp_dropin_scenarios(built_library, tmp_path):
+    """The C++ shim (`#include <TreeNSearch>`) run through the reference's test scenarios, compiled with g++."""
+    exe = tmp_path / "shim_scenarios"
+    lib_dir = os.path.dirname(built_library)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fopenmp", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "shim_scenarios.cpp"), "-o", str(exe),
+                           "-L" + lib_dir, "-ltnsx", "-Wl,-rpath," + lib_dir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    print(out.stdout[-3000:])
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "FAILED" not in out.stdout and "ALL PASSED" in out.stdout

@@ -1,0 +1,385 @@
+"""ctypes mirror of the reference's `tns::TreeNSearch` class on top of the C ABI (include/tnsx.h).
+
+Same method names, argument meaning and defaults as /root/reference/TreeNSearch/source/TreeNSearch.h:28-427
+(all searches inactive by default, symmetric search on, fixed radius XOR per-point radii, set-local indices,
+cell size write-once).  Where the reference prints a message and calls exit(-1) this mirror raises TnsxError
+with the same message.  There is NO CPU fallback: the native library must load and a gfx950 device must exist.
+
+Point data may be numpy arrays (host memory, re-read at every run() exactly like the reference re-reads the
+user's raw pointers, TreeNSearch.h:375-378) or torch CUDA tensors (HBM, read in place).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libtnsx.so")
+
+ARITH_STRICT = 0
+ARITH_CONTRACTED = 1
+
+TNSX_F32, TNSX_F64, TNSX_HOST, TNSX_DEVICE, TNSX_VARIABLE = 0, 1, 0, 2, 4
+
+
+class TnsxError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"[tnsx status {status}] {message}")
+        self.status = status
+        self.message = message
+
+
+class _Options(C.Structure):
+    _fields_ = [("device_id", C.c_int), ("stream", C.c_void_p), ("arith", C.c_int), ("mirror_to_host", C.c_int),
+                ("collect_stage_times", C.c_int), ("max_dense_cells", C.c_uint64), ("reserved", C.c_int * 8)]
+
+
+class _CsrView(C.Structure):
+    _fields_ = [("n_points", C.c_int), ("n_records", C.c_uint64), ("n_neighbors", C.c_uint64),
+                ("offsets_device", C.c_void_p), ("records_device", C.c_void_p),
+                ("offsets_host", C.c_void_p), ("records_host", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_sets", C.c_int), ("n_points", C.c_uint64), ("n_queries", C.c_uint64), ("n_neighbors", C.c_uint64),
+                ("n_occupied_cells", C.c_uint64), ("n_grid_cells", C.c_uint64), ("grid_dims", C.c_int * 3),
+                ("grid_cell_size", C.c_float), ("key_bits", C.c_int), ("radix_passes", C.c_int),
+                ("bytes_build", C.c_uint64), ("bytes_query", C.c_uint64),
+                ("ms_total", C.c_float), ("ms_upload", C.c_float), ("ms_bounds", C.c_float), ("ms_keys", C.c_float),
+                ("ms_sort", C.c_float), ("ms_gather", C.c_float), ("ms_cells", C.c_float), ("ms_count", C.c_float),
+                ("ms_scan", C.c_float), ("ms_fill", C.c_float), ("ms_mirror", C.c_float),
+                ("world_bottom", C.c_float * 3), ("world_top", C.c_float * 3), ("world_cells_pow2", C.c_int)]
+
+    def as_dict(self):
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = list(v) if hasattr(v, "__len__") else v
+        return d
+
+
+# every symbol include/tnsx.h declares (tests/test_abi.py checks the library exports all of them)
+ABI_SYMBOLS = [
+    "tnsx_default_options", "tnsx_create", "tnsx_destroy", "tnsx_last_error", "tnsx_version",
+    "tnsx_add_point_set", "tnsx_resize_point_set",
+    "tnsx_set_search_radius", "tnsx_set_cell_size", "tnsx_set_symmetric_search", "tnsx_set_active_search",
+    "tnsx_set_active_search_all", "tnsx_set_all_searches", "tnsx_set_arithmetic",
+    "tnsx_get_n_sets", "tnsx_get_n_points_in_set", "tnsx_get_total_n_points", "tnsx_is_search_active",
+    "tnsx_does_set_exist", "tnsx_get_neighborlist_n_bytes",
+    "tnsx_run", "tnsx_get_pair_view", "tnsx_mirror_pair_to_host", "tnsx_copy_pair",
+    "tnsx_prepare_zsort", "tnsx_get_zsort_order", "tnsx_apply_zsort", "tnsx_get_stats",
+]
+
+_lib = None
+
+
+def load_library():
+    """Loads libtnsx.so (built by treensearch_amd.build).  Raises if it is missing -- there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(f"{LIB_PATH} not found: build it with `python -m treensearch_amd.build` "
+                      "(the engine has no CPU fallback)")
+    # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  Two HIP runtimes in one process do not
+    # share devices or pointers, so torch's copy must be mapped BEFORE libtnsx.so: the loader then resolves our
+    # DT_NEEDED libamdhip64.so.7 to the already-loaded one and torch tensors / streams are valid in the engine.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, ci = C.c_void_p, C.c_int
+    L.tnsx_default_options.argtypes = [C.POINTER(_Options)]
+    L.tnsx_create.argtypes = [C.POINTER(_Options), C.POINTER(vp)]
+    L.tnsx_destroy.argtypes = [vp]
+    L.tnsx_destroy.restype = None
+    L.tnsx_last_error.argtypes = [vp]
+    L.tnsx_last_error.restype = C.c_char_p
+    L.tnsx_add_point_set.argtypes = [vp, vp, vp, ci, C.c_uint]
+    L.tnsx_resize_point_set.argtypes = [vp, ci, vp, vp, ci, C.c_uint]
+    L.tnsx_set_search_radius.argtypes = [vp, C.c_float]
+    L.tnsx_set_cell_size.argtypes = [vp, C.c_float]
+    L.tnsx_set_symmetric_search.argtypes = [vp, ci]
+    L.tnsx_set_active_search.argtypes = [vp, ci, ci, ci]
+    L.tnsx_set_active_search_all.argtypes = [vp, ci, ci, ci]
+    L.tnsx_set_all_searches.argtypes = [vp, ci]
+    L.tnsx_set_arithmetic.argtypes = [vp, ci]
+    L.tnsx_get_n_sets.argtypes = [vp]
+    L.tnsx_get_n_points_in_set.argtypes = [vp, ci]
+    L.tnsx_get_total_n_points.argtypes = [vp]
+    L.tnsx_get_total_n_points.restype = C.c_int64
+    L.tnsx_is_search_active.argtypes = [vp, ci, ci]
+    L.tnsx_does_set_exist.argtypes = [vp, ci]
+    L.tnsx_get_neighborlist_n_bytes.argtypes = [vp]
+    L.tnsx_get_neighborlist_n_bytes.restype = C.c_uint64
+    L.tnsx_run.argtypes = [vp]
+    L.tnsx_get_pair_view.argtypes = [vp, ci, ci, C.POINTER(_CsrView)]
+    L.tnsx_mirror_pair_to_host.argtypes = [vp, ci, ci]
+    L.tnsx_copy_pair.argtypes = [vp, ci, ci, vp, vp, ci]
+    L.tnsx_prepare_zsort.argtypes = [vp]
+    L.tnsx_get_zsort_order.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(ci)]
+    L.tnsx_apply_zsort.argtypes = [vp, ci, vp, C.c_size_t, ci, ci]
+    L.tnsx_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    _lib = L
+    return L
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _describe(arr, want_cols: Optional[int]):
+    """-> (pointer, n_elements, flags, keepalive)"""
+    if _is_torch(arr):
+        import torch
+        if arr.dtype not in (torch.float32, torch.float64):
+            raise TypeError("points/radii must be float32 or float64")
+        if not arr.is_contiguous():
+            raise ValueError("tensor must be contiguous (xyzxyz... layout)")
+        flags = (TNSX_F64 if arr.dtype == torch.float64 else TNSX_F32) | (TNSX_DEVICE if arr.is_cuda else TNSX_HOST)
+        return arr.data_ptr() if arr.numel() else None, arr.numel(), flags, arr
+    a = np.asarray(arr)
+    if a.dtype not in (np.float32, np.float64):
+        raise TypeError("points/radii must be float32 or float64")
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("array must be C-contiguous (xyzxyz... layout)")
+    flags = (TNSX_F64 if a.dtype == np.float64 else TNSX_F32) | TNSX_HOST
+    return a.ctypes.data if a.size else None, a.size, flags, a
+
+
+class NeighborList:
+    """tns::NeighborList (NeighborList.h:8-39): a view of one `[count, j0, j1, ...]` record."""
+
+    __slots__ = ("_rec",)
+
+    def __init__(self, rec: np.ndarray):
+        self._rec = rec
+
+    def size(self) -> int:
+        return int(self._rec[0])
+
+    def __len__(self):
+        return int(self._rec[0])
+
+    def __getitem__(self, i):
+        return int(self._rec[1 + i])
+
+    def get_ptr(self) -> np.ndarray:
+        return self._rec[1:1 + int(self._rec[0])]
+
+
+class TreeNSearch:
+    def __init__(self, *, arith: int = ARITH_STRICT, mirror_to_host: bool = False, device_id: int = -1,
+                 stream: Optional[int] = None, collect_stage_times: bool = False, max_dense_cells: int = 0):
+        self._L = load_library()
+        opt = _Options()
+        self._L.tnsx_default_options(C.byref(opt))
+        opt.device_id = device_id
+        opt.stream = stream
+        opt.arith = arith
+        opt.mirror_to_host = int(mirror_to_host)
+        opt.collect_stage_times = int(collect_stage_times)
+        opt.max_dense_cells = max_dense_cells
+        h = C.c_void_p()
+        st = self._L.tnsx_create(C.byref(opt), C.byref(h))
+        if st != 0:
+            raise TnsxError(st, self._L.tnsx_last_error(None).decode())
+        self._h = h
+        self._keep = {}
+        self._views = {}
+        self._n_threads = -1
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.tnsx_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _check(self, st: int):
+        if st != 0:
+            raise TnsxError(st, self._L.tnsx_last_error(self._h).decode())
+
+    def _set_args(self, points, radii, n_points):
+        pp, pn, pf, pk = _describe(points, 3)
+        if radii is not None:
+            rp, rn, rf, rk = _describe(radii, 1)
+            if (rf & TNSX_F64) != (pf & TNSX_F64) or (rf & TNSX_DEVICE) != (pf & TNSX_DEVICE):
+                raise TypeError("points and radii must have the same dtype and live in the same memory")
+            flags = pf | TNSX_VARIABLE
+        else:
+            rp, rn, rk = None, 0, None
+            flags = pf
+        n = pn // 3 if n_points is None else int(n_points)
+        if n * 3 > pn or (radii is not None and n > rn):
+            raise ValueError("n_points exceeds the array size")
+        return pp, rp, n, flags, (pk, rk)
+
+    # ------------------------------------------------------------------ main interface
+    def add_point_set(self, points, radii=None, n_points: Optional[int] = None) -> int:
+        """TreeNSearch.h:50,63,112,126.  `radii is None` => fixed-radius mode."""
+        pp, rp, n, flags, keep = self._set_args(points, radii, n_points)
+        s = self._L.tnsx_add_point_set(self._h, pp, rp, n, flags)
+        if s < 0:
+            self._check(-s)
+        self._keep[s] = keep
+        return s
+
+    def resize_point_set(self, set_id: int, points, radii=None, n_points: Optional[int] = None) -> None:
+        """TreeNSearch.h:72,81,136,146."""
+        pp, rp, n, flags, keep = self._set_args(points, radii, n_points)
+        self._check(self._L.tnsx_resize_point_set(self._h, int(set_id), pp, rp, n, flags))
+        self._keep[set_id] = keep
+
+    def set_search_radius(self, r) -> None:
+        self._check(self._L.tnsx_set_search_radius(self._h, C.c_float(float(np.float32(r)))))
+
+    def set_cell_size(self, c) -> None:
+        self._check(self._L.tnsx_set_cell_size(self._h, C.c_float(float(np.float32(c)))))
+
+    def set_symmetric_search(self, activate: bool) -> None:
+        self._check(self._L.tnsx_set_symmetric_search(self._h, int(bool(activate))))
+
+    def set_arithmetic(self, arith: int) -> None:
+        self._check(self._L.tnsx_set_arithmetic(self._h, int(arith)))
+
+    def run(self) -> None:
+        self._views = {}
+        self._check(self._L.tnsx_run(self._h))
+
+    def run_scalar(self) -> None:
+        """The reference's scalar twin accumulates in double (TreeNSearch.cpp:2080-2087) and is not a parity
+        target; here it is the same GPU path as run()."""
+        self.run()
+
+    # ------------------------------------------------------------------ searches
+    def set_all_searches(self, active: bool) -> None:
+        self._check(self._L.tnsx_set_all_searches(self._h, int(bool(active))))
+
+    def set_active_search(self, set_i: int, a=True, b=True) -> None:
+        """Both reference overloads (TreeNSearch.h:265, :275), resolved like C++ does: an `int` second
+        argument selects (set_i, set_j, active=True); a `bool` selects (set_i, search_in_all, be_found_by_all)."""
+        if isinstance(a, (bool, np.bool_)):
+            self._check(self._L.tnsx_set_active_search_all(self._h, int(set_i), int(a), int(bool(b))))
+        else:
+            self._check(self._L.tnsx_set_active_search(self._h, int(set_i), int(a), int(bool(b))))
+
+    # ------------------------------------------------------------------ no-op tuning knobs of the CPU design
+    def set_n_threads(self, n: int) -> None:
+        self._n_threads = int(n)
+
+    def set_recursion_cap(self, cap: int) -> None:
+        pass
+
+    def set_n_points_for_parallel_octree(self, n: int = 200000) -> None:
+        pass
+
+    # ------------------------------------------------------------------ getters
+    def get_n_sets(self) -> int:
+        return self._L.tnsx_get_n_sets(self._h)
+
+    def get_n_threads(self) -> int:
+        return self._n_threads
+
+    def get_n_points_in_set(self, s: int) -> int:
+        return self._L.tnsx_get_n_points_in_set(self._h, int(s))
+
+    def get_total_n_points(self) -> int:
+        return int(self._L.tnsx_get_total_n_points(self._h))
+
+    def is_search_active(self, i: int, j: int) -> bool:
+        return bool(self._L.tnsx_is_search_active(self._h, int(i), int(j)))
+
+    def does_set_exist(self, s: int) -> bool:
+        return bool(self._L.tnsx_does_set_exist(self._h, int(s)))
+
+    def get_neighborlist_n_bytes(self) -> int:
+        return int(self._L.tnsx_get_neighborlist_n_bytes(self._h))
+
+    def get_stats(self) -> dict:
+        st = Stats()
+        self._check(self._L.tnsx_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def print_state(self) -> None:
+        for k, v in self.get_stats().items():
+            print(f"{k}: {v}")
+
+    # ------------------------------------------------------------------ results
+    def pair_view(self, i: int, j: int) -> _CsrView:
+        v = _CsrView()
+        self._check(self._L.tnsx_get_pair_view(self._h, int(i), int(j), C.byref(v)))
+        return v
+
+    def neighbor_records(self, i: int, j: int):
+        """Host copies of the record storage of pair (i,j): (offsets uint64[n_i] by original point index,
+        records int32[n_records]) with records[offsets[p]] = count followed by the neighbour indices."""
+        key = (i, j)
+        if key not in self._views:
+            v = self.pair_view(i, j)
+            offs = np.zeros(max(v.n_points, 1), np.uint64)
+            recs = np.zeros(max(v.n_records, 1), np.int32)
+            self._check(self._L.tnsx_copy_pair(self._h, int(i), int(j), offs.ctypes.data, recs.ctypes.data, 0))
+            self._views[key] = (offs[:v.n_points], recs[:v.n_records])
+        return self._views[key]
+
+    def neighbor_csr(self, i: int, j: int, sort_each: bool = True):
+        """Standard CSR in original point order: (offsets int64[n_i+1], indices int32[E])."""
+        offs, recs = self.neighbor_records(i, j)
+        n = len(offs)
+        if n == 0:
+            return np.zeros(1, np.int64), np.zeros(0, np.int32)
+        o = offs.astype(np.int64)
+        counts = recs[o].astype(np.int64)
+        out_offs = np.zeros(n + 1, np.int64)
+        np.cumsum(counts, out=out_offs[1:])
+        total = int(out_offs[-1])
+        src = np.repeat(o + 1 - out_offs[:-1], counts) + np.arange(total, dtype=np.int64)
+        idx = recs[src]
+        if sort_each and total:
+            # sort inside each list: stable sort by (list id, value)
+            lid = np.repeat(np.arange(n, dtype=np.int64), counts)
+            order = np.lexsort((idx, lid))
+            idx = idx[order]
+        return out_offs, np.ascontiguousarray(idx, np.int32)
+
+    def get_neighborlist(self, set_i: int, set_j: int, point_i: int) -> NeighborList:
+        """TreeNSearch.h:182."""
+        offs, recs = self.neighbor_records(set_i, set_j)
+        o = int(offs[point_i])
+        return NeighborList(recs[o:o + 1 + int(recs[o])])
+
+    def for_each_neighbor(self, set_i: int, set_j: int, i: int, f) -> None:
+        """TreeNSearch.h:194-195."""
+        nl = self.get_neighborlist(set_i, set_j, i)
+        for k in range(nl.size()):
+            f(nl[k])
+
+    # ------------------------------------------------------------------ zsort
+    def prepare_zsort(self) -> None:
+        self._check(self._L.tnsx_prepare_zsort(self._h))
+
+    def get_zsort_order(self, set_i: int) -> np.ndarray:
+        hp, dp, n = C.c_void_p(), C.c_void_p(), C.c_int()
+        self._check(self._L.tnsx_get_zsort_order(self._h, int(set_i), C.byref(hp), C.byref(dp), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, np.int32)
+        return np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_int)), shape=(n.value,)).copy()
+
+    def apply_zsort(self, set_i: int, data, stride: int = 1) -> None:
+        """In-place permutation of a user array (TreeNSearch.h:214-215); numpy (host) or torch CUDA tensor."""
+        if _is_torch(data):
+            if not data.is_contiguous():
+                raise ValueError("tensor must be contiguous")
+            self._check(self._L.tnsx_apply_zsort(self._h, int(set_i), data.data_ptr(), data.element_size(), int(stride),
+                                                 1 if data.is_cuda else 0))
+        else:
+            if not data.flags["C_CONTIGUOUS"] or not data.flags["WRITEABLE"]:
+                raise ValueError("array must be C-contiguous and writeable")
+            self._check(self._L.tnsx_apply_zsort(self._h, int(set_i), data.ctypes.data, data.itemsize, int(stride), 0))

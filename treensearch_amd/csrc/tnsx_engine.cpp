@@ -1,0 +1,845 @@
+// Host engine behind include/tnsx.h: set registry, world box, device arenas, stage orchestration on one HIP
+// stream, optional pinned host mirror of the neighbour lists.  Mirrors the control flow of
+// tns::TreeNSearch::run() (TreeNSearch.cpp:138-149: _set_up, _check, _clear_neighborlists, world box, build, query)
+// but none of its data structures: the build is sort-based on a uniform grid and lives entirely in HBM.
+//
+// There is deliberately NO CPU fallback anywhere in this file.
+#include "../../include/tnsx.h"
+#include "tnsx_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// ------------------------------------------------------------------------------------------------ buffers
+struct DevBuf {
+	void* p = nullptr;
+	size_t cap = 0;
+	~DevBuf() { if (p) (void)hipFree(p); }
+	DevBuf() = default;
+	DevBuf(const DevBuf&) = delete;
+	DevBuf& operator=(const DevBuf&) = delete;
+	DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+	// grow-only; contents are NOT preserved
+	hipError_t reserve(size_t bytes)
+	{
+		if (bytes <= cap && p) return hipSuccess;
+		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+		size_t want = bytes + bytes / 8 + 256;   // 12.5 % slack so that slowly growing problems do not realloc every step
+		hipError_t e = hipMalloc(&p, want);
+		if (e != hipSuccess) { want = bytes < 256 ? 256 : bytes; e = hipMalloc(&p, want); }
+		if (e == hipSuccess) cap = want;
+		return e;
+	}
+	template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+struct PinnedBuf {
+	void* p = nullptr;
+	size_t cap = 0;
+	~PinnedBuf() { if (p) (void)hipHostFree(p); }
+	PinnedBuf() = default;
+	PinnedBuf(const PinnedBuf&) = delete;
+	PinnedBuf& operator=(const PinnedBuf&) = delete;
+	PinnedBuf(PinnedBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+	hipError_t reserve(size_t bytes)
+	{
+		if (bytes <= cap && p) return hipSuccess;
+		if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+		const size_t want = bytes + bytes / 8 + 256;
+		const hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+		if (e == hipSuccess) cap = want;
+		return e;
+	}
+	template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct PointSet {
+	const void* user_xyz = nullptr;
+	const void* user_radii = nullptr;
+	int n = 0;
+	bool is_double = false;
+	bool on_device = false;
+	bool has_radii = false;
+	// staging (host inputs and/or double inputs)
+	DevBuf raw_xyz, raw_radii;       // uploaded user bytes (host inputs)
+	DevBuf f32_xyz, f32_radii;       // converted floats (double inputs)
+	const float* d_xyz = nullptr;    // what the kernels read this run
+	const float* d_radii = nullptr;
+	// search structures
+	DevBuf keys[2], idx[2];
+	DevBuf xyzi, r2, table, occ;
+	int sorted_buf = 0;
+	// zsort
+	std::vector<int> zsort_host;
+	DevBuf zsort_dev;
+	bool zsort_ready = false;
+};
+
+struct PairResult {
+	bool valid = false;
+	int n_i = 0;
+	uint64_t n_records = 0;
+	DevBuf counts, offs_sorted, offs_orig, records;
+	PinnedBuf h_offs, h_records;
+	bool mirrored = false;
+};
+
+}  // namespace
+
+struct tnsx_context {
+	tnsx_options opt{};
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	int n_cus = 256;
+	std::string last_error;
+
+	std::vector<PointSet> sets;
+	std::vector<std::vector<char>> active;      // active[i][j]
+	std::vector<PairResult> pairs;              // [i * n_sets + j]
+	int n_sets_at_last_run = 0;
+
+	// radius / grid configuration (TreeNSearch.h:384-402)
+	bool symmetric = true;
+	bool radius_set = false;
+	float radius = -1.0f, radius_sq = -1.0f;
+	int n_sets_with_radii = 0;
+	float cell_size = -1.0f, cell_size_inv = -1.0f;
+	float world[6] = { FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX };   // bottom, top (octree_internals.h:29-30)
+	int world_cells_pow2 = 0;
+	bool ran = false;
+
+	// scratch
+	DevBuf bounds_partials, bounds_out, sort_temp, scan_temp, n_occ, permute_tmp;
+	PinnedBuf h_small;
+	DevBuf mkeys[2];   // 64-bit morton keys for zsort
+	tnsx_stats stats{};
+	std::vector<hipEvent_t> events;
+	std::mutex mirror_mutex;
+};
+
+namespace {
+
+#define TNSX_FAIL(ctx, code, ...)                                   \
+	do {                                                            \
+		char _b[512];                                               \
+		std::snprintf(_b, sizeof(_b), __VA_ARGS__);                 \
+		(ctx)->last_error = _b;                                     \
+		return (code);                                              \
+	} while (0)
+
+#define HIPCHK(ctx, expr)                                                                               \
+	do {                                                                                                \
+		const hipError_t _e = (expr);                                                                   \
+		if (_e != hipSuccess) TNSX_FAIL(ctx, TNSX_ERR_HIP, "HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__, __LINE__, #expr); \
+	} while (0)
+
+inline bool set_ok(const tnsx_context* c, int s) { return s >= 0 && s < (int)c->sets.size(); }
+
+void new_point_set(tnsx_context* c)
+{
+	// TreeNSearch.cpp:346-365: grow the active table with `false`
+	c->sets.emplace_back();
+	const size_t n = c->sets.size();
+	for (auto& row : c->active) row.push_back(0);
+	c->active.emplace_back(n, 0);
+}
+
+// world box update, TreeNSearch.cpp:474-521 (shared by the scalar and SIMD versions)
+tnsx_status update_world_box(tnsx_context* c, const float tight[6])
+{
+	float* bottom = c->world; float* top = c->world + 3;
+	if (bottom[0] <= tight[0] && tight[3] <= top[0] && bottom[1] <= tight[1] && tight[4] <= top[1] && bottom[2] <= tight[2] && tight[5] <= top[2]) {
+		return TNSX_OK;
+	}
+	for (int d = 0; d < 3; d++) { bottom[d] = tight[d]; top[d] = tight[3 + d]; }
+	float center[3];
+	for (int d = 0; d < 3; d++) center[d] = 0.5f * (top[d] + bottom[d]);
+	float length = 0.0f;
+	for (int d = 0; d < 3; d++) length = std::max(length, top[d] - bottom[d]);
+	length += 100.0f * std::numeric_limits<float>::epsilon();
+	length *= 1.1f;   // domain_enlargment, TreeNSearch.h:401
+	const int n_cells = (int)(length / c->cell_size) + 1;
+	int n_pow2 = 1;
+	while (n_pow2 < n_cells) n_pow2 *= 2;
+	length = c->cell_size * (float)n_pow2;
+	c->world_cells_pow2 = n_pow2;
+	if (n_pow2 > 32768) {
+		TNSX_FAIL(c, TNSX_ERR_GRID_TOO_LARGE, "TreeNSearch error: Max allowed cells per dimension is 32768 (2^15). Use set_cell_size() to set a larger value.");
+	}
+	for (int d = 0; d < 3; d++) {
+		bottom[d] = center[d] - 0.5f * length;
+		top[d] = center[d] + 0.5f * length;
+	}
+	return TNSX_OK;
+}
+
+// stage user data of every set into device floats for this run
+tnsx_status stage_inputs(tnsx_context* c)
+{
+	for (PointSet& s : c->sets) {
+		s.d_xyz = nullptr; s.d_radii = nullptr;
+		if (s.n == 0) continue;
+		if (!s.user_xyz) TNSX_FAIL(c, TNSX_ERR_INVALID, "point set with n > 0 has a null coordinate pointer");
+		const size_t esz = s.is_double ? sizeof(double) : sizeof(float);
+		const void* dx = s.user_xyz;
+		const void* dr = s.user_radii;
+		if (!s.on_device) {
+			HIPCHK(c, s.raw_xyz.reserve(3 * (size_t)s.n * esz));
+			HIPCHK(c, hipMemcpyAsync(s.raw_xyz.p, s.user_xyz, 3 * (size_t)s.n * esz, hipMemcpyHostToDevice, c->stream));
+			dx = s.raw_xyz.p;
+			if (s.has_radii) {
+				HIPCHK(c, s.raw_radii.reserve((size_t)s.n * esz));
+				HIPCHK(c, hipMemcpyAsync(s.raw_radii.p, s.user_radii, (size_t)s.n * esz, hipMemcpyHostToDevice, c->stream));
+				dr = s.raw_radii.p;
+			}
+		}
+		if (s.is_double) {
+			HIPCHK(c, s.f32_xyz.reserve(3 * (size_t)s.n * sizeof(float)));
+			tnsx::launch_f64_to_f32((const double*)dx, s.f32_xyz.as<float>(), 3 * (size_t)s.n, c->stream);
+			dx = s.f32_xyz.p;
+			if (s.has_radii) {
+				HIPCHK(c, s.f32_radii.reserve((size_t)s.n * sizeof(float)));
+				tnsx::launch_f64_to_f32((const double*)dr, s.f32_radii.as<float>(), (size_t)s.n, c->stream);
+				dr = s.f32_radii.p;
+			}
+		}
+		s.d_xyz = (const float*)dx;
+		s.d_radii = s.has_radii ? (const float*)dr : nullptr;
+	}
+	return TNSX_OK;
+}
+
+// tight bounds + radius range over all sets -> host (one stream sync)
+tnsx_status compute_bounds(tnsx_context* c, float out8[8])
+{
+	int total_partials = 0;
+	for (const PointSet& s : c->sets) if (s.n > 0) total_partials += tnsx::bounds_num_blocks(s.n);
+	out8[0] = out8[1] = out8[2] = FLT_MAX; out8[3] = out8[4] = out8[5] = -FLT_MAX; out8[6] = FLT_MAX; out8[7] = -FLT_MAX;
+	if (total_partials == 0) return TNSX_OK;
+	HIPCHK(c, c->bounds_partials.reserve((size_t)total_partials * 8 * sizeof(float)));
+	HIPCHK(c, c->bounds_out.reserve(8 * sizeof(float)));
+	HIPCHK(c, c->h_small.reserve(256));
+	int off = 0;
+	for (const PointSet& s : c->sets) {
+		if (s.n == 0) continue;
+		tnsx::launch_bounds_partial(s.d_xyz, s.d_radii, s.n, c->bounds_partials.as<float>() + 8 * (size_t)off, c->stream);
+		off += tnsx::bounds_num_blocks(s.n);
+	}
+	tnsx::launch_bounds_final(c->bounds_partials.as<float>(), total_partials, c->bounds_out.as<float>(), c->stream);
+	HIPCHK(c, hipMemcpyAsync(c->h_small.p, c->bounds_out.p, 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	std::memcpy(out8, c->h_small.p, 8 * sizeof(float));
+	return TNSX_OK;
+}
+
+// _set_up default cell size (TreeNSearch.cpp:300-316) and _check (TreeNSearch.cpp:366-392)
+tnsx_status setup_and_check(tnsx_context* c, const float bounds8[8])
+{
+	if (c->cell_size < 0.0f) {
+		float cs;
+		if (c->radius_set) cs = 1.5f * c->radius;
+		else {
+			float min_radius = bounds8[6];
+			if (min_radius == FLT_MAX) min_radius = 1.0f;
+			cs = 1.5f * min_radius;
+		}
+		c->cell_size = cs;
+		c->cell_size_inv = 1.0f / cs;
+	}
+	if (c->cell_size <= 0.0f) TNSX_FAIL(c, TNSX_ERR_CONFIG, "TreeNSearch error: cell_size is not set. Use TreeNSearch::set_cell_size().");
+	if (c->radius_set && c->radius <= 0.0f) TNSX_FAIL(c, TNSX_ERR_CONFIG, "TreeNSearch error: global_search_radius <= 0.");
+	if (c->radius_set && c->n_sets_with_radii > 0) TNSX_FAIL(c, TNSX_ERR_CONFIG, "TreeNSearch error: global search radius and per-point variable search radii specified.");
+	if (!c->radius_set && c->n_sets_with_radii != (int)c->sets.size()) TNSX_FAIL(c, TNSX_ERR_CONFIG, "TreeNSearch error: not all point sets have per-point search radius specified.");
+	return TNSX_OK;
+}
+
+int ceil_log2_u64(uint64_t v)
+{
+	int b = 0;
+	while (((uint64_t)1 << b) < v) b++;
+	return b;
+}
+
+struct StageTimer {
+	tnsx_context* c;
+	size_t next = 0;
+	explicit StageTimer(tnsx_context* ctx) : c(ctx) {}
+	int mark()
+	{
+		if (!c->opt.collect_stage_times) return -1;
+		if (next >= c->events.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return -1; c->events.push_back(e); }
+		(void)hipEventRecord(c->events[next], c->stream);
+		return (int)next++;
+	}
+	float ms(int a, int b)
+	{
+		if (a < 0 || b < 0) return 0.f;
+		float t = 0.f;
+		(void)hipEventElapsedTime(&t, c->events[a], c->events[b]);
+		return t;
+	}
+};
+
+}  // namespace
+
+// ================================================================================================== C ABI
+extern "C" {
+
+int tnsx_version(void) { return TNSX_VERSION; }
+
+tnsx_status tnsx_default_options(tnsx_options* opt)
+{
+	if (!opt) return TNSX_ERR_INVALID;
+	std::memset(opt, 0, sizeof(*opt));
+	opt->device_id = -1;
+	opt->stream = nullptr;
+	opt->arith = TNSX_ARITH_STRICT;
+	opt->mirror_to_host = 0;
+	opt->collect_stage_times = 0;
+	opt->max_dense_cells = 0;
+	return TNSX_OK;
+}
+
+const char* tnsx_last_error(const tnsx_context* ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
+
+tnsx_status tnsx_create(const tnsx_options* opt, tnsx_context** out)
+{
+	if (!out) return TNSX_ERR_INVALID;
+	*out = nullptr;
+	int n_dev = 0;
+	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+		g_create_error = "tnsx_create: no HIP device available (this engine has no CPU fallback)";
+		return TNSX_ERR_NO_DEVICE;
+	}
+	tnsx_context* c = new tnsx_context();
+	if (opt) c->opt = *opt; else tnsx_default_options(&c->opt);
+	if (c->opt.max_dense_cells == 0) c->opt.max_dense_cells = (uint64_t)1 << 26;
+	int dev = c->opt.device_id;
+	if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+	if (dev >= n_dev) { g_create_error = "tnsx_create: device_id out of range"; delete c; return TNSX_ERR_NO_DEVICE; }
+	if (hipSetDevice(dev) != hipSuccess) { g_create_error = "tnsx_create: hipSetDevice failed"; delete c; return TNSX_ERR_HIP; }
+	c->device = dev;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+		c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+		if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+			g_create_error = std::string("tnsx_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+			delete c;
+			return TNSX_ERR_NO_DEVICE;
+		}
+	}
+	if (c->opt.stream) { c->stream = (hipStream_t)c->opt.stream; c->own_stream = false; }
+	else {
+		if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "tnsx_create: hipStreamCreate failed"; delete c; return TNSX_ERR_HIP; }
+		c->own_stream = true;
+	}
+	*out = c;
+	return TNSX_OK;
+}
+
+void tnsx_destroy(tnsx_context* c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+	if (c->own_stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+// ------------------------------------------------------------------------------------------------ sets
+int tnsx_add_point_set(tnsx_context* c, const void* xyz, const void* radii, int n, unsigned flags)
+{
+	if (!c) return -TNSX_ERR_INVALID;
+	if (n < 0) { c->last_error = "add_point_set: n_points < 0"; return -TNSX_ERR_INVALID; }
+	new_point_set(c);
+	PointSet& s = c->sets.back();
+	s.user_xyz = xyz; s.user_radii = radii; s.n = n;
+	s.is_double = (flags & TNSX_F64) != 0;
+	s.on_device = (flags & TNSX_DEVICE) != 0;
+	s.has_radii = radii != nullptr || false;
+	// a set declared through the radii overload is a variable-radius set even when n == 0 and radii == nullptr
+	// (tests.cpp:453 hands null pointers for empty sets); the caller flags that case with TNSX_VARIABLE.
+	if (flags & TNSX_VARIABLE) s.has_radii = true;
+	if (s.has_radii) c->n_sets_with_radii++;
+	return (int)c->sets.size() - 1;
+}
+
+tnsx_status tnsx_resize_point_set(tnsx_context* c, int set_id, const void* xyz, const void* radii, int n, unsigned flags)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	if (!set_ok(c, set_id)) TNSX_FAIL(c, TNSX_ERR_INVALID, "TreeNSearch::resize_point_set error: Cannot resize a set that was not previously added.");
+	if (n < 0) TNSX_FAIL(c, TNSX_ERR_INVALID, "resize_point_set: n_points < 0");
+	PointSet& s = c->sets[set_id];
+	const bool with_radii = radii != nullptr || (flags & TNSX_VARIABLE);
+	if (with_radii && c->n_sets_with_radii == 0) {
+		TNSX_FAIL(c, TNSX_ERR_INVALID, "TreeNSearch::resize_point_set error: Cannot resize a set with a radii array if it previously didn't have one.");
+	}
+	s.user_xyz = xyz; s.n = n;
+	if (with_radii) s.user_radii = radii;
+	s.is_double = (flags & TNSX_F64) != 0;
+	s.on_device = (flags & TNSX_DEVICE) != 0;
+	s.zsort_ready = false;
+	return TNSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ config
+tnsx_status tnsx_set_search_radius(tnsx_context* c, float r)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	if (c->n_sets_with_radii > 0) {
+		TNSX_FAIL(c, TNSX_ERR_INVALID, "tns::TreeNSearch::set_search_radius error: Cannot set a global search radius if a set with a radii array was already added.");
+	}
+	c->radius_set = true;
+	c->radius = r;
+	c->radius_sq = r * r;   // TreeNSearch.cpp:29, fp32
+	return TNSX_OK;
+}
+tnsx_status tnsx_set_cell_size(tnsx_context* c, float cell_size)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	if (c->cell_size > 0.0f) {
+		TNSX_FAIL(c, TNSX_ERR_INVALID, "tns::TreeNSearch::set_cell_size error: Cell size already set. Create a new TreeNSearch instance if you need a different cell_size.");
+	}
+	c->cell_size = cell_size;
+	c->cell_size_inv = 1.0f / cell_size;
+	return TNSX_OK;
+}
+tnsx_status tnsx_set_symmetric_search(tnsx_context* c, int active) { if (!c) return TNSX_ERR_INVALID; c->symmetric = active != 0; return TNSX_OK; }
+tnsx_status tnsx_set_arithmetic(tnsx_context* c, int arith)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	if (arith != TNSX_ARITH_STRICT && arith != TNSX_ARITH_CONTRACTED) TNSX_FAIL(c, TNSX_ERR_INVALID, "set_arithmetic: unknown mode %d", arith);
+	c->opt.arith = arith;
+	return TNSX_OK;
+}
+tnsx_status tnsx_set_active_search(tnsx_context* c, int i, int j, int active)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	if (!set_ok(c, i) || !set_ok(c, j)) TNSX_FAIL(c, TNSX_ERR_INVALID, "set_active_search: set does not exist (%d, %d)", i, j);
+	c->active[i][j] = active != 0;
+	return TNSX_OK;
+}
+tnsx_status tnsx_set_active_search_all(tnsx_context* c, int i, int search_in_all, int be_found_by_all)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	if (!set_ok(c, i)) TNSX_FAIL(c, TNSX_ERR_INVALID, "set_active_search: set does not exist (%d)", i);
+	// column first, then row (TreeNSearch.cpp:223-232)
+	for (size_t j = 0; j < c->sets.size(); j++) c->active[j][i] = be_found_by_all != 0;
+	for (size_t j = 0; j < c->sets.size(); j++) c->active[i][j] = search_in_all != 0;
+	return TNSX_OK;
+}
+tnsx_status tnsx_set_all_searches(tnsx_context* c, int active)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	for (auto& row : c->active) for (auto& v : row) v = active != 0;
+	return TNSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ getters
+int tnsx_get_n_sets(const tnsx_context* c) { return c ? (int)c->sets.size() : 0; }
+int tnsx_get_n_points_in_set(const tnsx_context* c, int s) { return (c && set_ok(c, s)) ? c->sets[s].n : -1; }
+int64_t tnsx_get_total_n_points(const tnsx_context* c)
+{
+	int64_t t = 0;
+	if (c) for (const PointSet& s : c->sets) t += s.n;
+	return t;
+}
+int tnsx_is_search_active(const tnsx_context* c, int i, int j) { return (c && set_ok(c, i) && set_ok(c, j)) ? (int)c->active[i][j] : 0; }
+int tnsx_does_set_exist(const tnsx_context* c, int s) { return (c && s < (int)c->sets.size()) ? 1 : 0; }   // TreeNSearch.cpp:215-218
+uint64_t tnsx_get_neighborlist_n_bytes(const tnsx_context* c)
+{
+	uint64_t b = 0;
+	if (c) for (const PairResult& p : c->pairs) if (p.valid) b += p.n_records * sizeof(int);
+	return b;
+}
+
+// ------------------------------------------------------------------------------------------------ run
+enum Stage { ST_UPLOAD, ST_BOUNDS, ST_KEYS, ST_SORT, ST_GATHER, ST_CELLS, ST_COUNT, ST_SCAN, ST_FILL, ST_MIRROR, ST_N };
+
+tnsx_status tnsx_run(tnsx_context* c)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
+	StageTimer tm(c);
+	struct Span { int stage, a, b; };
+	std::vector<Span> spans;
+	auto span = [&](int stage, int a, int b) { if (a >= 0 && b >= 0) spans.push_back({ stage, a, b }); };
+
+	const int n_sets = (int)c->sets.size();
+	hipStream_t st = c->stream;
+	tnsx_stats& S = c->stats;
+	std::memset(&S, 0, sizeof(S));
+	S.n_sets = n_sets;
+	c->ran = false;
+
+	const int e_begin = tm.mark();
+	// ---- inputs -> device floats
+	{ const tnsx_status r = stage_inputs(c); if (r != TNSX_OK) return r; }
+	const int e_up = tm.mark();
+	span(ST_UPLOAD, e_begin, e_up);
+
+	// ---- bounds (tight AABB, radius range) -> host
+	float b8[8];
+	{ const tnsx_status r = compute_bounds(c, b8); if (r != TNSX_OK) return r; }
+	const int e_bounds = tm.mark();
+	span(ST_BOUNDS, e_up, e_bounds);
+	{ const tnsx_status r = setup_and_check(c, b8); if (r != TNSX_OK) return r; }
+
+	// ---- result slots (TreeNSearch.cpp:393-413)
+	c->pairs.resize((size_t)n_sets * n_sets);
+	for (PairResult& p : c->pairs) { p.valid = false; p.mirrored = false; }
+	c->n_sets_at_last_run = n_sets;
+
+	int64_t n_total = 0;
+	for (const PointSet& s : c->sets) n_total += s.n;
+	S.n_points = (uint64_t)n_total;
+
+	// ---- world box of the reference semantics (kept for zsort + the 2^15 cells/dimension limit)
+	if (n_total > 0) { const tnsx_status r = update_world_box(c, b8); if (r != TNSX_OK) return r; }
+	for (int d = 0; d < 3; d++) { S.world_bottom[d] = c->world[d]; S.world_top[d] = c->world[3 + d]; }
+	S.world_cells_pow2 = c->world_cells_pow2;
+
+	const bool variable = !c->radius_set;
+	const float r_max = variable ? b8[7] : c->radius;
+	if (n_total > 0 && !(r_max > 0.0f)) TNSX_FAIL(c, TNSX_ERR_CONFIG, "TreeNSearch error: search radius must be > 0");
+
+	// ---- search grid: cell edge h >= r_max with a margin that covers the fp32 rounding of the binning, so that any
+	//      pair the fp32 predicate can accept lies in adjacent cells.  Coarsened until the dense table fits.
+	tnsx::GridParams g{};
+	uint64_t n_cells = 1;
+	if (n_total > 0) {
+		const double ext[3] = { (double)b8[3] - b8[0], (double)b8[4] - b8[1], (double)b8[5] - b8[2] };
+		const double max_ext = std::max(ext[0], std::max(ext[1], ext[2]));
+		const double n0 = std::floor(max_ext / (double)r_max) + 2.0;
+		double h = (double)r_max * (1.0 + 8.0 * 5.9604644775390625e-08 * (n0 + 2.0)) * (1.0 + 1e-6);
+		for (;;) {
+			const double nx = std::floor(ext[0] / h) + 1.0, ny = std::floor(ext[1] / h) + 1.0, nz = std::floor(ext[2] / h) + 1.0;
+			if (nx * ny * nz <= (double)c->opt.max_dense_cells && nx < 2.0e9 && ny < 2.0e9 && nz < 2.0e9) {
+				g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz;
+				break;
+			}
+			h *= 1.26;
+		}
+		g.ox = b8[0]; g.oy = b8[1]; g.oz = b8[2];
+		float hf = (float)h;
+		if ((double)hf < h) hf = std::nextafter(hf, FLT_MAX);
+		g.inv_h = 1.0f / hf;
+		if ((double)g.inv_h * (double)hf > 1.0) g.inv_h = std::nextafter(g.inv_h, 0.0f);   // never overestimate 1/h
+		n_cells = (uint64_t)g.nx * g.ny * g.nz;
+		S.grid_cell_size = hf;
+	}
+	else { g.nx = g.ny = g.nz = 1; g.inv_h = 1.0f; }
+	S.grid_dims[0] = g.nx; S.grid_dims[1] = g.ny; S.grid_dims[2] = g.nz;
+	S.n_grid_cells = n_cells;
+	const int key_bits = std::max(1, ceil_log2_u64(n_cells));
+	S.key_bits = key_bits;
+	S.radix_passes = (key_bits + 7) / 8;
+
+	// ---- per set: keys -> sort -> gather -> cell table
+	HIPCHK(c, c->n_occ.reserve(sizeof(uint32_t) * (size_t)std::max(n_sets, 1)));
+	HIPCHK(c, hipMemsetAsync(c->n_occ.p, 0, sizeof(uint32_t) * (size_t)std::max(n_sets, 1), st));
+	for (int si = 0; si < n_sets; si++) {
+		PointSet& s = c->sets[si];
+		// the table is needed even for empty sets (they can be searched into)
+		HIPCHK(c, s.table.reserve(n_cells * sizeof(uint2)));
+		HIPCHK(c, s.occ.reserve((size_t)std::max(s.n, 1) * sizeof(uint32_t)));
+		HIPCHK(c, s.keys[0].reserve((size_t)std::max(s.n, 1) * sizeof(uint32_t)));
+		const int t0 = tm.mark();
+		HIPCHK(c, hipMemsetAsync(s.table.p, 0, n_cells * sizeof(uint2), st));
+		if (s.n == 0) continue;
+		for (int k = 0; k < 2; k++) { HIPCHK(c, s.keys[k].reserve((size_t)s.n * sizeof(uint32_t))); HIPCHK(c, s.idx[k].reserve((size_t)s.n * sizeof(uint32_t))); }
+		HIPCHK(c, s.xyzi.reserve((size_t)s.n * sizeof(float4)));
+		if (variable) HIPCHK(c, s.r2.reserve((size_t)s.n * sizeof(float)));
+		HIPCHK(c, c->sort_temp.reserve(tnsx::radix_temp_bytes(s.n)));
+		tnsx::launch_cell_keys(s.d_xyz, s.n, g, s.keys[0].as<uint32_t>(), s.idx[0].as<uint32_t>(), st);
+		const int t1 = tm.mark();
+		uint32_t* kk[2] = { s.keys[0].as<uint32_t>(), s.keys[1].as<uint32_t>() };
+		uint32_t* vv[2] = { s.idx[0].as<uint32_t>(), s.idx[1].as<uint32_t>() };
+		s.sorted_buf = tnsx::radix_sort_pairs_u32(kk, vv, s.n, key_bits, c->sort_temp.p, st);
+		const int t2 = tm.mark();
+		tnsx::launch_gather_sorted(s.d_xyz, variable ? s.d_radii : nullptr, vv[s.sorted_buf], s.n, s.xyzi.as<float4>(),
+		                           variable ? s.r2.as<float>() : nullptr, st);
+		const int t3 = tm.mark();
+		tnsx::launch_cell_table(kk[s.sorted_buf], s.n, s.table.as<uint2>(), s.occ.as<uint32_t>(), c->n_occ.as<uint32_t>() + si, st);
+		const int t4 = tm.mark();
+		span(ST_KEYS, t0, t1); span(ST_SORT, t1, t2); span(ST_GATHER, t2, t3); span(ST_CELLS, t3, t4);
+	}
+
+	// ---- per active pair: count -> scan
+	struct Job { int i, j; };
+	std::vector<Job> jobs;
+	for (int i = 0; i < n_sets; i++) for (int j = 0; j < n_sets; j++) if (c->active[i][j]) jobs.push_back({ i, j });
+	HIPCHK(c, c->h_small.reserve(sizeof(uint64_t) * (jobs.size() + 1) + sizeof(uint32_t) * (size_t)(n_sets + 1) + 64));
+	uint64_t* h_totals = c->h_small.as<uint64_t>();
+	uint32_t* h_nocc = reinterpret_cast<uint32_t*>(h_totals + jobs.size() + 1);
+
+	auto make_args = [&](const Job& jb, PairResult& pr) {
+		const PointSet& A = c->sets[jb.i];
+		const PointSet& B = c->sets[jb.j];
+		tnsx::QueryArgs a{};
+		a.occ_i = A.occ.as<uint32_t>(); a.n_occ_i = c->n_occ.as<uint32_t>() + jb.i;
+		a.keys_i = A.keys[A.sorted_buf].as<uint32_t>(); a.table_i = A.table.as<uint2>();
+		a.xyzi_i = A.xyzi.as<float4>(); a.r2_i = A.r2.as<float>();
+		a.table_j = B.table.as<uint2>(); a.xyzi_j = B.xyzi.as<float4>(); a.r2_j = B.r2.as<float>();
+		a.r2_fixed = c->radius_sq;
+		a.g = g;
+		a.counts = pr.counts.as<uint32_t>();
+		a.offs_sorted = pr.offs_sorted.as<uint64_t>();
+		a.records = pr.records.as<int>();
+		a.offs_by_orig = pr.offs_orig.as<uint64_t>();
+		return a;
+	};
+	tnsx::QueryConfig qc{};
+	qc.arith = c->opt.arith;
+	qc.variable = variable;
+	qc.symmetric = variable && c->symmetric;   // TreeNSearch.cpp:2431
+
+	for (size_t k = 0; k < jobs.size(); k++) {
+		const Job& jb = jobs[k];
+		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
+		const int n_i = c->sets[jb.i].n;
+		pr.n_i = n_i;
+		HIPCHK(c, pr.counts.reserve((size_t)std::max(n_i, 1) * sizeof(uint32_t)));
+		HIPCHK(c, pr.offs_sorted.reserve(((size_t)n_i + 1) * sizeof(uint64_t)));
+		HIPCHK(c, pr.offs_orig.reserve((size_t)std::max(n_i, 1) * sizeof(uint64_t)));
+		HIPCHK(c, c->scan_temp.reserve(tnsx::scan_temp_bytes((size_t)n_i)));
+		const int t0 = tm.mark();
+		if (n_i > 0) {
+			qc.self = jb.i == jb.j; qc.fill = false;
+			tnsx::launch_query(make_args(jb, pr), qc, c->n_cus, st);
+		}
+		const int t1 = tm.mark();
+		tnsx::exclusive_scan_u32_to_u64(pr.counts.as<uint32_t>(), pr.offs_sorted.as<uint64_t>(), (size_t)n_i, c->scan_temp.p, st);
+		HIPCHK(c, hipMemcpyAsync(h_totals + k, pr.offs_sorted.as<uint64_t>() + n_i, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+		const int t2 = tm.mark();
+		span(ST_COUNT, t0, t1); span(ST_SCAN, t1, t2);
+	}
+	HIPCHK(c, hipMemcpyAsync(h_nocc, c->n_occ.p, sizeof(uint32_t) * (size_t)std::max(n_sets, 1), hipMemcpyDeviceToHost, st));
+	HIPCHK(c, hipStreamSynchronize(st));   // the record totals size the output allocation
+
+	// ---- fill
+	for (size_t k = 0; k < jobs.size(); k++) {
+		const Job& jb = jobs[k];
+		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
+		pr.n_records = h_totals[k];
+		HIPCHK(c, pr.records.reserve(std::max<uint64_t>(pr.n_records, 1) * sizeof(int)));
+		const int t0 = tm.mark();
+		if (pr.n_i > 0) {
+			qc.self = jb.i == jb.j; qc.fill = true;
+			tnsx::launch_query(make_args(jb, pr), qc, c->n_cus, st);
+		}
+		const int t1 = tm.mark();
+		span(ST_FILL, t0, t1);
+		pr.valid = true;
+		S.n_queries += (uint64_t)pr.n_i;
+		S.n_neighbors += pr.n_records - (uint64_t)pr.n_i;
+	}
+	for (int si = 0; si < n_sets; si++) S.n_occupied_cells += h_nocc[si];
+
+	// ---- optional pinned host mirror (what get_neighborlist needs on the CPU side)
+	const int e_m0 = tm.mark();
+	if (c->opt.mirror_to_host) {
+		for (const Job& jb : jobs) {
+			PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
+			HIPCHK(c, pr.h_offs.reserve((size_t)std::max(pr.n_i, 1) * sizeof(uint64_t)));
+			HIPCHK(c, pr.h_records.reserve(std::max<uint64_t>(pr.n_records, 1) * sizeof(int)));
+			if (pr.n_i > 0) {
+				HIPCHK(c, hipMemcpyAsync(pr.h_offs.p, pr.offs_orig.p, (size_t)pr.n_i * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+				HIPCHK(c, hipMemcpyAsync(pr.h_records.p, pr.records.p, pr.n_records * sizeof(int), hipMemcpyDeviceToHost, st));
+			}
+			pr.mirrored = true;
+		}
+	}
+	const int e_end = tm.mark();
+	span(ST_MIRROR, e_m0, e_end);
+	HIPCHK(c, hipStreamSynchronize(st));   // run() is synchronous like the reference
+
+	// ---- statistics: algorithmic bytes with the measured Q, E, C
+	{
+		const uint64_t N = S.n_points, Q = S.n_queries, E = S.n_neighbors, C = S.n_occupied_cells;
+		const uint64_t rho = variable ? 4 : 0;
+		const uint64_t P = (uint64_t)S.radix_passes;
+		S.bytes_build = (68 + rho + 16 * P) * N + 8 * C;
+		S.bytes_query = 16 * N + 16 * Q + 4 * E;
+	}
+	if (c->opt.collect_stage_times) {
+		float acc[ST_N] = { 0 };
+		for (const Span& sp : spans) acc[sp.stage] += tm.ms(sp.a, sp.b);
+		S.ms_upload = acc[ST_UPLOAD]; S.ms_bounds = acc[ST_BOUNDS]; S.ms_keys = acc[ST_KEYS]; S.ms_sort = acc[ST_SORT];
+		S.ms_gather = acc[ST_GATHER]; S.ms_cells = acc[ST_CELLS]; S.ms_count = acc[ST_COUNT]; S.ms_scan = acc[ST_SCAN];
+		S.ms_fill = acc[ST_FILL]; S.ms_mirror = acc[ST_MIRROR];
+		S.ms_total = tm.ms(e_begin, e_end);
+	}
+	c->ran = true;
+	return TNSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ results
+static tnsx_status find_pair(tnsx_context* c, int i, int j, PairResult** out)
+{
+	if (!c->ran) TNSX_FAIL(c, TNSX_ERR_STATE, "neighbour lists requested before a successful run()");
+	const int n = c->n_sets_at_last_run;
+	if (i < 0 || j < 0 || i >= n || j >= n) TNSX_FAIL(c, TNSX_ERR_INVALID, "TreeNSearch::get_neighborlist error: Set does not exist.");
+	PairResult& pr = c->pairs[(size_t)i * n + j];
+	if (!pr.valid) TNSX_FAIL(c, TNSX_ERR_STATE, "TreeNSearch::get_neighborlist error: Set pair not active.");
+	*out = &pr;
+	return TNSX_OK;
+}
+
+tnsx_status tnsx_mirror_pair_to_host(tnsx_context* c, int i, int j)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	PairResult* pr = nullptr;
+	{ const tnsx_status r = find_pair(c, i, j, &pr); if (r != TNSX_OK) return r; }
+	std::lock_guard<std::mutex> lock(c->mirror_mutex);
+	if (pr->mirrored) return TNSX_OK;
+	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
+	HIPCHK(c, pr->h_offs.reserve((size_t)std::max(pr->n_i, 1) * sizeof(uint64_t)));
+	HIPCHK(c, pr->h_records.reserve(std::max<uint64_t>(pr->n_records, 1) * sizeof(int)));
+	if (pr->n_i > 0) {
+		HIPCHK(c, hipMemcpyAsync(pr->h_offs.p, pr->offs_orig.p, (size_t)pr->n_i * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipMemcpyAsync(pr->h_records.p, pr->records.p, pr->n_records * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+	}
+	pr->mirrored = true;
+	return TNSX_OK;
+}
+
+tnsx_status tnsx_get_pair_view(tnsx_context* c, int i, int j, tnsx_csr_view* out)
+{
+	if (!c || !out) return TNSX_ERR_INVALID;
+	PairResult* pr = nullptr;
+	{ const tnsx_status r = find_pair(c, i, j, &pr); if (r != TNSX_OK) return r; }
+	out->n_points = pr->n_i;
+	out->n_records = pr->n_records;
+	out->n_neighbors = pr->n_records - (uint64_t)pr->n_i;
+	out->offsets_device = pr->offs_orig.as<uint64_t>();
+	out->records_device = pr->records.as<int>();
+	out->offsets_host = pr->mirrored ? pr->h_offs.as<uint64_t>() : nullptr;
+	out->records_host = pr->mirrored ? pr->h_records.as<int>() : nullptr;
+	return TNSX_OK;
+}
+
+tnsx_status tnsx_copy_pair(tnsx_context* c, int i, int j, uint64_t* offsets_dst, int* records_dst, int dst_on_device)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	PairResult* pr = nullptr;
+	{ const tnsx_status r = find_pair(c, i, j, &pr); if (r != TNSX_OK) return r; }
+	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
+	const hipMemcpyKind kind = dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+	if (offsets_dst && pr->n_i > 0) HIPCHK(c, hipMemcpyAsync(offsets_dst, pr->offs_orig.p, (size_t)pr->n_i * sizeof(uint64_t), kind, c->stream));
+	if (records_dst && pr->n_records > 0) HIPCHK(c, hipMemcpyAsync(records_dst, pr->records.p, pr->n_records * sizeof(int), kind, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return TNSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ zsort
+tnsx_status tnsx_prepare_zsort(tnsx_context* c)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
+	hipStream_t st = c->stream;
+	// _set_up (TreeNSearch.cpp:2584) + world box (TreeNSearch.cpp:2666)
+	{ const tnsx_status r = stage_inputs(c); if (r != TNSX_OK) return r; }
+	float b8[8];
+	{ const tnsx_status r = compute_bounds(c, b8); if (r != TNSX_OK) return r; }
+	if (c->cell_size < 0.0f) {
+		// _set_up's default (TreeNSearch.cpp:300-316); prepare_zsort does not run _check
+		if (!c->radius_set && c->n_sets_with_radii != (int)c->sets.size()) {
+			TNSX_FAIL(c, TNSX_ERR_CONFIG, "TreeNSearch error: not all point sets have per-point search radius specified.");
+		}
+		const tnsx_status r = setup_and_check(c, b8);
+		if (r != TNSX_OK) return r;
+	}
+	int64_t n_total = 0;
+	for (const PointSet& s : c->sets) n_total += s.n;
+	if (n_total > 0) { const tnsx_status r = update_world_box(c, b8); if (r != TNSX_OK) return r; }
+	const int n_pow2 = std::max(c->world_cells_pow2, 1);
+	const int bits_per_axis = std::max(1, ceil_log2_u64((uint64_t)n_pow2));
+	const int key_bits = 3 * bits_per_axis;
+
+	for (PointSet& s : c->sets) {
+		s.zsort_host.assign((size_t)s.n, 0);
+		s.zsort_ready = true;
+		if (s.n == 0) continue;
+		HIPCHK(c, c->mkeys[0].reserve((size_t)s.n * sizeof(uint64_t)));
+		HIPCHK(c, c->mkeys[1].reserve((size_t)s.n * sizeof(uint64_t)));
+		for (int k = 0; k < 2; k++) HIPCHK(c, s.idx[k].reserve((size_t)s.n * sizeof(uint32_t)));
+		HIPCHK(c, c->sort_temp.reserve(tnsx::radix_temp_bytes(s.n)));
+		HIPCHK(c, s.zsort_dev.reserve((size_t)s.n * sizeof(int)));
+		// Morton key of the point's cell on the reference grid (cell-level order, stable => deterministic)
+		tnsx::launch_morton_keys(s.d_xyz, s.n, c->world[0], c->world[1], c->world[2], c->cell_size_inv, n_pow2 - 1, c->mkeys[0].as<uint64_t>(),
+		                         s.idx[0].as<uint32_t>(), st);
+		uint64_t* kk[2] = { c->mkeys[0].as<uint64_t>(), c->mkeys[1].as<uint64_t>() };
+		uint32_t* vv[2] = { s.idx[0].as<uint32_t>(), s.idx[1].as<uint32_t>() };
+		const int res = tnsx::radix_sort_pairs_u64(kk, vv, s.n, key_bits, c->sort_temp.p, st);
+		HIPCHK(c, hipMemcpyAsync(s.zsort_dev.p, vv[res], (size_t)s.n * sizeof(int), hipMemcpyDeviceToDevice, st));
+		HIPCHK(c, hipMemcpyAsync(s.zsort_host.data(), vv[res], (size_t)s.n * sizeof(int), hipMemcpyDeviceToHost, st));
+		HIPCHK(c, hipStreamSynchronize(st));
+	}
+	// idx[] of the search structures was reused as scratch: results of the previous run() stay valid (they do not
+	// depend on it), but the next run() rebuilds everything anyway.
+	return TNSX_OK;
+}
+
+tnsx_status tnsx_get_zsort_order(tnsx_context* c, int set_i, const int** host, const int** dev, int* n)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	if (!set_ok(c, set_i)) TNSX_FAIL(c, TNSX_ERR_INVALID, "tns::TreeNSearch::apply_zsort error: set to z_sort does not exit.");
+	PointSet& s = c->sets[set_i];
+	if (!s.zsort_ready) TNSX_FAIL(c, TNSX_ERR_STATE, "tns::TreeNSearch::apply_zsort error: no zsort order ready for set_i (%d).", set_i);
+	if (host) *host = s.zsort_host.data();
+	if (dev) *dev = s.zsort_dev.as<int>();
+	if (n) *n = (int)s.zsort_host.size();
+	return TNSX_OK;
+}
+
+tnsx_status tnsx_apply_zsort(tnsx_context* c, int set_i, void* data, size_t elem_bytes, int stride, int on_device)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	if (!set_ok(c, set_i)) TNSX_FAIL(c, TNSX_ERR_INVALID, "tns::TreeNSearch::apply_zsort error: set to z_sort does not exit.");
+	PointSet& s = c->sets[set_i];
+	if (!s.zsort_ready) TNSX_FAIL(c, TNSX_ERR_STATE, "tns::TreeNSearch::apply_zsort error: no zsort order ready for set_i (%d).", set_i);
+	const int n = (int)s.zsort_host.size();
+	if (n == 0 || stride <= 0 || elem_bytes == 0) return TNSX_OK;
+	if (!data) TNSX_FAIL(c, TNSX_ERR_INVALID, "apply_zsort: null data pointer");
+	const size_t rec = elem_bytes * (size_t)stride;
+	if (on_device) {
+		if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
+		HIPCHK(c, c->permute_tmp.reserve(rec * (size_t)n));
+		HIPCHK(c, hipMemcpyAsync(c->permute_tmp.p, data, rec * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+		tnsx::launch_permute_bytes(c->permute_tmp.p, data, s.zsort_dev.as<int>(), n, rec, c->stream);
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+	}
+	else {
+		// user memory on the host: plain gather through a swap buffer, as TreeNSearch.h:456-480 does
+		std::vector<unsigned char> swap((const unsigned char*)data, (const unsigned char*)data + rec * (size_t)n);
+		unsigned char* dst = (unsigned char*)data;
+		const int* map = s.zsort_host.data();
+		for (int i = 0; i < n; i++) std::memcpy(dst + rec * (size_t)i, swap.data() + rec * (size_t)map[i], rec);
+	}
+	return TNSX_OK;
+}
+
+tnsx_status tnsx_get_stats(const tnsx_context* c, tnsx_stats* out)
+{
+	if (!c || !out) return TNSX_ERR_INVALID;
+	*out = c->stats;
+	return TNSX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,79 @@
+// Internal launcher interface between the host engine (tnsx_engine.cpp) and the gfx950 kernels
+// (tnsx_kernels.hip).  Not part of the public ABI (that is include/tnsx.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace tnsx {
+
+// Search grid: cells of edge h >= r_max (with an fp-rounding safety margin), row-major keys with x fastest:
+// key = (iz*ny + iy)*nx + ix, so the three x-neighbours of a row are contiguous in sorted order.
+struct GridParams {
+	float ox, oy, oz;   // origin = tight minimum of all points
+	float inv_h;        // 1/h (fp32, rounded)
+	int nx, ny, nz;
+};
+
+// ---- elementwise ------------------------------------------------------------------------------
+void launch_f64_to_f32(const double* in, float* out, size_t n, hipStream_t s);
+
+// ---- bounds: {min xyz, max xyz, min r, max r} ---------------------------------------------------
+int  bounds_num_blocks(int n);
+void launch_bounds_partial(const float* xyz, const float* radii, int n, float* partials /*[nb*8]*/, hipStream_t s);
+void launch_bounds_final(const float* partials, int n_partials, float* out8, hipStream_t s);
+
+// ---- keys ---------------------------------------------------------------------------------------
+void launch_cell_keys(const float* xyz, int n, GridParams g, uint32_t* keys, uint32_t* idx, hipStream_t s);
+// Morton keys of the reference grid (TreeNSearch.cpp:713-715 quantisation, libmorton bit order)
+void launch_morton_keys(const float* xyz, int n, float bx, float by, float bz, float cell_size_inv, int max_coord,
+                        uint64_t* keys, uint32_t* idx, hipStream_t s);
+
+// ---- LSD radix sort of (key, value) pairs; stable ------------------------------------------------
+size_t radix_temp_bytes(int n);
+// sorts `key_bits` low bits.  Buffers ping-pong between [0] and [1]; returns the index holding the result.
+int radix_sort_pairs_u32(uint32_t* keys[2], uint32_t* vals[2], int n, int key_bits, void* temp, hipStream_t s);
+int radix_sort_pairs_u64(uint64_t* keys[2], uint32_t* vals[2], int n, int key_bits, void* temp, hipStream_t s);
+
+// ---- exclusive scans ----------------------------------------------------------------------------
+size_t scan_temp_bytes(size_t n);
+void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* temp, hipStream_t s);          // out[n]
+void exclusive_scan_u32_to_u64(const uint32_t* in, uint64_t* out, size_t n, void* temp, hipStream_t s);   // out[n+1], out[n]=total
+
+// ---- gather into sorted order: xyzi[p] = (x,y,z, bits(idx[p])), r2[p] = r*r ------------------------
+void launch_gather_sorted(const float* xyz, const float* radii, const uint32_t* idx_sorted, int n, float4* xyzi,
+                          float* r2, hipStream_t s);
+
+// ---- cell table: table[key] = (first sorted position, one past last), occ = sorted positions of the
+//      first point of every occupied cell (unordered), *n_occ = their number (must be zeroed before) ----
+void launch_cell_table(const uint32_t* keys_sorted, int n, uint2* table, uint32_t* occ, uint32_t* n_occ, hipStream_t s);
+
+// ---- the query ----------------------------------------------------------------------------------
+struct QueryArgs {
+	// query set i
+	const uint32_t* occ_i; const uint32_t* n_occ_i; const uint32_t* keys_i; const uint2* table_i;
+	const float4* xyzi_i; const float* r2_i;
+	// candidate set j
+	const uint2* table_j; const float4* xyzi_j; const float* r2_j;
+	float r2_fixed;
+	GridParams g;
+	// count pass: counts[p] = n_neighbours + 1 (record length), by sorted position of set i
+	uint32_t* counts;
+	// fill pass
+	const uint64_t* offs_sorted;   // exclusive scan of counts
+	int* records;                  // [count, j...] records
+	uint64_t* offs_by_orig;        // offsets by original index of set i
+};
+struct QueryConfig {
+	int arith;       // 0 strict, 1 contracted
+	bool variable;   // per-point radii
+	bool symmetric;  // d2 <= r_i^2 || d2 <= r_j^2 (only meaningful with variable)
+	bool self;       // set_i == set_j: exclude the point itself
+	bool fill;       // false: count pass, true: fill pass
+};
+void launch_query(const QueryArgs& a, const QueryConfig& c, int n_compute_units, hipStream_t s);
+
+// ---- permutation of byte records: out[new] = in[perm[new]] ------------------------------------------
+void launch_permute_bytes(const void* in, void* out, const int* new_to_old, int n, size_t rec_bytes, hipStream_t s);
+
+}  // namespace tnsx

@@ -1,0 +1,672 @@
+// gfx950 (MI355X, CDNA4) kernels of the fixed-radius neighbour search engine.
+//
+// Everything here is sort / bin / compare-and-compact work bounded by HBM bandwidth and VALU issue; no MFMA.
+// Wave = 64 lanes everywhere.  Compiled with -ffp-contract=off: the distance arithmetic is spelled with
+// explicit round-to-nearest intrinsics so that the neighbour predicate is bit-identical to the reference
+// (TreeNSearch.cpp:2478-2486 / BruteforceNSearch.cpp:88) in either arithmetic mode.
+#include "tnsx_kernels.h"
+
+#include <cfloat>
+
+namespace tnsx {
+
+static constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
+{
+	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ float readlane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ void wave_lds_fence()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// =====================================================================================================
+// f64 -> f32 staging (TreeNSearch.cpp:277-296: `(float)` cast, round to nearest even)
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_f64_to_f32(const double* __restrict__ in, float* __restrict__ out, size_t n)
+{
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = __double2float_rn(in[i]);
+}
+void launch_f64_to_f32(const double* in, float* out, size_t n, hipStream_t s)
+{
+	if (!n) return;
+	const int blocks = (int)((n + 256 * 8 - 1) / (256 * 8) < 4096 ? (n + 256 * 8 - 1) / (256 * 8) : 4096);
+	hipLaunchKernelGGL(k_f64_to_f32, dim3(blocks), dim3(256), 0, s, in, out, n);
+}
+
+// =====================================================================================================
+// bounds: tight AABB (TreeNSearch.cpp:432-472) + min/max radius (TreeNSearch.cpp:304-313, :831-834)
+// =====================================================================================================
+static constexpr int BOUNDS_THREADS = 256;
+static constexpr int BOUNDS_MAX_BLOCKS = 1024;
+int bounds_num_blocks(int n)
+{
+	const int b = (n + BOUNDS_THREADS * 16 - 1) / (BOUNDS_THREADS * 16);
+	return b < 1 ? 1 : (b > BOUNDS_MAX_BLOCKS ? BOUNDS_MAX_BLOCKS : b);
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+	#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, WAVE));
+	return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+	#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+	return v;
+}
+__device__ void block_reduce_write8(float (&v)[8], float* out)
+{
+	// v[0..2] min xyz, v[3..5] max xyz, v[6] min r, v[7] max r
+	__shared__ float sh[BOUNDS_THREADS / WAVE][8];
+	#pragma unroll
+	for (int k = 0; k < 8; k++) v[k] = (k < 3 || k == 6) ? wave_min(v[k]) : wave_max(v[k]);
+	const int w = threadIdx.x / WAVE;
+	if (lane_id() == 0) {
+		#pragma unroll
+		for (int k = 0; k < 8; k++) sh[w][k] = v[k];
+	}
+	__syncthreads();
+	if (threadIdx.x < 8) {
+		const int k = threadIdx.x;
+		float r = sh[0][k];
+		for (int ww = 1; ww < BOUNDS_THREADS / WAVE; ww++) r = (k < 3 || k == 6) ? fminf(r, sh[ww][k]) : fmaxf(r, sh[ww][k]);
+		out[k] = r;
+	}
+}
+__global__ void __launch_bounds__(BOUNDS_THREADS) k_bounds_partial(const float* __restrict__ xyz, const float* __restrict__ radii, int n,
+                                                                   float* __restrict__ partials)
+{
+	float v[8] = { FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX, FLT_MAX, -FLT_MAX };
+	for (int i = blockIdx.x * BOUNDS_THREADS + threadIdx.x; i < n; i += gridDim.x * BOUNDS_THREADS) {
+		const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+		v[0] = fminf(v[0], x); v[1] = fminf(v[1], y); v[2] = fminf(v[2], z);
+		v[3] = fmaxf(v[3], x); v[4] = fmaxf(v[4], y); v[5] = fmaxf(v[5], z);
+		if (radii) { const float r = radii[i]; v[6] = fminf(v[6], r); v[7] = fmaxf(v[7], r); }
+	}
+	block_reduce_write8(v, partials + 8 * (size_t)blockIdx.x);
+}
+__global__ void __launch_bounds__(BOUNDS_THREADS) k_bounds_final(const float* __restrict__ partials, int n_partials, float* __restrict__ out8)
+{
+	float v[8] = { FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX, FLT_MAX, -FLT_MAX };
+	for (int i = threadIdx.x; i < n_partials; i += BOUNDS_THREADS) {
+		#pragma unroll
+		for (int k = 0; k < 8; k++) v[k] = (k < 3 || k == 6) ? fminf(v[k], partials[8 * (size_t)i + k]) : fmaxf(v[k], partials[8 * (size_t)i + k]);
+	}
+	block_reduce_write8(v, out8);
+}
+void launch_bounds_partial(const float* xyz, const float* radii, int n, float* partials, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_bounds_partial, dim3(bounds_num_blocks(n)), dim3(BOUNDS_THREADS), 0, s, xyz, radii, n, partials);
+}
+void launch_bounds_final(const float* partials, int n_partials, float* out8, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(BOUNDS_THREADS), 0, s, partials, n_partials, out8);
+}
+
+// =====================================================================================================
+// keys
+// =====================================================================================================
+__device__ __forceinline__ int cell_coord(float p, float o, float inv_h, int n)
+{
+	// fp32 sub, mul, truncate -- the same quantisation form as TreeNSearch.cpp:713-715
+	const float f = __fmul_rn(__fsub_rn(p, o), inv_h);
+	int c = (int)f;
+	c = c < 0 ? 0 : c;
+	return c > n - 1 ? n - 1 : c;
+}
+__global__ void __launch_bounds__(256) k_cell_keys(const float* __restrict__ xyz, int n, GridParams g, uint32_t* __restrict__ keys,
+                                                  uint32_t* __restrict__ idx)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	const int ix = cell_coord(xyz[3 * (size_t)i], g.ox, g.inv_h, g.nx);
+	const int iy = cell_coord(xyz[3 * (size_t)i + 1], g.oy, g.inv_h, g.ny);
+	const int iz = cell_coord(xyz[3 * (size_t)i + 2], g.oz, g.inv_h, g.nz);
+	keys[i] = (uint32_t)((iz * g.ny + iy) * g.nx + ix);
+	idx[i] = (uint32_t)i;
+}
+void launch_cell_keys(const float* xyz, int n, GridParams g, uint32_t* keys, uint32_t* idx, hipStream_t s)
+{
+	if (n <= 0) return;
+	hipLaunchKernelGGL(k_cell_keys, dim3((n + 255) / 256), dim3(256), 0, s, xyz, n, g, keys, idx);
+}
+
+__device__ __forceinline__ uint64_t spread3(uint64_t v)
+{
+	v &= 0x1fffffull;
+	v = (v | (v << 32)) & 0x1f00000000ffffull;
+	v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+	v = (v | (v << 8)) & 0x100f00f00f00f00full;
+	v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+	v = (v | (v << 2)) & 0x1249249249249249ull;
+	return v;
+}
+__global__ void __launch_bounds__(256) k_morton_keys(const float* __restrict__ xyz, int n, float bx, float by, float bz, float inv, int max_coord,
+                                                    uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	// (uint)((p - bottom) * cell_size_inv), TreeNSearch.cpp:713-715 / :2694-2696; x -> bit 0, y -> bit 1, z -> bit 2 (libmorton)
+	const uint32_t ux = (uint32_t)cell_coord(xyz[3 * (size_t)i], bx, inv, max_coord + 1);
+	const uint32_t uy = (uint32_t)cell_coord(xyz[3 * (size_t)i + 1], by, inv, max_coord + 1);
+	const uint32_t uz = (uint32_t)cell_coord(xyz[3 * (size_t)i + 2], bz, inv, max_coord + 1);
+	keys[i] = spread3(ux) | (spread3(uy) << 1) | (spread3(uz) << 2);
+	idx[i] = (uint32_t)i;
+}
+void launch_morton_keys(const float* xyz, int n, float bx, float by, float bz, float cell_size_inv, int max_coord, uint64_t* keys,
+                        uint32_t* idx, hipStream_t s)
+{
+	if (n <= 0) return;
+	hipLaunchKernelGGL(k_morton_keys, dim3((n + 255) / 256), dim3(256), 0, s, xyz, n, bx, by, bz, cell_size_inv, max_coord, keys, idx);
+}
+
+// =====================================================================================================
+// exclusive scan (reduce -> spine -> apply), tiles of 4096 elements, 16-byte vector loads
+// =====================================================================================================
+static constexpr int SCAN_THREADS = 256;
+static constexpr int SCAN_TILE = 4096;   // 4 sub-tiles of 1024 (uint4 per thread)
+
+size_t scan_temp_bytes(size_t n) { return ((n + SCAN_TILE - 1) / SCAN_TILE + 2) * sizeof(uint64_t); }
+
+__device__ __forceinline__ uint4 load4_guarded(const uint32_t* in, size_t e, size_t n)
+{
+	if (e + 3 < n) return *reinterpret_cast<const uint4*>(in + e);
+	uint4 v = { 0, 0, 0, 0 };
+	if (e < n) v.x = in[e];
+	if (e + 1 < n) v.y = in[e + 1];
+	if (e + 2 < n) v.z = in[e + 2];
+	return v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce(const uint32_t* __restrict__ in, size_t n, uint64_t* __restrict__ sums)
+{
+	__shared__ uint64_t sh[SCAN_THREADS / WAVE];
+	const size_t base = (size_t)blockIdx.x * SCAN_TILE;
+	uint64_t acc = 0;
+	#pragma unroll
+	for (int it = 0; it < 4; it++) {
+		const uint4 v = load4_guarded(in, base + (size_t)it * 1024 + threadIdx.x * 4, n);
+		acc += (uint64_t)v.x + v.y + v.z + v.w;
+	}
+	#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
+	if (lane_id() == 0) sh[threadIdx.x / WAVE] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) sums[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// single block: exclusive scan of sums[nb] in place, total -> sums[nb]
+__global__ void __launch_bounds__(1024) k_scan_spine(uint64_t* __restrict__ sums, int nb)
+{
+	__shared__ uint64_t wsum[16];
+	__shared__ uint64_t carry_sh;
+	if (threadIdx.x == 0) carry_sh = 0;
+	__syncthreads();
+	for (int base = 0; base < nb; base += 1024) {
+		const int i = base + threadIdx.x;
+		const uint64_t v = i < nb ? sums[i] : 0;
+		uint64_t inc = v;
+		#pragma unroll
+		for (int o = 1; o < WAVE; o <<= 1) { const uint64_t t = __shfl_up(inc, o, WAVE); if (lane_id() >= o) inc += t; }
+		if (lane_id() == WAVE - 1) wsum[threadIdx.x / WAVE] = inc;
+		__syncthreads();
+		uint64_t woff = 0;
+		for (int w = 0; w < (int)(threadIdx.x / WAVE); w++) woff += wsum[w];
+		const uint64_t carry = carry_sh;
+		if (i < nb) sums[i] = carry + woff + inc - v;
+		__syncthreads();
+		if (threadIdx.x == 1023) carry_sh = carry + woff + inc;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) sums[nb] = carry_sh;
+}
+
+template <typename TOut>
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(const uint32_t* __restrict__ in, TOut* __restrict__ out, size_t n,
+                                                            const uint64_t* __restrict__ sums, int nb, int write_total)
+{
+	__shared__ uint64_t wsum[SCAN_THREADS / WAVE];
+	const size_t base = (size_t)blockIdx.x * SCAN_TILE;
+	uint64_t carry = sums[blockIdx.x];
+	#pragma unroll 1
+	for (int it = 0; it < 4; it++) {
+		const size_t e = base + (size_t)it * 1024 + threadIdx.x * 4;
+		const uint4 v = load4_guarded(in, e, n);
+		const uint64_t t = (uint64_t)v.x + v.y + v.z + v.w;
+		uint64_t inc = t;
+		#pragma unroll
+		for (int o = 1; o < WAVE; o <<= 1) { const uint64_t u = __shfl_up(inc, o, WAVE); if (lane_id() >= o) inc += u; }
+		__syncthreads();   // wsum reuse
+		if (lane_id() == WAVE - 1) wsum[threadIdx.x / WAVE] = inc;
+		__syncthreads();
+		uint64_t woff = 0, tile_total = 0;
+		#pragma unroll
+		for (int w = 0; w < SCAN_THREADS / WAVE; w++) { if (w < (int)(threadIdx.x / WAVE)) woff += wsum[w]; tile_total += wsum[w]; }
+		const uint64_t ex = carry + woff + inc - t;
+		if (e < n) out[e] = (TOut)ex;
+		if (e + 1 < n) out[e + 1] = (TOut)(ex + v.x);
+		if (e + 2 < n) out[e + 2] = (TOut)(ex + v.x + v.y);
+		if (e + 3 < n) out[e + 3] = (TOut)(ex + v.x + v.y + v.z);
+		carry += tile_total;
+	}
+	if (write_total && blockIdx.x == 0 && threadIdx.x == 0) out[n] = (TOut)sums[nb];
+}
+
+template <typename TOut>
+static void scan_impl(const uint32_t* in, TOut* out, size_t n, void* temp, hipStream_t s, int write_total)
+{
+	uint64_t* sums = (uint64_t*)temp;
+	if (n == 0) {
+		if (write_total) (void)hipMemsetAsync(out, 0, sizeof(TOut), s);
+		return;
+	}
+	const int nb = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+	hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, sums);
+	hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, sums, nb);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<TOut>), dim3(nb), dim3(SCAN_THREADS), 0, s, in, out, n, sums, nb, write_total);
+}
+void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* temp, hipStream_t s) { scan_impl<uint32_t>(in, out, n, temp, s, 0); }
+void exclusive_scan_u32_to_u64(const uint32_t* in, uint64_t* out, size_t n, void* temp, hipStream_t s) { scan_impl<uint64_t>(in, out, n, temp, s, 1); }
+
+// =====================================================================================================
+// LSD radix sort, 8-bit digits, stable.  Per pass: per-block digit histogram -> scan -> ranked scatter.
+// A block owns a tile of 4096 consecutive elements; wave w owns the 1024-element sub-tile w and walks it
+// in 16 rounds of 64 consecutive elements, so (wave, round, lane) order == index order == stable order.
+// =====================================================================================================
+static constexpr int RS_BITS = 8;
+static constexpr int RS_RADIX = 1 << RS_BITS;
+static constexpr int RS_THREADS = 256;
+static constexpr int RS_ITEMS = 16;
+static constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
+
+static int rs_num_blocks(int n) { return (n + RS_TILE - 1) / RS_TILE; }
+size_t radix_temp_bytes(int n)
+{
+	const size_t hist = (size_t)RS_RADIX * rs_num_blocks(n) * sizeof(uint32_t);
+	return ((hist + 255) / 256) * 256 * 2 + scan_temp_bytes((size_t)RS_RADIX * rs_num_blocks(n)) + 256;
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(RS_THREADS) k_radix_hist(const KeyT* __restrict__ keys, int n, int shift, uint32_t* __restrict__ hist, int nblocks)
+{
+	__shared__ uint32_t h[RS_RADIX];
+	h[threadIdx.x] = 0;
+	__syncthreads();
+	const size_t base = (size_t)blockIdx.x * RS_TILE;
+	#pragma unroll
+	for (int i = 0; i < RS_ITEMS; i++) {
+		const size_t e = base + (size_t)i * RS_THREADS + threadIdx.x;
+		if (e < (size_t)n) atomicAdd(&h[(uint32_t)(keys[e] >> shift) & (RS_RADIX - 1)], 1u);
+	}
+	__syncthreads();
+	hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                             KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n, int shift,
+                                                             const uint32_t* __restrict__ hist_scanned, int nblocks)
+{
+	__shared__ uint32_t wcount[RS_THREADS / WAVE][RS_RADIX];
+	__shared__ uint32_t gbase[RS_RADIX];
+	const int w = threadIdx.x / WAVE, lane = lane_id();
+	#pragma unroll
+	for (int ww = 0; ww < RS_THREADS / WAVE; ww++) wcount[ww][threadIdx.x] = 0;
+	gbase[threadIdx.x] = hist_scanned[(size_t)threadIdx.x * nblocks + blockIdx.x];
+	__syncthreads();
+
+	KeyT key[RS_ITEMS];
+	uint32_t val[RS_ITEMS];
+	uint32_t rank[RS_ITEMS];
+	const size_t wbase = (size_t)blockIdx.x * RS_TILE + (size_t)w * (RS_ITEMS * WAVE);
+	#pragma unroll
+	for (int i = 0; i < RS_ITEMS; i++) {
+		const size_t e = wbase + (size_t)i * WAVE + lane;
+		const bool valid = e < (size_t)n;
+		key[i] = valid ? keys_in[e] : (KeyT)0;
+		val[i] = valid ? vals_in[e] : 0u;
+		const uint32_t d = (uint32_t)(key[i] >> shift) & (RS_RADIX - 1);
+		uint64_t peers = __ballot(valid);
+		#pragma unroll
+		for (int b = 0; b < RS_BITS; b++) {
+			const bool bit = (d >> b) & 1u;
+			const uint64_t m = __ballot(valid && bit);
+			peers &= bit ? m : ~m;
+		}
+		const uint32_t r = mbcnt64(peers);                 // peers in lower lanes
+		const uint32_t c = (uint32_t)__popcll(peers);
+		uint32_t prev = 0;
+		if (valid) prev = wcount[w][d];
+		wave_lds_fence();
+		if (valid && r == 0) wcount[w][d] = prev + c;
+		wave_lds_fence();
+		rank[i] = prev + r;
+	}
+	__syncthreads();
+	{
+		const int d = threadIdx.x;
+		uint32_t s = 0;
+		#pragma unroll
+		for (int ww = 0; ww < RS_THREADS / WAVE; ww++) { const uint32_t t = wcount[ww][d]; wcount[ww][d] = s; s += t; }
+	}
+	__syncthreads();
+	#pragma unroll
+	for (int i = 0; i < RS_ITEMS; i++) {
+		const size_t e = wbase + (size_t)i * WAVE + lane;
+		if (e < (size_t)n) {
+			const uint32_t d = (uint32_t)(key[i] >> shift) & (RS_RADIX - 1);
+			const uint32_t pos = gbase[d] + wcount[w][d] + rank[i];
+			keys_out[pos] = key[i];
+			vals_out[pos] = val[i];
+		}
+	}
+}
+
+template <typename KeyT>
+static int radix_sort_impl(KeyT* keys[2], uint32_t* vals[2], int n, int key_bits, void* temp, hipStream_t s)
+{
+	if (n <= 1 || key_bits <= 0) return 0;
+	const int nblocks = rs_num_blocks(n);
+	const size_t hist_elems = (size_t)RS_RADIX * nblocks;
+	const size_t hist_bytes = ((hist_elems * sizeof(uint32_t) + 255) / 256) * 256;
+	uint32_t* hist = (uint32_t*)temp;
+	uint32_t* hist_scanned = (uint32_t*)((char*)temp + hist_bytes);
+	void* scan_temp = (char*)temp + 2 * hist_bytes;
+	int cur = 0;
+	for (int shift = 0; shift < key_bits; shift += RS_BITS) {
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<KeyT>), dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], n, shift, hist, nblocks);
+		exclusive_scan_u32(hist, hist_scanned, hist_elems, scan_temp, s);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<KeyT>), dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
+		                   vals[cur ^ 1], n, shift, hist_scanned, nblocks);
+		cur ^= 1;
+	}
+	return cur;
+}
+int radix_sort_pairs_u32(uint32_t* keys[2], uint32_t* vals[2], int n, int key_bits, void* temp, hipStream_t s) { return radix_sort_impl<uint32_t>(keys, vals, n, key_bits, temp, s); }
+int radix_sort_pairs_u64(uint64_t* keys[2], uint32_t* vals[2], int n, int key_bits, void* temp, hipStream_t s) { return radix_sort_impl<uint64_t>(keys, vals, n, key_bits, temp, s); }
+
+// =====================================================================================================
+// gather into sorted order
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_gather_sorted(const float* __restrict__ xyz, const float* __restrict__ radii, const uint32_t* __restrict__ idx,
+                                                      int n, float4* __restrict__ xyzi, float* __restrict__ r2)
+{
+	const int p = blockIdx.x * 256 + threadIdx.x;
+	if (p >= n) return;
+	const uint32_t i = idx[p];
+	float4 v;
+	v.x = xyz[3 * (size_t)i]; v.y = xyz[3 * (size_t)i + 1]; v.z = xyz[3 * (size_t)i + 2];
+	v.w = __uint_as_float(i);
+	xyzi[p] = v;
+	if (radii) { const float r = radii[i]; r2[p] = __fmul_rn(r, r); }   // radii_sq = r*r in fp32, TreeNSearch.cpp:2352
+}
+void launch_gather_sorted(const float* xyz, const float* radii, const uint32_t* idx_sorted, int n, float4* xyzi, float* r2, hipStream_t s)
+{
+	if (n <= 0) return;
+	hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, s, xyz, radii, idx_sorted, n, xyzi, r2);
+}
+
+// =====================================================================================================
+// cell table + list of occupied cells
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_cell_table(const uint32_t* __restrict__ keys, int n, uint2* __restrict__ table, uint32_t* __restrict__ occ,
+                                                   uint32_t* __restrict__ n_occ)
+{
+	__shared__ uint32_t wcnt[4];
+	__shared__ uint32_t block_base;
+	const int p = blockIdx.x * 256 + threadIdx.x;
+	bool is_start = false;
+	if (p < n) {
+		const uint32_t k = keys[p];
+		is_start = (p == 0) || (keys[p - 1] != k);
+		const bool is_end = (p == n - 1) || (keys[p + 1] != k);
+		if (is_start) table[k].x = (uint32_t)p;
+		if (is_end) table[k].y = (uint32_t)p + 1u;
+	}
+	const uint64_t m = __ballot(is_start);
+	const int w = threadIdx.x / WAVE;
+	if (lane_id() == 0) wcnt[w] = (uint32_t)__popcll(m);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const uint32_t tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+		block_base = tot ? atomicAdd(n_occ, tot) : 0u;
+	}
+	__syncthreads();
+	if (is_start) {
+		uint32_t off = block_base;
+		for (int ww = 0; ww < w; ww++) off += wcnt[ww];
+		occ[off + mbcnt64(m)] = (uint32_t)p;
+	}
+}
+void launch_cell_table(const uint32_t* keys_sorted, int n, uint2* table, uint32_t* occ, uint32_t* n_occ, hipStream_t s)
+{
+	if (n <= 0) return;
+	hipLaunchKernelGGL(k_cell_table, dim3((n + 255) / 256), dim3(256), 0, s, keys_sorted, n, table, occ, n_occ);
+}
+
+// =====================================================================================================
+// the query: one wave per occupied cell of set i.
+//   * 27 neighbour cells of set j looked up by 27 lanes, merged into 9 x-contiguous runs
+//   * runs staged through a wave-private LDS tile (coalesced 16-byte loads), then held in registers,
+//     one candidate per lane per 64-slot chunk
+//   * query points of the cell broadcast lane by lane (v_readlane), every chunk tested by all 64 lanes,
+//     hits compacted with ballot + mbcnt into the CSR record of the query (fill) or just counted (count)
+// =====================================================================================================
+static constexpr int Q_THREADS = 256;
+static constexpr int Q_WAVES = Q_THREADS / WAVE;
+static constexpr int Q_CHUNKS = 8;                 // 64-slot chunks of candidates held in registers per batch
+static constexpr int Q_SLOTS = Q_CHUNKS * WAVE;
+
+template <int ARITH>
+__device__ __forceinline__ float dist_sq(float qx, float qy, float qz, float cx, float cy, float cz)
+{
+	const float dx = __fsub_rn(qx, cx);
+	const float dy = __fsub_rn(qy, cy);
+	const float dz = __fsub_rn(qz, cz);
+	if (ARITH == 0) {
+		// ((dx*dx + dy*dy) + dz*dz), every op rounded
+		return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+	}
+	else {
+		// fma(dz,dz, fma(dx,dx, dy*dy))
+		return __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
+	}
+}
+
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF, bool FILL>
+__global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = lane_id();
+	const int w = threadIdx.x / WAVE;
+	float4* cand = reinterpret_cast<float4*>(smem) + (size_t)w * Q_SLOTS;
+	float* cand_r2 = reinterpret_cast<float*>(smem + (size_t)Q_WAVES * Q_SLOTS * sizeof(float4)) + (size_t)w * Q_SLOTS;
+
+	const uint32_t n_occ = *a.n_occ_i;
+	const uint32_t n_waves = gridDim.x * Q_WAVES;
+	const int nx = a.g.nx, ny = a.g.ny, nz = a.g.nz;
+
+	for (uint32_t ci = blockIdx.x * Q_WAVES + w; ci < n_occ; ci += n_waves) {
+		const uint32_t p0 = a.occ_i[ci];
+		const uint32_t key = a.keys_i[p0];
+		const uint2 qrange = a.table_i[key];
+		const int cx = (int)(key % (uint32_t)nx);
+		const int cy = (int)((key / (uint32_t)nx) % (uint32_t)ny);
+		const int cz = (int)(key / ((uint32_t)nx * (uint32_t)ny));
+
+		// ---- 27 neighbour cells of set j -> 9 merged x-runs (lanes 0,3,..,24)
+		uint32_t s = 0, e = 0;
+		if (lane < 27) {
+			const int x = cx + (lane % 3) - 1, y = cy + ((lane / 3) % 3) - 1, z = cz + (lane / 9) - 1;
+			if (x >= 0 && x < nx && y >= 0 && y < ny && z >= 0 && z < nz) {
+				const uint2 r = a.table_j[((size_t)z * ny + y) * nx + x];
+				s = r.x; e = r.y;
+			}
+		}
+		const uint32_t s1 = __shfl_down(s, 1, WAVE), e1 = __shfl_down(e, 1, WAVE);
+		const uint32_t s2 = __shfl_down(s, 2, WAVE), e2 = __shfl_down(e, 2, WAVE);
+		const uint32_t run_start = (e > s) ? s : ((e1 > s1) ? s1 : s2);
+		const uint32_t run_end = (e2 > s2) ? e2 : ((e1 > s1) ? e1 : e);
+		const uint32_t run_len_v = run_end > run_start ? run_end - run_start : 0u;
+		uint32_t rs[9], rn[9];
+		uint32_t total = 0;
+		#pragma unroll
+		for (int r = 0; r < 9; r++) {
+			rs[r] = readlane_u32(run_start, 3 * r);
+			rn[r] = readlane_u32(run_len_v, 3 * r);
+			total += rn[r];
+		}
+
+		// ---- query points of this cell, 64 at a time
+		for (uint32_t qb = qrange.x; qb < qrange.y; qb += WAVE) {
+			const uint32_t nq = (qrange.y - qb) < (uint32_t)WAVE ? (qrange.y - qb) : (uint32_t)WAVE;
+			float4 qv = { 0.f, 0.f, 0.f, 0.f };
+			float qr2 = a.r2_fixed;
+			uint64_t my_off = 0;
+			if ((uint32_t)lane < nq) {
+				qv = a.xyzi_i[qb + lane];
+				if (VARIABLE) qr2 = a.r2_i[qb + lane];
+				if (FILL) my_off = a.offs_sorted[qb + lane];
+			}
+			uint32_t run_cnt = 0;
+
+			// ---- candidate batches of Q_SLOTS slots
+			for (uint32_t wb = 0; wb < total; wb += Q_SLOTS) {
+				wave_lds_fence();   // previous batch fully consumed before the tile is overwritten
+				uint32_t pre = 0;
+				#pragma unroll
+				for (int r = 0; r < 9; r++) {
+					const uint32_t lo = pre > wb ? pre : wb;
+					const uint32_t hi_full = pre + rn[r];
+					const uint32_t hi = hi_full < wb + Q_SLOTS ? hi_full : wb + Q_SLOTS;
+					for (uint32_t sl = lo + lane; sl < hi; sl += WAVE) {
+						const uint32_t src = rs[r] + (sl - pre);
+						cand[sl - wb] = a.xyzi_j[src];
+						if (SYM) cand_r2[sl - wb] = a.r2_j[src];
+					}
+					pre = hi_full;
+				}
+				const uint32_t nb = (total - wb) < (uint32_t)Q_SLOTS ? (total - wb) : (uint32_t)Q_SLOTS;
+				wave_lds_fence();
+				float4 c[Q_CHUNKS];
+				float cr2[Q_CHUNKS];
+				#pragma unroll
+				for (int k = 0; k < Q_CHUNKS; k++) {
+					const uint32_t slot = (uint32_t)(k * WAVE + lane);
+					if (slot < nb) {
+						c[k] = cand[slot];
+						cr2[k] = SYM ? cand_r2[slot] : 0.f;
+					}
+					else {
+						c[k] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, __uint_as_float(0xffffffffu));
+						cr2[k] = -1.0f;
+					}
+				}
+
+				// ---- every query of the batch against the register-resident candidates
+				for (uint32_t t = 0; t < nq; t++) {
+					const float qx = readlane_f32(qv.x, (int)t), qy = readlane_f32(qv.y, (int)t), qz = readlane_f32(qv.z, (int)t);
+					const uint32_t qi = readlane_u32(__float_as_uint(qv.w), (int)t);
+					const float r2 = VARIABLE ? readlane_f32(qr2, (int)t) : a.r2_fixed;
+					uint64_t base = 0;
+					if (FILL) {
+						const uint32_t lo = readlane_u32((uint32_t)my_off, (int)t), hi = readlane_u32((uint32_t)(my_off >> 32), (int)t);
+						base = (((uint64_t)hi << 32) | lo) + 1u + readlane_u32(run_cnt, (int)t);
+					}
+					uint32_t cnt = 0;
+					#pragma unroll
+					for (int k = 0; k < Q_CHUNKS; k++) {
+						if ((uint32_t)(k * WAVE) < nb) {
+							const float d2 = dist_sq<ARITH>(qx, qy, qz, c[k].x, c[k].y, c[k].z);
+							bool hit = d2 <= r2;
+							if (SYM) hit = hit || (d2 <= cr2[k]);
+							if (SELF) hit = hit && (__float_as_uint(c[k].w) != qi);
+							const uint64_t m = __ballot(hit);
+							if (FILL) {
+								if (hit) a.records[base + cnt + mbcnt64(m)] = (int)__float_as_uint(c[k].w);
+							}
+							cnt += (uint32_t)__popcll(m);
+						}
+					}
+					if ((uint32_t)lane == t) run_cnt += cnt;
+				}
+			}
+
+			if ((uint32_t)lane < nq) {
+				if (FILL) {
+					a.records[my_off] = (int)run_cnt;
+					a.offs_by_orig[__float_as_uint(qv.w)] = my_off;
+				}
+				else {
+					a.counts[qb + lane] = run_cnt + 1u;
+				}
+			}
+		}
+	}
+}
+
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF, bool FILL>
+static void launch_query_t(const QueryArgs& a, int blocks, hipStream_t s)
+{
+	const size_t lds = (size_t)Q_WAVES * Q_SLOTS * (sizeof(float4) + (SYM ? sizeof(float) : 0));
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<ARITH, VARIABLE, SYM, SELF, FILL>), dim3(blocks), dim3(Q_THREADS), lds, s, a);
+}
+template <int ARITH, bool VARIABLE, bool SYM>
+static void launch_query_2(const QueryArgs& a, const QueryConfig& c, int blocks, hipStream_t s)
+{
+	if (c.self) { if (c.fill) launch_query_t<ARITH, VARIABLE, SYM, true, true>(a, blocks, s); else launch_query_t<ARITH, VARIABLE, SYM, true, false>(a, blocks, s); }
+	else        { if (c.fill) launch_query_t<ARITH, VARIABLE, SYM, false, true>(a, blocks, s); else launch_query_t<ARITH, VARIABLE, SYM, false, false>(a, blocks, s); }
+}
+template <int ARITH>
+static void launch_query_1(const QueryArgs& a, const QueryConfig& c, int blocks, hipStream_t s)
+{
+	if (!c.variable) launch_query_2<ARITH, false, false>(a, c, blocks, s);
+	else if (c.symmetric) launch_query_2<ARITH, true, true>(a, c, blocks, s);
+	else launch_query_2<ARITH, true, false>(a, c, blocks, s);
+}
+void launch_query(const QueryArgs& a, const QueryConfig& c, int n_compute_units, hipStream_t s)
+{
+	// persistent grid: waves stride over the list of occupied cells (its length lives in device memory)
+	const int blocks = n_compute_units * 4;
+	if (c.arith == 0) launch_query_1<0>(a, c, blocks, s); else launch_query_1<1>(a, c, blocks, s);
+}
+
+// =====================================================================================================
+// permutation of fixed-size byte records (device-side apply_zsort, TreeNSearch.h:465-480)
+// =====================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) k_permute_t(const T* __restrict__ in, T* __restrict__ out, const int* __restrict__ perm, int n, int words)
+{
+	const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+	const size_t total = (size_t)n * words;
+	if (g >= total) return;
+	const size_t rec = g / words, wd = g % words;
+	out[g] = in[(size_t)perm[rec] * words + wd];
+}
+void launch_permute_bytes(const void* in, void* out, const int* new_to_old, int n, size_t rec_bytes, hipStream_t s)
+{
+	if (n <= 0 || rec_bytes == 0) return;
+	const bool aligned4 = (rec_bytes % 4 == 0) && (((uintptr_t)in | (uintptr_t)out) % 4 == 0);
+	if (aligned4) {
+		const int words = (int)(rec_bytes / 4);
+		const size_t total = (size_t)n * words;
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_permute_t<uint32_t>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const uint32_t*)in, (uint32_t*)out,
+		                   new_to_old, n, words);
+	}
+	else {
+		const int words = (int)rec_bytes;
+		const size_t total = (size_t)n * words;
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_permute_t<unsigned char>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const unsigned char*)in,
+		                   (unsigned char*)out, new_to_old, n, words);
+	}
+}
+
+}  // namespace tnsx
