@@ -68,8 +68,12 @@ typedef struct tnsx_options {
 	int mirror_to_host;       /* 1: tnsx_run also mirrors every active pair's lists into pinned host memory
 	                             (what get_neighborlist needs for CPU consumers); 0: lists stay in HBM */
 	int collect_stage_times;  /* 1: record hipEvents around every stage (tnsx_get_stats) */
+	int exact_layout;         /* 0 (default): once a pair has run, its lists are built in ONE pass into a record pool
+	                             (per-wave slabs from a device cursor; records exact and contiguous, order of records in
+	                             memory unspecified, pool has unused gaps).  1: always count -> scan -> fill, records laid
+	                             out in spatially sorted point order without gaps (deterministic, ~1.6x more query work) */
 	uint64_t max_dense_cells; /* upper bound of the dense cell table; 0 = default (2^26) */
-	int reserved[8];
+	int reserved[7];
 } tnsx_options;
 
 /* Neighbour lists of one active (set_i -> set_j) pair.  Record layout == the reference's chunk storage
@@ -77,7 +81,7 @@ typedef struct tnsx_options {
  * set-local indices into set_j, so `tns::NeighborList(records + offsets[p])` works unchanged. */
 typedef struct tnsx_csr_view {
 	int n_points;                    /* points in set_i */
-	uint64_t n_records;              /* ints in `records` = total neighbours + n_points */
+	uint64_t n_records;              /* ints of `records` in use: total neighbours + n_points (+ unused gaps in pool mode) */
 	uint64_t n_neighbors;            /* total neighbour indices */
 	const uint64_t* offsets_device;  /* [n_points] by ORIGINAL point index, HBM */
 	const int* records_device;       /* [n_records], HBM */
@@ -100,6 +104,8 @@ typedef struct tnsx_stats {
 	uint64_t bytes_build, bytes_query;
 	/* stage times in ms (0 unless collect_stage_times) */
 	float ms_total, ms_upload, ms_bounds, ms_keys, ms_sort, ms_gather, ms_cells, ms_count, ms_scan, ms_fill, ms_mirror;
+	int n_pool_pairs;             /* pairs built in single-pass pool mode in the last run */
+	int pool_retries;             /* pool passes repeated because the pool was too small */
 	/* world box of the reference semantics (TreeNSearch.cpp:415-522) */
 	float world_bottom[3], world_top[3];
 	int world_cells_pow2;

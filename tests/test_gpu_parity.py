@@ -78,3 +78,64 @@ def test_coarsened_grid_still_exact(oracle):
     res, ns = P.run_engine_case(case, 0, max_dense_cells=512)
     assert ns.get_stats()["n_grid_cells"] <= 512
     P.assert_matches_golden(res, load_golden(case.name), 0, oracle, "coarsened")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# single-pass pool mode: from the second run() on, every pair is built in one pass into a record pool
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", SMALL, ids=[c.name for c in SMALL])
+@pytest.mark.parametrize("mode", [0, 1], ids=["strict", "contracted"])
+def test_pool_mode_matches_golden(case, mode, oracle):
+    ns = P.make_engine(case, mode)
+    ns.run()                      # exact two-pass layout, sizes the pools
+    first = {pr: ns.neighbor_csr(*pr) for pr in case.active}
+    ns.run()                      # pool mode
+    st = ns.get_stats()
+    n_nonempty = sum(1 for (i, j) in case.active if len(case.points[i]) > 0)
+    assert st["n_pool_pairs"] == n_nonempty and st["pool_retries"] == 0
+    res = {pr: ns.neighbor_csr(*pr) for pr in case.active}
+    for pr in case.active:
+        P.assert_same_csr(res[pr], first[pr], f"{case.name} {pr} pool-vs-exact")
+    P.assert_matches_golden(res, load_golden(case.name), mode, oracle, case.name + " (pool)")
+    assert st["n_neighbors"] == sum(int(first[pr][0][-1]) for pr in case.active)
+
+
+def test_pool_overflow_is_detected_and_repaired(oracle):
+    """The pool is sized from the previous run; when the point set grows it overflows, the engine notices (device
+    cursor > capacity) and repeats the pass with a bigger pool.  Results stay exact."""
+    import treensearch_amd as T
+    case = CS.by_name("uniform_fixed_100000")
+    pts = case.points[0]
+    ns = T.TreeNSearch()
+    ns.set_search_radius(case.radius)
+    ns.add_point_set(pts, n_points=5000)
+    ns.set_active_search(0, 0, True)
+    ns.run()
+    ns.run()
+    assert ns.get_stats()["n_pool_pairs"] == 1
+    ns.resize_point_set(0, pts, n_points=len(pts))      # 20x more points, ~400x more neighbours
+    ns.run()
+    st = ns.get_stats()
+    assert st["n_pool_pairs"] == 1 and st["pool_retries"] >= 1
+    P.assert_matches_golden({(0, 0): ns.neighbor_csr(0, 0)}, load_golden(case.name), 0, oracle, "after overflow")
+
+
+def test_exact_layout_option_is_sorted_and_gapless(oracle):
+    case = CS.by_name("uniform_fixed_100000")
+    ns = P.make_engine(case, 0, exact_layout=True)
+    ns.run(); ns.run()
+    st = ns.get_stats()
+    assert st["n_pool_pairs"] == 0
+    v = ns.pair_view(0, 0)
+    assert v.n_records == v.n_neighbors + v.n_points           # no gaps
+    P.assert_matches_golden({(0, 0): ns.neighbor_csr(0, 0)}, load_golden(case.name), 0, oracle, "exact layout")
+
+
+def test_c2_10m_pool_mode_matches_reference_digest(oracle):
+    case = CS.by_name("uniform_fixed_10000000")
+    golden = load_golden(case.name)
+    ns = P.make_engine(case, 0, device_inputs=True)
+    ns.run(); ns.run()
+    st = ns.get_stats()
+    assert st["n_pool_pairs"] == 1 and st["n_neighbors"] == golden["pairs"]["0->0"]["strict"]["total"]
+    P.assert_matches_golden({(0, 0): ns.neighbor_csr(0, 0)}, golden, 0, oracle, case.name + " (pool)")

@@ -3,7 +3,7 @@
 import re, subprocess, sys, os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-x", "hip", "-I" + root + "/include",
-       "-c", root + "/treensearch_amd/csrc/tnsx_kernels.hip", "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only"]
+       "-c", root + "/treensearch_amd/csrc/" + (os.environ.get("TNSX_SRC", "tnsx_kernels.hip")), "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = {}
 rows = []

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Condenses a tools/prof_gpu.sh output directory into per-kernel averages (kernel-trace stats + PMC counters)."""
+import csv, glob, os, re, sys
+from collections import defaultdict
+
+d = sys.argv[1]
+def short(name):
+    name = re.sub(r"\(.*", "", name)
+    return name.replace("void tnsx::", "").replace("tnsx::", "")[:58]
+
+for f in glob.glob(os.path.join(d, "kt", "**", "*kernel_stats.csv"), recursive=True):
+    print("== kernel-trace stats (us):", os.path.relpath(f, d))
+    for r in csv.DictReader(open(f)):
+        print(f"  {short(r['Name']):58s} calls {r['Calls']:>5} avg_us {float(r['AverageNs'])/1e3:10.2f} total_us {float(r['TotalDurationNs'])/1e3:11.1f} {float(r['Percentage']):6.2f}%")
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("== PMC counters, mean per dispatch")
+for k in sorted(acc):
+    print(" ", k)
+    c = {n: sum(v) / len(v) for n, v in acc[k].items()}
+    for n in sorted(c):
+        print(f"      {n:32s} {c[n]:18.1f}")

@@ -1,0 +1,63 @@
+// Micro-benchmark: issue cost of the VALU instructions the query kernel is made of (gfx950), 8 waves/SIMD.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define ITERS 4096
+template <int MODE>
+__global__ void __launch_bounds__(256) k(float* out, float seed)
+{
+	float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+	v2f b0 = {a0, a1}, b1 = {a2, a3}, b2 = {a4, a5}, b3 = {a6, a7}, b4 = b0 + 1.f, b5 = b1 + 1.f, b6 = b2 + 1.f, b7 = b3 + 1.f;
+	const float c = seed * 0.5f;
+	unsigned cnt = 0;
+	for (int i = 0; i < ITERS; i++) {
+		if (MODE == 0) {  // 8 x v_mul_f32
+			asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+		}
+		else if (MODE == 1) {  // 8 x v_pk_mul_f32
+			asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8"
+			             : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7) : "v"(b0));
+		}
+		else if (MODE == 2) {  // 8 x v_fma_f32
+			asm volatile("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+		}
+		else if (MODE == 3) {  // 8 x v_pk_fma_f32
+			asm volatile("v_pk_fma_f32 %0, %0, %8, %8\n v_pk_fma_f32 %1, %1, %8, %8\n v_pk_fma_f32 %2, %2, %8, %8\n v_pk_fma_f32 %3, %3, %8, %8\n v_pk_fma_f32 %4, %4, %8, %8\n v_pk_fma_f32 %5, %5, %8, %8\n v_pk_fma_f32 %6, %6, %8, %8\n v_pk_fma_f32 %7, %7, %8, %8"
+			             : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7) : "v"(b0));
+		}
+		else if (MODE == 4) {  // 8 x v_cmp_ge_f32 -> sgpr pair
+			asm volatile("v_cmp_ge_f32 s[20:21], %0, %8\n v_cmp_ge_f32 s[22:23], %1, %8\n v_cmp_ge_f32 s[24:25], %2, %8\n v_cmp_ge_f32 s[26:27], %3, %8\n v_cmp_ge_f32 s[28:29], %4, %8\n v_cmp_ge_f32 s[30:31], %5, %8\n v_cmp_ge_f32 s[32:33], %6, %8\n v_cmp_ge_f32 s[34:35], %7, %8"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c) : "s20","s21","s22","s23","s24","s25","s26","s27","s28","s29","s30","s31","s32","s33","s34","s35");
+		}
+		else if (MODE == 5) {  // 8 x v_pk_add_f32 with sgpr-pair broadcast operand (op_sel_hi:[0,1]) as in the query kernel
+			asm volatile("v_pk_add_f32 %0, s[20:21], %0 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %1, s[20:21], %1 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %2, s[20:21], %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %3, s[20:21], %3 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %4, s[20:21], %4 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %5, s[20:21], %5 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %6, s[20:21], %6 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %7, s[20:21], %7 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]"
+			             : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7) : : "s20", "s21");
+		}
+		else if (MODE == 6) {  // 8 x v_sub_f32 with sgpr operand
+			asm volatile("v_sub_f32 %0, s20, %0\n v_sub_f32 %1, s20, %1\n v_sub_f32 %2, s20, %2\n v_sub_f32 %3, s20, %3\n v_sub_f32 %4, s20, %4\n v_sub_f32 %5, s20, %5\n v_sub_f32 %6, s20, %6\n v_sub_f32 %7, s20, %7"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "s20");
+		}
+	}
+	out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0.x + b1.y + b2.x + b3.y + b4.x + b5.y + b6.x + b7.y + cnt;
+}
+template <int MODE> void run(const char* name, float* d)
+{
+	const int blocks = 256 * 8;   // 8 blocks of 4 waves per CU = 8 waves/SIMD
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 1.0f);
+	hipEventRecord(e0);
+	hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 1.0f);
+	hipEventRecord(e1); hipEventSynchronize(e1);
+	float ms; hipEventElapsedTime(&ms, e0, e1);
+	const double instr_per_simd = (double)blocks * 4 / (256.0 * 4) * ITERS * 8;   // wave-instructions per SIMD
+	printf("%-34s %8.3f ms  -> %.2f ns per wave-instr per SIMD (= %.2f cycles @2.4GHz)\n", name, ms, ms * 1e6 / instr_per_simd, ms * 1e6 / instr_per_simd * 2.4);
+}
+int main()
+{
+	float* d; hipMalloc(&d, 256 * 8 * 256 * 4);
+	run<0>("v_mul_f32", d); run<1>("v_pk_mul_f32", d); run<2>("v_fma_f32", d); run<3>("v_pk_fma_f32", d);
+	run<4>("v_cmp_ge_f32 -> sgpr", d); run<5>("v_pk_add_f32 sgpr bcast operand", d); run<6>("v_sub_f32 sgpr operand", d);
+	return 0;
+}

@@ -34,7 +34,7 @@ class TnsxError(RuntimeError):
 
 class _Options(C.Structure):
     _fields_ = [("device_id", C.c_int), ("stream", C.c_void_p), ("arith", C.c_int), ("mirror_to_host", C.c_int),
-                ("collect_stage_times", C.c_int), ("max_dense_cells", C.c_uint64), ("reserved", C.c_int * 8)]
+                ("collect_stage_times", C.c_int), ("exact_layout", C.c_int), ("max_dense_cells", C.c_uint64), ("reserved", C.c_int * 7)]
 
 
 class _CsrView(C.Structure):
@@ -51,6 +51,7 @@ class Stats(C.Structure):
                 ("ms_total", C.c_float), ("ms_upload", C.c_float), ("ms_bounds", C.c_float), ("ms_keys", C.c_float),
                 ("ms_sort", C.c_float), ("ms_gather", C.c_float), ("ms_cells", C.c_float), ("ms_count", C.c_float),
                 ("ms_scan", C.c_float), ("ms_fill", C.c_float), ("ms_mirror", C.c_float),
+                ("n_pool_pairs", C.c_int), ("pool_retries", C.c_int),
                 ("world_bottom", C.c_float * 3), ("world_top", C.c_float * 3), ("world_cells_pow2", C.c_int)]
 
     def as_dict(self):
@@ -174,7 +175,8 @@ class NeighborList:
 
 class TreeNSearch:
     def __init__(self, *, arith: int = ARITH_STRICT, mirror_to_host: bool = False, device_id: int = -1,
-                 stream: Optional[int] = None, collect_stage_times: bool = False, max_dense_cells: int = 0):
+                 stream: Optional[int] = None, collect_stage_times: bool = False, max_dense_cells: int = 0,
+                 exact_layout: bool = False):
         self._L = load_library()
         opt = _Options()
         self._L.tnsx_default_options(C.byref(opt))
@@ -184,6 +186,7 @@ class TreeNSearch:
         opt.mirror_to_host = int(mirror_to_host)
         opt.collect_stage_times = int(collect_stage_times)
         opt.max_dense_cells = max_dense_cells
+        opt.exact_layout = int(exact_layout)
         h = C.c_void_p()
         st = self._L.tnsx_create(C.byref(opt), C.byref(h))
         if st != 0:

@@ -90,7 +90,10 @@ struct PointSet {
 struct PairResult {
 	bool valid = false;
 	int n_i = 0;
-	uint64_t n_records = 0;
+	uint64_t n_records = 0;      // ints of `records` in use (pool mode: including slab holes)
+	uint64_t n_neighbors = 0;
+	uint64_t need_hint = 0;      // neighbours + points of the previous run: sizes the pool of the next one
+	uint32_t pool_slab = 16384;
 	DevBuf counts, offs_sorted, offs_orig, records;
 	PinnedBuf h_offs, h_records;
 	bool mirrored = false;
@@ -122,7 +125,7 @@ struct tnsx_context {
 	bool ran = false;
 
 	// scratch
-	DevBuf bounds_partials, bounds_out, sort_temp, scan_temp, n_occ, permute_tmp;
+	DevBuf bounds_partials, bounds_out, sort_temp, scan_temp, n_occ, permute_tmp, pool_ctrl;
 	PinnedBuf h_small;
 	DevBuf mkeys[2];   // 64-bit morton keys for zsort
 	tnsx_stats stats{};
@@ -309,6 +312,7 @@ tnsx_status tnsx_default_options(tnsx_options* opt)
 	opt->arith = TNSX_ARITH_STRICT;
 	opt->mirror_to_host = 0;
 	opt->collect_stage_times = 0;
+	opt->exact_layout = 0;
 	opt->max_dense_cells = 0;
 	return TNSX_OK;
 }
@@ -556,7 +560,7 @@ tnsx_status tnsx_run(tnsx_context* c)
 		PointSet& s = c->sets[si];
 		// the table is needed even for empty sets (they can be searched into)
 		HIPCHK(c, s.table.reserve(n_cells * sizeof(uint2)));
-		HIPCHK(c, s.occ.reserve((size_t)std::max(s.n, 1) * sizeof(uint32_t)));
+		HIPCHK(c, s.occ.reserve((size_t)std::max(s.n, 1) * sizeof(uint2)));
 		HIPCHK(c, s.keys[0].reserve((size_t)std::max(s.n, 1) * sizeof(uint32_t)));
 		const int t0 = tm.mark();
 		HIPCHK(c, hipMemsetAsync(s.table.p, 0, n_cells * sizeof(uint2), st));
@@ -574,25 +578,30 @@ tnsx_status tnsx_run(tnsx_context* c)
 		tnsx::launch_gather_sorted(s.d_xyz, variable ? s.d_radii : nullptr, vv[s.sorted_buf], s.n, s.xyzi.as<float4>(),
 		                           variable ? s.r2.as<float>() : nullptr, st);
 		const int t3 = tm.mark();
-		tnsx::launch_cell_table(kk[s.sorted_buf], s.n, s.table.as<uint2>(), s.occ.as<uint32_t>(), c->n_occ.as<uint32_t>() + si, st);
+		tnsx::launch_cell_table(kk[s.sorted_buf], s.n, s.table.as<uint2>(), s.occ.as<uint2>(), c->n_occ.as<uint32_t>() + si, st);
 		const int t4 = tm.mark();
 		span(ST_KEYS, t0, t1); span(ST_SORT, t1, t2); span(ST_GATHER, t2, t3); span(ST_CELLS, t3, t4);
 	}
 
-	// ---- per active pair: count -> scan
-	struct Job { int i, j; };
+	// ---- per active pair: the query.
+	//      pool mode (default once a pair has run before): ONE pass, records bump-allocated from a device cursor;
+	//      exact mode (first run of a pair, overflow, or opt.exact_layout): count -> scan -> fill, CSR in sorted order.
+	struct Job { int i, j; bool pool; };
 	std::vector<Job> jobs;
-	for (int i = 0; i < n_sets; i++) for (int j = 0; j < n_sets; j++) if (c->active[i][j]) jobs.push_back({ i, j });
-	HIPCHK(c, c->h_small.reserve(sizeof(uint64_t) * (jobs.size() + 1) + sizeof(uint32_t) * (size_t)(n_sets + 1) + 64));
-	uint64_t* h_totals = c->h_small.as<uint64_t>();
-	uint32_t* h_nocc = reinterpret_cast<uint32_t*>(h_totals + jobs.size() + 1);
+	for (int i = 0; i < n_sets; i++) for (int j = 0; j < n_sets; j++) if (c->active[i][j]) jobs.push_back({ i, j, false });
+	HIPCHK(c, c->h_small.reserve(sizeof(uint64_t) * (2 * jobs.size() + 2) + sizeof(uint32_t) * (size_t)(n_sets + 1) + 64));
+	uint64_t* h_ctrl = c->h_small.as<uint64_t>();                       // per job: {cursor | total, hit_total}
+	uint32_t* h_nocc = reinterpret_cast<uint32_t*>(h_ctrl + 2 * jobs.size() + 2);
+	HIPCHK(c, c->pool_ctrl.reserve(sizeof(uint64_t) * (2 * jobs.size() + 2)));
+	unsigned long long* d_ctrl = c->pool_ctrl.as<unsigned long long>();
+	const int query_waves = c->n_cus * 8 * 4;
 
-	auto make_args = [&](const Job& jb, PairResult& pr) {
+	auto make_args = [&](const Job& jb, PairResult& pr, size_t k) {
 		const PointSet& A = c->sets[jb.i];
 		const PointSet& B = c->sets[jb.j];
 		tnsx::QueryArgs a{};
-		a.occ_i = A.occ.as<uint32_t>(); a.n_occ_i = c->n_occ.as<uint32_t>() + jb.i;
-		a.keys_i = A.keys[A.sorted_buf].as<uint32_t>(); a.table_i = A.table.as<uint2>();
+		a.occ_i = A.occ.as<uint2>(); a.n_occ_i = c->n_occ.as<uint32_t>() + jb.i;
+		a.table_i = A.table.as<uint2>();
 		a.xyzi_i = A.xyzi.as<float4>(); a.r2_i = A.r2.as<float>();
 		a.table_j = B.table.as<uint2>(); a.xyzi_j = B.xyzi.as<float4>(); a.r2_j = B.r2.as<float>();
 		a.r2_fixed = c->radius_sq;
@@ -601,6 +610,10 @@ tnsx_status tnsx_run(tnsx_context* c)
 		a.offs_sorted = pr.offs_sorted.as<uint64_t>();
 		a.records = pr.records.as<int>();
 		a.offs_by_orig = pr.offs_orig.as<uint64_t>();
+		a.pool_cursor = d_ctrl + 2 * k;
+		a.hit_total = d_ctrl + 2 * k + 1;
+		a.pool_capacity = pr.records.cap / sizeof(int);
+		a.pool_slab = pr.pool_slab;
 		return a;
 	};
 	tnsx::QueryConfig qc{};
@@ -608,45 +621,93 @@ tnsx_status tnsx_run(tnsx_context* c)
 	qc.variable = variable;
 	qc.symmetric = variable && c->symmetric;   // TreeNSearch.cpp:2431
 
-	for (size_t k = 0; k < jobs.size(); k++) {
+	auto launch_pool = [&](size_t k) -> tnsx_status {
 		const Job& jb = jobs[k];
 		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
-		const int n_i = c->sets[jb.i].n;
-		pr.n_i = n_i;
-		HIPCHK(c, pr.counts.reserve((size_t)std::max(n_i, 1) * sizeof(uint32_t)));
-		HIPCHK(c, pr.offs_sorted.reserve(((size_t)n_i + 1) * sizeof(uint64_t)));
-		HIPCHK(c, pr.offs_orig.reserve((size_t)std::max(n_i, 1) * sizeof(uint64_t)));
-		HIPCHK(c, c->scan_temp.reserve(tnsx::scan_temp_bytes((size_t)n_i)));
-		const int t0 = tm.mark();
-		if (n_i > 0) {
-			qc.self = jb.i == jb.j; qc.fill = false;
-			tnsx::launch_query(make_args(jb, pr), qc, c->n_cus, st);
-		}
-		const int t1 = tm.mark();
-		tnsx::exclusive_scan_u32_to_u64(pr.counts.as<uint32_t>(), pr.offs_sorted.as<uint64_t>(), (size_t)n_i, c->scan_temp.p, st);
-		HIPCHK(c, hipMemcpyAsync(h_totals + k, pr.offs_sorted.as<uint64_t>() + n_i, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-		const int t2 = tm.mark();
-		span(ST_COUNT, t0, t1); span(ST_SCAN, t1, t2);
-	}
-	HIPCHK(c, hipMemcpyAsync(h_nocc, c->n_occ.p, sizeof(uint32_t) * (size_t)std::max(n_sets, 1), hipMemcpyDeviceToHost, st));
-	HIPCHK(c, hipStreamSynchronize(st));   // the record totals size the output allocation
-
-	// ---- fill
-	for (size_t k = 0; k < jobs.size(); k++) {
-		const Job& jb = jobs[k];
-		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
-		pr.n_records = h_totals[k];
-		HIPCHK(c, pr.records.reserve(std::max<uint64_t>(pr.n_records, 1) * sizeof(int)));
+		HIPCHK(c, hipMemsetAsync(d_ctrl + 2 * k, 0, 2 * sizeof(uint64_t), st));
 		const int t0 = tm.mark();
 		if (pr.n_i > 0) {
-			qc.self = jb.i == jb.j; qc.fill = true;
-			tnsx::launch_query(make_args(jb, pr), qc, c->n_cus, st);
+			qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_POOL;
+			tnsx::launch_query(make_args(jb, pr, k), qc, c->n_cus, st);
 		}
 		const int t1 = tm.mark();
 		span(ST_FILL, t0, t1);
+		HIPCHK(c, hipMemcpyAsync(h_ctrl + 2 * k, d_ctrl + 2 * k, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+		return TNSX_OK;
+	};
+
+	for (size_t k = 0; k < jobs.size(); k++) {
+		Job& jb = jobs[k];
+		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
+		const int n_i = c->sets[jb.i].n;
+		pr.n_i = n_i;
+		HIPCHK(c, pr.offs_orig.reserve((size_t)std::max(n_i, 1) * sizeof(uint64_t)));
+		jb.pool = !c->opt.exact_layout && pr.need_hint > 0 && n_i > 0;
+		if (jb.pool) {
+			// capacity: last run's exact need + 12 % + room for every wave's partly used slab
+			const uint64_t expect = pr.need_hint + pr.need_hint / 8 + 1024;
+			uint64_t slab = expect / ((uint64_t)query_waves * 8);
+			slab = std::min<uint64_t>(16384, std::max<uint64_t>(256, slab));
+			pr.pool_slab = (uint32_t)slab;
+			HIPCHK(c, pr.records.reserve((expect + (uint64_t)query_waves * slab * 2) * sizeof(int)));
+			const tnsx_status r = launch_pool(k);
+			if (r != TNSX_OK) return r;
+		}
+		else {
+			HIPCHK(c, pr.counts.reserve((size_t)std::max(n_i, 1) * sizeof(uint32_t)));
+			HIPCHK(c, pr.offs_sorted.reserve(((size_t)n_i + 1) * sizeof(uint64_t)));
+			HIPCHK(c, c->scan_temp.reserve(tnsx::scan_temp_bytes((size_t)n_i)));
+			const int t0 = tm.mark();
+			if (n_i > 0) {
+				qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_COUNT;
+				tnsx::launch_query(make_args(jb, pr, k), qc, c->n_cus, st);
+			}
+			const int t1 = tm.mark();
+			tnsx::exclusive_scan_u32_to_u64(pr.counts.as<uint32_t>(), pr.offs_sorted.as<uint64_t>(), (size_t)n_i, c->scan_temp.p, st);
+			HIPCHK(c, hipMemcpyAsync(h_ctrl + 2 * k, pr.offs_sorted.as<uint64_t>() + n_i, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+			const int t2 = tm.mark();
+			span(ST_COUNT, t0, t1); span(ST_SCAN, t1, t2);
+		}
+	}
+	HIPCHK(c, hipMemcpyAsync(h_nocc, c->n_occ.p, sizeof(uint32_t) * (size_t)std::max(n_sets, 1), hipMemcpyDeviceToHost, st));
+	HIPCHK(c, hipStreamSynchronize(st));   // record totals / pool cursors are needed on the host
+
+	for (size_t k = 0; k < jobs.size(); k++) {
+		const Job& jb = jobs[k];
+		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
+		uint64_t n_neighbors = 0;
+		if (jb.pool) {
+			// pool overflow: the cursor says how much was needed; grow and redo this pair's pass
+			for (int attempt = 0; h_ctrl[2 * k] > pr.records.cap / sizeof(int); attempt++) {
+				if (attempt >= 4) TNSX_FAIL(c, TNSX_ERR_HIP, "neighbour pool kept overflowing (needed %llu ints)", (unsigned long long)h_ctrl[2 * k]);
+				const uint64_t need = h_ctrl[2 * k];
+				HIPCHK(c, pr.records.reserve((need + need / 8 + (uint64_t)query_waves * pr.pool_slab * 2) * sizeof(int)));
+				const tnsx_status r = launch_pool(k);
+				if (r != TNSX_OK) return r;
+				HIPCHK(c, hipStreamSynchronize(st));
+				S.pool_retries++;
+			}
+			pr.n_records = h_ctrl[2 * k];
+			n_neighbors = h_ctrl[2 * k + 1];
+		}
+		else {
+			pr.n_records = h_ctrl[2 * k];
+			n_neighbors = pr.n_records - (uint64_t)pr.n_i;
+			HIPCHK(c, pr.records.reserve(std::max<uint64_t>(pr.n_records, 1) * sizeof(int)));
+			const int t0 = tm.mark();
+			if (pr.n_i > 0) {
+				qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_FILL;
+				tnsx::launch_query(make_args(jb, pr, k), qc, c->n_cus, st);
+			}
+			const int t1 = tm.mark();
+			span(ST_FILL, t0, t1);
+		}
+		pr.n_neighbors = n_neighbors;
+		pr.need_hint = n_neighbors + (uint64_t)pr.n_i;
 		pr.valid = true;
 		S.n_queries += (uint64_t)pr.n_i;
-		S.n_neighbors += pr.n_records - (uint64_t)pr.n_i;
+		S.n_neighbors += n_neighbors;
+		if (jb.pool) S.n_pool_pairs++;
 	}
 	for (int si = 0; si < n_sets; si++) S.n_occupied_cells += h_nocc[si];
 
@@ -726,7 +787,7 @@ tnsx_status tnsx_get_pair_view(tnsx_context* c, int i, int j, tnsx_csr_view* out
 	{ const tnsx_status r = find_pair(c, i, j, &pr); if (r != TNSX_OK) return r; }
 	out->n_points = pr->n_i;
 	out->n_records = pr->n_records;
-	out->n_neighbors = pr->n_records - (uint64_t)pr->n_i;
+	out->n_neighbors = pr->n_neighbors;
 	out->offsets_device = pr->offs_orig.as<uint64_t>();
 	out->records_device = pr->records.as<int>();
 	out->offsets_host = pr->mirrored ? pr->h_offs.as<uint64_t>() : nullptr;

@@ -44,14 +44,14 @@ void exclusive_scan_u32_to_u64(const uint32_t* in, uint64_t* out, size_t n, void
 void launch_gather_sorted(const float* xyz, const float* radii, const uint32_t* idx_sorted, int n, float4* xyzi,
                           float* r2, hipStream_t s);
 
-// ---- cell table: table[key] = (first sorted position, one past last), occ = sorted positions of the
-//      first point of every occupied cell (unordered), *n_occ = their number (must be zeroed before) ----
-void launch_cell_table(const uint32_t* keys_sorted, int n, uint2* table, uint32_t* occ, uint32_t* n_occ, hipStream_t s);
+// ---- cell table: table[key] = (first sorted position, one past last); occ = {first sorted position, key} of every
+//      occupied cell (order of blocks of 4096 points is arbitrary), *n_occ = their number (must be zeroed before) ----
+void launch_cell_table(const uint32_t* keys_sorted, int n, uint2* table, uint2* occ, uint32_t* n_occ, hipStream_t s);
 
 // ---- the query ----------------------------------------------------------------------------------
 struct QueryArgs {
 	// query set i
-	const uint32_t* occ_i; const uint32_t* n_occ_i; const uint32_t* keys_i; const uint2* table_i;
+	const uint2* occ_i; const uint32_t* n_occ_i; const uint2* table_i;
 	const float4* xyzi_i; const float* r2_i;
 	// candidate set j
 	const uint2* table_j; const float4* xyzi_j; const float* r2_j;
@@ -63,13 +63,19 @@ struct QueryArgs {
 	const uint64_t* offs_sorted;   // exclusive scan of counts
 	int* records;                  // [count, j...] records
 	uint64_t* offs_by_orig;        // offsets by original index of set i
+	// pool pass (single pass, no count/scan): records are bump-allocated from *pool_cursor in per-wave slabs
+	unsigned long long* pool_cursor;   // ints handed out so far (may exceed pool_capacity: then the pass must be redone)
+	uint64_t pool_capacity;            // ints available in `records`
+	uint32_t pool_slab;                // ints a wave takes from the cursor per atomic
+	unsigned long long* hit_total;     // += number of neighbour indices emitted
 };
+enum { QUERY_COUNT = 0, QUERY_FILL = 1, QUERY_POOL = 2 };
 struct QueryConfig {
 	int arith;       // 0 strict, 1 contracted
 	bool variable;   // per-point radii
 	bool symmetric;  // d2 <= r_i^2 || d2 <= r_j^2 (only meaningful with variable)
 	bool self;       // set_i == set_j: exclude the point itself
-	bool fill;       // false: count pass, true: fill pass
+	int mode;        // QUERY_COUNT / QUERY_FILL (exact two-pass layout) / QUERY_POOL (single pass)
 };
 void launch_query(const QueryArgs& a, const QueryConfig& c, int n_compute_units, hipStream_t s);
 

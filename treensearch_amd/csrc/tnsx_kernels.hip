@@ -5,26 +5,11 @@
 // explicit round-to-nearest intrinsics so that the neighbour predicate is bit-identical to the reference
 // (TreeNSearch.cpp:2478-2486 / BruteforceNSearch.cpp:88) in either arithmetic mode.
 #include "tnsx_kernels.h"
+#include "tnsx_device.h"
 
 #include <cfloat>
 
 namespace tnsx {
-
-static constexpr int WAVE = 64;
-
-__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
-__device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
-{
-	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
-__device__ __forceinline__ float readlane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-__device__ __forceinline__ void wave_lds_fence()
-{
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // =====================================================================================================
 // f64 -> f32 staging (TreeNSearch.cpp:277-296: `(float)` cast, round to nearest even)
@@ -414,230 +399,6 @@ void launch_gather_sorted(const float* xyz, const float* radii, const uint32_t* 
 	hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, s, xyz, radii, idx_sorted, n, xyzi, r2);
 }
 
-// =====================================================================================================
-// cell table + list of occupied cells
-// =====================================================================================================
-__global__ void __launch_bounds__(256) k_cell_table(const uint32_t* __restrict__ keys, int n, uint2* __restrict__ table, uint32_t* __restrict__ occ,
-                                                   uint32_t* __restrict__ n_occ)
-{
-	__shared__ uint32_t wcnt[4];
-	__shared__ uint32_t block_base;
-	const int p = blockIdx.x * 256 + threadIdx.x;
-	bool is_start = false;
-	if (p < n) {
-		const uint32_t k = keys[p];
-		is_start = (p == 0) || (keys[p - 1] != k);
-		const bool is_end = (p == n - 1) || (keys[p + 1] != k);
-		if (is_start) table[k].x = (uint32_t)p;
-		if (is_end) table[k].y = (uint32_t)p + 1u;
-	}
-	const uint64_t m = __ballot(is_start);
-	const int w = threadIdx.x / WAVE;
-	if (lane_id() == 0) wcnt[w] = (uint32_t)__popcll(m);
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		const uint32_t tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-		block_base = tot ? atomicAdd(n_occ, tot) : 0u;
-	}
-	__syncthreads();
-	if (is_start) {
-		uint32_t off = block_base;
-		for (int ww = 0; ww < w; ww++) off += wcnt[ww];
-		occ[off + mbcnt64(m)] = (uint32_t)p;
-	}
-}
-void launch_cell_table(const uint32_t* keys_sorted, int n, uint2* table, uint32_t* occ, uint32_t* n_occ, hipStream_t s)
-{
-	if (n <= 0) return;
-	hipLaunchKernelGGL(k_cell_table, dim3((n + 255) / 256), dim3(256), 0, s, keys_sorted, n, table, occ, n_occ);
-}
-
-// =====================================================================================================
-// the query: one wave per occupied cell of set i.
-//   * 27 neighbour cells of set j looked up by 27 lanes, merged into 9 x-contiguous runs
-//   * runs staged through a wave-private LDS tile (coalesced 16-byte loads), then held in registers,
-//     one candidate per lane per 64-slot chunk
-//   * query points of the cell broadcast lane by lane (v_readlane), every chunk tested by all 64 lanes,
-//     hits compacted with ballot + mbcnt into the CSR record of the query (fill) or just counted (count)
-// =====================================================================================================
-static constexpr int Q_THREADS = 256;
-static constexpr int Q_WAVES = Q_THREADS / WAVE;
-static constexpr int Q_CHUNKS = 8;                 // 64-slot chunks of candidates held in registers per batch
-static constexpr int Q_SLOTS = Q_CHUNKS * WAVE;
-
-template <int ARITH>
-__device__ __forceinline__ float dist_sq(float qx, float qy, float qz, float cx, float cy, float cz)
-{
-	const float dx = __fsub_rn(qx, cx);
-	const float dy = __fsub_rn(qy, cy);
-	const float dz = __fsub_rn(qz, cz);
-	if (ARITH == 0) {
-		// ((dx*dx + dy*dy) + dz*dz), every op rounded
-		return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-	}
-	else {
-		// fma(dz,dz, fma(dx,dx, dy*dy))
-		return __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
-	}
-}
-
-template <int ARITH, bool VARIABLE, bool SYM, bool SELF, bool FILL>
-__global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
-{
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	const int lane = lane_id();
-	const int w = threadIdx.x / WAVE;
-	float4* cand = reinterpret_cast<float4*>(smem) + (size_t)w * Q_SLOTS;
-	float* cand_r2 = reinterpret_cast<float*>(smem + (size_t)Q_WAVES * Q_SLOTS * sizeof(float4)) + (size_t)w * Q_SLOTS;
-
-	const uint32_t n_occ = *a.n_occ_i;
-	const uint32_t n_waves = gridDim.x * Q_WAVES;
-	const int nx = a.g.nx, ny = a.g.ny, nz = a.g.nz;
-
-	for (uint32_t ci = blockIdx.x * Q_WAVES + w; ci < n_occ; ci += n_waves) {
-		const uint32_t p0 = a.occ_i[ci];
-		const uint32_t key = a.keys_i[p0];
-		const uint2 qrange = a.table_i[key];
-		const int cx = (int)(key % (uint32_t)nx);
-		const int cy = (int)((key / (uint32_t)nx) % (uint32_t)ny);
-		const int cz = (int)(key / ((uint32_t)nx * (uint32_t)ny));
-
-		// ---- 27 neighbour cells of set j -> 9 merged x-runs (lanes 0,3,..,24)
-		uint32_t s = 0, e = 0;
-		if (lane < 27) {
-			const int x = cx + (lane % 3) - 1, y = cy + ((lane / 3) % 3) - 1, z = cz + (lane / 9) - 1;
-			if (x >= 0 && x < nx && y >= 0 && y < ny && z >= 0 && z < nz) {
-				const uint2 r = a.table_j[((size_t)z * ny + y) * nx + x];
-				s = r.x; e = r.y;
-			}
-		}
-		const uint32_t s1 = __shfl_down(s, 1, WAVE), e1 = __shfl_down(e, 1, WAVE);
-		const uint32_t s2 = __shfl_down(s, 2, WAVE), e2 = __shfl_down(e, 2, WAVE);
-		const uint32_t run_start = (e > s) ? s : ((e1 > s1) ? s1 : s2);
-		const uint32_t run_end = (e2 > s2) ? e2 : ((e1 > s1) ? e1 : e);
-		const uint32_t run_len_v = run_end > run_start ? run_end - run_start : 0u;
-		uint32_t rs[9], rn[9];
-		uint32_t total = 0;
-		#pragma unroll
-		for (int r = 0; r < 9; r++) {
-			rs[r] = readlane_u32(run_start, 3 * r);
-			rn[r] = readlane_u32(run_len_v, 3 * r);
-			total += rn[r];
-		}
-
-		// ---- query points of this cell, 64 at a time
-		for (uint32_t qb = qrange.x; qb < qrange.y; qb += WAVE) {
-			const uint32_t nq = (qrange.y - qb) < (uint32_t)WAVE ? (qrange.y - qb) : (uint32_t)WAVE;
-			float4 qv = { 0.f, 0.f, 0.f, 0.f };
-			float qr2 = a.r2_fixed;
-			uint64_t my_off = 0;
-			if ((uint32_t)lane < nq) {
-				qv = a.xyzi_i[qb + lane];
-				if (VARIABLE) qr2 = a.r2_i[qb + lane];
-				if (FILL) my_off = a.offs_sorted[qb + lane];
-			}
-			uint32_t run_cnt = 0;
-
-			// ---- candidate batches of Q_SLOTS slots
-			for (uint32_t wb = 0; wb < total; wb += Q_SLOTS) {
-				wave_lds_fence();   // previous batch fully consumed before the tile is overwritten
-				uint32_t pre = 0;
-				#pragma unroll
-				for (int r = 0; r < 9; r++) {
-					const uint32_t lo = pre > wb ? pre : wb;
-					const uint32_t hi_full = pre + rn[r];
-					const uint32_t hi = hi_full < wb + Q_SLOTS ? hi_full : wb + Q_SLOTS;
-					for (uint32_t sl = lo + lane; sl < hi; sl += WAVE) {
-						const uint32_t src = rs[r] + (sl - pre);
-						cand[sl - wb] = a.xyzi_j[src];
-						if (SYM) cand_r2[sl - wb] = a.r2_j[src];
-					}
-					pre = hi_full;
-				}
-				const uint32_t nb = (total - wb) < (uint32_t)Q_SLOTS ? (total - wb) : (uint32_t)Q_SLOTS;
-				wave_lds_fence();
-				float4 c[Q_CHUNKS];
-				float cr2[Q_CHUNKS];
-				#pragma unroll
-				for (int k = 0; k < Q_CHUNKS; k++) {
-					const uint32_t slot = (uint32_t)(k * WAVE + lane);
-					if (slot < nb) {
-						c[k] = cand[slot];
-						cr2[k] = SYM ? cand_r2[slot] : 0.f;
-					}
-					else {
-						c[k] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, __uint_as_float(0xffffffffu));
-						cr2[k] = -1.0f;
-					}
-				}
-
-				// ---- every query of the batch against the register-resident candidates
-				for (uint32_t t = 0; t < nq; t++) {
-					const float qx = readlane_f32(qv.x, (int)t), qy = readlane_f32(qv.y, (int)t), qz = readlane_f32(qv.z, (int)t);
-					const uint32_t qi = readlane_u32(__float_as_uint(qv.w), (int)t);
-					const float r2 = VARIABLE ? readlane_f32(qr2, (int)t) : a.r2_fixed;
-					uint64_t base = 0;
-					if (FILL) {
-						const uint32_t lo = readlane_u32((uint32_t)my_off, (int)t), hi = readlane_u32((uint32_t)(my_off >> 32), (int)t);
-						base = (((uint64_t)hi << 32) | lo) + 1u + readlane_u32(run_cnt, (int)t);
-					}
-					uint32_t cnt = 0;
-					#pragma unroll
-					for (int k = 0; k < Q_CHUNKS; k++) {
-						if ((uint32_t)(k * WAVE) < nb) {
-							const float d2 = dist_sq<ARITH>(qx, qy, qz, c[k].x, c[k].y, c[k].z);
-							bool hit = d2 <= r2;
-							if (SYM) hit = hit || (d2 <= cr2[k]);
-							if (SELF) hit = hit && (__float_as_uint(c[k].w) != qi);
-							const uint64_t m = __ballot(hit);
-							if (FILL) {
-								if (hit) a.records[base + cnt + mbcnt64(m)] = (int)__float_as_uint(c[k].w);
-							}
-							cnt += (uint32_t)__popcll(m);
-						}
-					}
-					if ((uint32_t)lane == t) run_cnt += cnt;
-				}
-			}
-
-			if ((uint32_t)lane < nq) {
-				if (FILL) {
-					a.records[my_off] = (int)run_cnt;
-					a.offs_by_orig[__float_as_uint(qv.w)] = my_off;
-				}
-				else {
-					a.counts[qb + lane] = run_cnt + 1u;
-				}
-			}
-		}
-	}
-}
-
-template <int ARITH, bool VARIABLE, bool SYM, bool SELF, bool FILL>
-static void launch_query_t(const QueryArgs& a, int blocks, hipStream_t s)
-{
-	const size_t lds = (size_t)Q_WAVES * Q_SLOTS * (sizeof(float4) + (SYM ? sizeof(float) : 0));
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<ARITH, VARIABLE, SYM, SELF, FILL>), dim3(blocks), dim3(Q_THREADS), lds, s, a);
-}
-template <int ARITH, bool VARIABLE, bool SYM>
-static void launch_query_2(const QueryArgs& a, const QueryConfig& c, int blocks, hipStream_t s)
-{
-	if (c.self) { if (c.fill) launch_query_t<ARITH, VARIABLE, SYM, true, true>(a, blocks, s); else launch_query_t<ARITH, VARIABLE, SYM, true, false>(a, blocks, s); }
-	else        { if (c.fill) launch_query_t<ARITH, VARIABLE, SYM, false, true>(a, blocks, s); else launch_query_t<ARITH, VARIABLE, SYM, false, false>(a, blocks, s); }
-}
-template <int ARITH>
-static void launch_query_1(const QueryArgs& a, const QueryConfig& c, int blocks, hipStream_t s)
-{
-	if (!c.variable) launch_query_2<ARITH, false, false>(a, c, blocks, s);
-	else if (c.symmetric) launch_query_2<ARITH, true, true>(a, c, blocks, s);
-	else launch_query_2<ARITH, true, false>(a, c, blocks, s);
-}
-void launch_query(const QueryArgs& a, const QueryConfig& c, int n_compute_units, hipStream_t s)
-{
-	// persistent grid: waves stride over the list of occupied cells (its length lives in device memory)
-	const int blocks = n_compute_units * 4;
-	if (c.arith == 0) launch_query_1<0>(a, c, blocks, s); else launch_query_1<1>(a, c, blocks, s);
-}
 
 // =====================================================================================================
 // permutation of fixed-size byte records (device-side apply_zsort, TreeNSearch.h:465-480)

@@ -1,0 +1,440 @@
+// gfx950 kernels: cell table and THE QUERY (count / fill passes of the 27-cell distance test).
+//
+// Query design (one wave64 per occupied cell of the query set; no LDS, no MFMA):
+//   * the 27 neighbour cells of the candidate set are looked up by 27 lanes in one round trip and merged into 9
+//     x-contiguous runs of the sorted candidate array (row-major keys: x-neighbours are adjacent in sorted order);
+//   * the concatenation of the 9 runs is dealt to the lanes slot by slot (slot = chunk*64 + lane); every lane finds the
+//     run of its slot with 8 scalar-operand compares, so ALL candidate loads (one coalesced 16-byte load per lane and
+//     chunk) are issued back to back and land directly in registers -- one memory round trip per cell;
+//   * the occupied-cell list entry is prefetched two cells ahead and the 27 lookups one cell ahead, so that the only
+//     exposed latency per cell is the candidate load, which the other resident waves hide;
+//   * the cell's query points are broadcast one at a time (v_readlane); each is tested against all register-resident
+//     candidates, two chunks per packed-fp32 instruction (v_pk_add/mul/fma_f32), and the hits are compacted with
+//     ballot + mbcnt straight into the query's CSR record (fill) or just counted (count);
+//   * work assignment is XCD-aware: workgroup b runs on XCD b % 8, and every XCD owns one contiguous eighth of the
+//     (roughly key-ordered) occupied-cell list, so the three z-planes a wave touches stay in that XCD's L2.
+// The distance arithmetic is spelled op by op (file compiled with -ffp-contract=off) and is bit-identical to the
+// reference's AVX2 path / BruteforceNSearch in either arithmetic mode (TreeNSearch.cpp:2478-2486, BF.cpp:88).
+#include "tnsx_kernels.h"
+#include "tnsx_device.h"
+
+#include <cfloat>
+#include <cstdlib>
+
+namespace tnsx {
+
+// =====================================================================================================
+// cell table + list of occupied cells.  One block per tile of 4096 sorted points, ONE atomic per block.
+// =====================================================================================================
+static constexpr int CT_THREADS = 256;
+static constexpr int CT_ITEMS = 16;
+static constexpr int CT_TILE = CT_THREADS * CT_ITEMS;
+
+__global__ void __launch_bounds__(CT_THREADS) k_cell_table(const uint32_t* __restrict__ keys, int n, uint2* __restrict__ table,
+                                                          uint2* __restrict__ occ, uint32_t* __restrict__ n_occ)
+{
+	__shared__ uint32_t wcnt[CT_ITEMS * (CT_THREADS / WAVE)];   // [round][wave] -> exclusive prefix
+	__shared__ uint32_t block_base;
+	const int w = threadIdx.x / WAVE;
+	const size_t base = (size_t)blockIdx.x * CT_TILE;
+	uint32_t key[CT_ITEMS];
+	uint32_t flags = 0;
+	#pragma unroll
+	for (int i = 0; i < CT_ITEMS; i++) {
+		const size_t p = base + (size_t)i * CT_THREADS + threadIdx.x;
+		bool is_start = false;
+		key[i] = 0;
+		if (p < (size_t)n) {
+			const uint32_t k = keys[p];
+			key[i] = k;
+			is_start = (p == 0) || (keys[p - 1] != k);
+			const bool is_end = (p == (size_t)n - 1) || (keys[p + 1] != k);
+			if (is_start) table[k].x = (uint32_t)p;
+			if (is_end) table[k].y = (uint32_t)p + 1u;
+		}
+		flags |= (is_start ? 1u : 0u) << i;
+		const uint64_t m = __builtin_amdgcn_ballot_w64(is_start);
+		if (lane_id() == 0) wcnt[i * (CT_THREADS / WAVE) + w] = (uint32_t)__popcll(m);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t s = 0;
+		for (int q = 0; q < CT_ITEMS * (CT_THREADS / WAVE); q++) { const uint32_t t = wcnt[q]; wcnt[q] = s; s += t; }
+		block_base = s ? atomicAdd(n_occ, s) : 0u;
+	}
+	__syncthreads();
+	const uint32_t bb = block_base;
+	#pragma unroll
+	for (int i = 0; i < CT_ITEMS; i++) {
+		const bool is_start = (flags >> i) & 1u;
+		const uint64_t m = __builtin_amdgcn_ballot_w64(is_start);
+		if (is_start) {
+			const size_t p = base + (size_t)i * CT_THREADS + threadIdx.x;
+			occ[bb + wcnt[i * (CT_THREADS / WAVE) + w] + mbcnt64(m)] = make_uint2((uint32_t)p, key[i]);
+		}
+	}
+}
+void launch_cell_table(const uint32_t* keys_sorted, int n, uint2* table, uint2* occ, uint32_t* n_occ, hipStream_t s)
+{
+	if (n <= 0) return;
+	hipLaunchKernelGGL(k_cell_table, dim3((n + CT_TILE - 1) / CT_TILE), dim3(CT_THREADS), 0, s, keys_sorted, n, table, occ, n_occ);
+}
+
+// =====================================================================================================
+// the query
+// =====================================================================================================
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+static constexpr int Q_THREADS = 256;
+static constexpr int Q_WAVES = Q_THREADS / WAVE;
+static constexpr int Q_MAXPAIRS = 4;                       // chunk pairs per batch
+static constexpr int Q_SLOTS = Q_MAXPAIRS * 2 * WAVE;      // 512 candidates per batch
+
+// squared distances of one query to two candidates at once (packed fp32, every op individually rounded)
+template <int ARITH>
+__device__ __forceinline__ v2f dist_sq2(float qx, float qy, float qz, v2f cx, v2f cy, v2f cz)
+{
+	const v2f dx = (v2f)(qx) - cx;
+	const v2f dy = (v2f)(qy) - cy;
+	const v2f dz = (v2f)(qz) - cz;
+	if (ARITH == 0) {
+		return (dx * dx + dy * dy) + dz * dz;                                                   // STRICT
+	}
+	else {
+		return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));   // CONTRACTED
+	}
+}
+
+// Wave-uniform description of the 9 merged candidate runs of one cell.  Deliberately NINE NAMED SCALARS per field and
+// not arrays: with arrays the compiler turns the select chain below into a table lookup and parks the table in LDS.
+struct Runs {
+	uint32_t p1, p2, p3, p4, p5, p6, p7, p8;        // first slot of run r (run 0 starts at slot 0)
+	uint32_t d0, d1, d2, d3, d4, d5, d6, d7, d8;    // sorted position = slot + d_r
+	uint32_t total;
+};
+
+// What stays live across the query loop: the two VGPRs the 18 scalars are extracted from, plus two scalars.
+struct RunRef {
+	uint32_t run_start, run_len;   // per lane; lanes 0,3,..,24 hold run 0..8
+	uint32_t total;                // wave-uniform: number of candidates
+	uint32_t d4;                   // wave-uniform: delta of the centre run (the one holding the query cell itself)
+};
+
+__device__ __forceinline__ Runs extract_runs(uint32_t run_start, uint32_t run_len)
+{
+	Runs R;
+	uint32_t acc = 0, rs, rn, p0_unused;
+#define TNSX_RUN(r, P, D)                                                       \
+	rs = readlane_u32(run_start, 3 * r); rn = readlane_u32(run_len, 3 * r); \
+	P = acc; D = rs - acc; acc += rn;
+	TNSX_RUN(0, p0_unused, R.d0) TNSX_RUN(1, R.p1, R.d1) TNSX_RUN(2, R.p2, R.d2) TNSX_RUN(3, R.p3, R.d3) TNSX_RUN(4, R.p4, R.d4)
+	TNSX_RUN(5, R.p5, R.d5) TNSX_RUN(6, R.p6, R.d6) TNSX_RUN(7, R.p7, R.d7) TNSX_RUN(8, R.p8, R.d8)
+#undef TNSX_RUN
+	(void)p0_unused;
+	R.total = acc;
+	return R;
+}
+
+__device__ __forceinline__ uint32_t slot_to_src(uint32_t slot, const Runs R)
+{
+	uint32_t d = R.d0;
+	d = slot >= R.p1 ? R.d1 : d;
+	d = slot >= R.p2 ? R.d2 : d;
+	d = slot >= R.p3 ? R.d3 : d;
+	d = slot >= R.p4 ? R.d4 : d;
+	d = slot >= R.p5 ? R.d5 : d;
+	d = slot >= R.p6 ? R.d6 : d;
+	d = slot >= R.p7 ? R.d7 : d;
+	d = slot >= R.p8 ? R.d8 : d;
+	return slot + d;
+}
+
+// 27 neighbour lookups of the cell with this key (lanes 0..26), wave-uniform key
+__device__ __forceinline__ void lookup_cell(const QueryArgs& a, uint32_t key, bool valid, int lane, uint32_t& s, uint32_t& e)
+{
+	s = 0; e = 0;
+	const uint32_t nx = (uint32_t)a.g.nx, ny = (uint32_t)a.g.ny, nz = (uint32_t)a.g.nz;
+	const int cx = (int)(key % nx);
+	const int cy = (int)((key / nx) % ny);
+	const int cz = (int)(key / (nx * ny));
+	if (valid && lane < 27) {
+		const int x = cx + (lane % 3) - 1, y = cy + ((lane / 3) % 3) - 1, z = cz + (lane / 9) - 1;
+		if (x >= 0 && x < (int)nx && y >= 0 && y < (int)ny && z >= 0 && z < (int)nz) {
+			const uint2 r = a.table_j[((size_t)z * ny + y) * nx + x];
+			s = r.x; e = r.y;
+		}
+	}
+}
+
+enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_POOL = 2 };
+
+// Per-wave bump allocator over the record pool (MODE_POOL): a wave owns a slab of POOL_SLAB ints at a time and takes a
+// new one from the global cursor with ONE atomic when the next record does not fit.  Slab remainders stay unused, so
+// the pool has holes; every record is still contiguous and exact.
+struct PoolState { uint64_t cur, end; };
+
+__device__ __forceinline__ uint64_t pool_alloc(const QueryArgs& a, PoolState& ps, uint32_t len, int lane)
+{
+	if (ps.cur + len > ps.end) {
+		const uint64_t sz = len > a.pool_slab ? (uint64_t)len : (uint64_t)a.pool_slab;
+		unsigned long long old = 0;
+		if (lane == 0) old = atomicAdd(a.pool_cursor, (unsigned long long)sz);
+		const uint32_t lo = readfirstlane_u32((uint32_t)old), hi = readfirstlane_u32((uint32_t)(old >> 32));
+		ps.cur = ((uint64_t)hi << 32) | lo;
+		ps.end = ps.cur + sz;
+	}
+	const uint64_t off = ps.cur;
+	ps.cur += len;
+	return off;
+}
+
+// One batch of <= NC*64 candidates (register resident) against the nq query points held one per lane in qv.
+//   MODE_COUNT: run_cnt (lane t) += hits of query t
+//   MODE_FILL : record of query t starts at my_off (lane t); indices appended at my_off + 1 + run_cnt
+//   MODE_POOL : record allocated here (single-batch cells only); my_off (lane t) receives its offset
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int MODE, int NC>
+__device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef RR, uint32_t wb, int lane, const float4& qv, float qr2, uint32_t qb,
+                                              uint32_t nq, uint64_t& my_off, uint32_t& run_cnt, PoolState& ps, uint32_t& wave_hits)
+{
+	constexpr int NP = (NC + 1) / 2;
+	// the 18 run scalars live only during the load phase (SGPR pressure); the query loop needs just d4 and total
+	const Runs R = extract_runs(RR.run_start, RR.run_len);
+	// ---- candidates of this batch -> registers (all loads independent, issued back to back)
+	v2f cx[NP], cy[NP], cz[NP];
+	uint32_t cid[2 * NP];
+	float cr2[2 * NP];
+	#pragma unroll
+	for (int k = 0; k < 2 * NP; k++) {
+		const uint32_t slot = wb + (uint32_t)(k * WAVE + lane);
+		float4 c = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, __uint_as_float(0xffffffffu));
+		float r2c = -1.0f;
+		if (k < NC && slot < R.total) {
+			const uint32_t src = slot_to_src(slot, R);
+			c = a.xyzi_j[src];
+			if (SYM) r2c = a.r2_j[src];
+		}
+		cx[k >> 1][k & 1] = c.x; cy[k >> 1][k & 1] = c.y; cz[k >> 1][k & 1] = c.z;
+		cid[k] = __float_as_uint(c.w);
+		cr2[k] = r2c;
+	}
+	// ---- every query of the cell against them
+	for (uint32_t t = 0; t < nq; t++) {
+		const float qx = readlane_f32(qv.x, (int)t), qy = readlane_f32(qv.y, (int)t), qz = readlane_f32(qv.z, (int)t);
+		const float r2 = VARIABLE ? readlane_f32(qr2, (int)t) : a.r2_fixed;
+		// hit masks of all chunks first: every compare writes its lane mask to an SGPR pair, the rest is scalar work
+		uint64_t m[NC];
+		#pragma unroll
+		for (int h = 0; h < NP; h++) {
+			const v2f d2 = dist_sq2<ARITH>(qx, qy, qz, cx[h], cy[h], cz[h]);
+			#pragma unroll
+			for (int u = 0; u < 2; u++) {
+				const int k = 2 * h + u;
+				if (k < NC) {
+					m[k] = __builtin_amdgcn_ballot_w64(d2[u] <= r2);
+					if (SYM) m[k] |= __builtin_amdgcn_ballot_w64(d2[u] <= cr2[k]);
+				}
+			}
+		}
+		if (SELF) {
+			// the query itself is always a hit (d2 == 0) and sits in the centre run (run 4) at slot qpos - d4:
+			// clear that one bit on the scalar unit instead of comparing indices in every lane
+			const uint32_t ss = (qb + t) - RR.d4 - wb;
+			#pragma unroll
+			for (int k = 0; k < NC; k++) m[k] &= ~(((ss >> 6) == (uint32_t)k) ? (1ull << (ss & 63u)) : 0ull);
+		}
+		uint32_t cnt = 0;
+		#pragma unroll
+		for (int k = 0; k < NC; k++) cnt += (uint32_t)__popcll(m[k]);
+
+		if (MODE != MODE_COUNT) {
+			uint64_t off;
+			bool ok = true;
+			if (MODE == MODE_POOL) {
+				off = pool_alloc(a, ps, cnt + 1u, lane);
+				ok = off + cnt + 1u <= a.pool_capacity;
+				if ((uint32_t)lane == t) my_off = off;
+			}
+			else {
+				const uint32_t lo = readlane_u32((uint32_t)my_off, (int)t), hi = readlane_u32((uint32_t)(my_off >> 32), (int)t);
+				off = (((uint64_t)hi << 32) | lo) + readlane_u32(run_cnt, (int)t);
+			}
+			if (ok) {
+				int* dst = a.records + off + 1u;
+				uint32_t pos = 0;
+				#pragma unroll
+				for (int k = 0; k < NC; k++) {
+					if (__builtin_amdgcn_inverse_ballot_w64(m[k])) dst[pos + mbcnt64(m[k])] = (int)cid[k];
+					pos += (uint32_t)__popcll(m[k]);
+				}
+			}
+		}
+		if ((uint32_t)lane == t) run_cnt += cnt;
+		wave_hits += cnt;
+	}
+}
+
+// FULL = false: only the 8-chunk body is instantiated (used on the rare multi-batch path to keep the code small)
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int MODE, bool FULL>
+__device__ __forceinline__ void process_batch_nc(const QueryArgs& a, const RunRef RR, uint32_t wb, uint32_t nb, int lane, const float4& qv, float qr2,
+                                                 uint32_t qb, uint32_t nq, uint64_t& my_off, uint32_t& run_cnt, PoolState& ps, uint32_t& wave_hits)
+{
+	const uint32_t nc = FULL ? (nb + WAVE - 1) / WAVE : 8u;
+	switch (nc) {
+	case 1: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 1>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
+	case 2: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 2>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
+	case 3: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 3>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
+	case 4: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 4>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
+	case 5: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 5>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
+	case 6: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 6>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
+	case 7: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 7>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
+	default: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 8>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
+	}
+}
+
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int MODE>
+__global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
+{
+	const int lane = lane_id();
+	const uint32_t w = readfirstlane_u32(threadIdx.x / WAVE);
+	const uint32_t n_occ = *a.n_occ_i;
+	// XCD-aware assignment: this workgroup's XCD owns the contiguous cell range [lo, hi)
+	const uint32_t xcd = blockIdx.x & 7u;
+	const uint32_t lo = (uint32_t)(((uint64_t)n_occ * xcd) >> 3), hi = (uint32_t)(((uint64_t)n_occ * (xcd + 1u)) >> 3);
+	const uint32_t stride = (gridDim.x >> 3) * Q_WAVES;
+	uint32_t ci = lo + (blockIdx.x >> 3) * Q_WAVES + w;
+	PoolState ps = { 0, 0 };
+	uint32_t wave_hits = 0;
+
+	// software pipeline: occ entry two cells ahead, 27 lookups one cell ahead
+	uint2 oc = ci < hi ? a.occ_i[ci] : make_uint2(0u, 0u);
+	uint2 oc_n = (ci + stride) < hi ? a.occ_i[ci + stride] : make_uint2(0u, 0u);
+	uint32_t s, e;
+	lookup_cell(a, oc.y, ci < hi, lane, s, e);
+	uint2 qrange = ci < hi ? a.table_i[oc.y] : make_uint2(0u, 0u);
+
+	while (ci < hi) {
+		const uint32_t ci_n = ci + stride, ci_nn = ci_n + stride;
+		const uint2 oc_nn = ci_nn < hi ? a.occ_i[ci_nn] : make_uint2(0u, 0u);
+
+		// ---- merge the 27 lookups of the CURRENT cell into 9 x-runs (lanes 0,3,..,24)
+		const uint32_t s1 = __shfl_down(s, 1, WAVE), e1 = __shfl_down(e, 1, WAVE);
+		const uint32_t s2 = __shfl_down(s, 2, WAVE), e2 = __shfl_down(e, 2, WAVE);
+		RunRef RR;
+		RR.run_start = (e > s) ? s : ((e1 > s1) ? s1 : s2);
+		const uint32_t run_end = (e2 > s2) ? e2 : ((e1 > s1) ? e1 : e);
+		RR.run_len = run_end > RR.run_start ? run_end - RR.run_start : 0u;
+		{
+			const Runs R0 = extract_runs(RR.run_start, RR.run_len);
+			RR.total = R0.total;
+			RR.d4 = R0.d4;
+		}
+		const uint2 cur_q = qrange;
+
+		// ---- issue the lookups of the NEXT cell now; they complete under this cell's arithmetic
+		lookup_cell(a, oc_n.y, ci_n < hi, lane, s, e);
+		qrange = ci_n < hi ? a.table_i[oc_n.y] : make_uint2(0u, 0u);
+
+		// ---- query points of this cell, 64 at a time
+		for (uint32_t qb = cur_q.x; qb < cur_q.y; qb += WAVE) {
+			const uint32_t nq = (cur_q.y - qb) < (uint32_t)WAVE ? (cur_q.y - qb) : (uint32_t)WAVE;
+			float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
+			float qr2 = a.r2_fixed;
+			uint64_t my_off = 0;
+			if ((uint32_t)lane < nq) {
+				qv = a.xyzi_i[qb + lane];
+				if (VARIABLE) qr2 = a.r2_i[qb + lane];
+				if (MODE == MODE_FILL) my_off = a.offs_sorted[qb + lane];   // start of the record (its count word)
+			}
+			uint32_t run_cnt = 0;
+			if (RR.total <= (uint32_t)Q_SLOTS) {
+				// ---- the normal case: all candidates of the cell fit into one register-resident batch
+				if (RR.total > 0) {
+					process_batch_nc<ARITH, VARIABLE, SYM, SELF, MODE, true>(a, RR, 0u, RR.total, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits);
+				}
+				else if (MODE == MODE_POOL) {
+					// no candidates at all: every query still gets its (empty) record
+					for (uint32_t t = 0; t < nq; t++) {
+						const uint64_t off = pool_alloc(a, ps, 1u, lane);
+						if ((uint32_t)lane == t) my_off = off;
+					}
+				}
+			}
+			else if (MODE != MODE_POOL) {
+				for (uint32_t wb = 0; wb < RR.total; wb += Q_SLOTS) {
+					process_batch_nc<ARITH, VARIABLE, SYM, SELF, MODE, false>(a, RR, wb, Q_SLOTS, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits);
+				}
+			}
+			else {
+				// ---- rare: several candidate batches in pool mode.  Count sweep, allocate the records of all nq queries
+				//      at once, fill sweep.
+				uint32_t unused_hits = 0;
+				for (uint32_t wb = 0; wb < RR.total; wb += Q_SLOTS) {
+					process_batch_nc<ARITH, VARIABLE, SYM, SELF, MODE_COUNT, false>(a, RR, wb, Q_SLOTS, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, unused_hits);
+				}
+				const uint32_t len = (uint32_t)lane < nq ? run_cnt + 1u : 0u;
+				uint32_t inc = len;
+				#pragma unroll
+				for (int o = 1; o < WAVE; o <<= 1) { const uint32_t tv = __shfl_up(inc, o, WAVE); if (lane >= o) inc += tv; }
+				const uint32_t total_len = readlane_u32(inc, WAVE - 1);
+				const uint64_t base = pool_alloc(a, ps, total_len, lane);
+				my_off = base + (inc - len);
+				run_cnt = 0;
+				if (base + total_len <= a.pool_capacity) {
+					for (uint32_t wb = 0; wb < RR.total; wb += Q_SLOTS) {
+						process_batch_nc<ARITH, VARIABLE, SYM, SELF, MODE_FILL, false>(a, RR, wb, Q_SLOTS, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits);
+					}
+				}
+			}
+			if ((uint32_t)lane < nq) {
+				if (MODE == MODE_COUNT) {
+					a.counts[qb + lane] = run_cnt + 1u;
+				}
+				else if (MODE == MODE_FILL || my_off + run_cnt + 1u <= a.pool_capacity) {
+					a.records[my_off] = (int)run_cnt;
+					a.offs_by_orig[__float_as_uint(qv.w)] = my_off;
+				}
+			}
+		}
+		ci = ci_n; oc = oc_n; oc_n = oc_nn;
+	}
+	if (MODE == MODE_POOL) {
+		if (lane == 0 && wave_hits) atomicAdd(a.hit_total, (unsigned long long)wave_hits);
+	}
+}
+
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int MODE>
+static void launch_query_t(const QueryArgs& a, int blocks, hipStream_t s)
+{
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<ARITH, VARIABLE, SYM, SELF, MODE>), dim3(blocks), dim3(Q_THREADS), 0, s, a);
+}
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF>
+static void launch_query_3(const QueryArgs& a, const QueryConfig& c, int blocks, hipStream_t s)
+{
+	if (c.mode == QUERY_COUNT) launch_query_t<ARITH, VARIABLE, SYM, SELF, MODE_COUNT>(a, blocks, s);
+	else if (c.mode == QUERY_FILL) launch_query_t<ARITH, VARIABLE, SYM, SELF, MODE_FILL>(a, blocks, s);
+	else launch_query_t<ARITH, VARIABLE, SYM, SELF, MODE_POOL>(a, blocks, s);
+}
+template <int ARITH, bool VARIABLE, bool SYM>
+static void launch_query_2(const QueryArgs& a, const QueryConfig& c, int blocks, hipStream_t s)
+{
+	if (c.self) launch_query_3<ARITH, VARIABLE, SYM, true>(a, c, blocks, s); else launch_query_3<ARITH, VARIABLE, SYM, false>(a, c, blocks, s);
+}
+template <int ARITH>
+static void launch_query_1(const QueryArgs& a, const QueryConfig& c, int blocks, hipStream_t s)
+{
+	if (!c.variable) launch_query_2<ARITH, false, false>(a, c, blocks, s);
+	else if (c.symmetric) launch_query_2<ARITH, true, true>(a, c, blocks, s);
+	else launch_query_2<ARITH, true, false>(a, c, blocks, s);
+}
+void launch_query(const QueryArgs& a, const QueryConfig& c, int n_compute_units, hipStream_t s)
+{
+	// persistent grid (a multiple of 8 workgroups so that every XCD gets the same number): waves stride over their
+	// XCD's share of the occupied-cell list, whose length lives in device memory
+	int per_cu = 7;
+	if (const char* e = getenv("TNSX_QUERY_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) per_cu = v; }   // tuning knob
+	int blocks = n_compute_units * per_cu;
+	blocks = ((blocks + 7) / 8) * 8;
+	if (c.arith == 0) launch_query_1<0>(a, c, blocks, s); else launch_query_1<1>(a, c, blocks, s);
+}
+
+}  // namespace tnsx
