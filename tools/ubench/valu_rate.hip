@@ -39,6 +39,30 @@ __global__ void __launch_bounds__(256) k(float* out, float seed)
 			asm volatile("v_sub_f32 %0, s20, %0\n v_sub_f32 %1, s20, %1\n v_sub_f32 %2, s20, %2\n v_sub_f32 %3, s20, %3\n v_sub_f32 %4, s20, %4\n v_sub_f32 %5, s20, %5\n v_sub_f32 %6, s20, %6\n v_sub_f32 %7, s20, %7"
 			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "s20");
 		}
+		else if (MODE == 7) {  // 8 x v_cmp_ge_f32 e32 -> vcc
+			asm volatile("v_cmp_ge_f32 vcc, %0, %8\n v_cmp_ge_f32 vcc, %1, %8\n v_cmp_ge_f32 vcc, %2, %8\n v_cmp_ge_f32 vcc, %3, %8\n v_cmp_ge_f32 vcc, %4, %8\n v_cmp_ge_f32 vcc, %5, %8\n v_cmp_ge_f32 vcc, %6, %8\n v_cmp_ge_f32 vcc, %7, %8"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c) : "vcc");
+		}
+		else if (MODE == 8) {  // 4 x (v_mbcnt_lo + v_mbcnt_hi) with sgpr masks
+			asm volatile("v_mbcnt_lo_u32_b32 %0, s20, 0\n v_mbcnt_hi_u32_b32 %0, s21, %0\n v_mbcnt_lo_u32_b32 %1, s20, 0\n v_mbcnt_hi_u32_b32 %1, s21, %1\n v_mbcnt_lo_u32_b32 %2, s20, 0\n v_mbcnt_hi_u32_b32 %2, s21, %2\n v_mbcnt_lo_u32_b32 %3, s20, 0\n v_mbcnt_hi_u32_b32 %3, s21, %3"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "s20", "s21");
+		}
+		else if (MODE == 9) {  // 8 x v_cndmask_b32 with sgpr data operand, vcc select
+			asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c) : "vcc");
+		}
+		else if (MODE == 10) {  // 8 x v_readlane_b32
+			asm volatile("v_readlane_b32 s20, %0, 3\n v_readlane_b32 s21, %1, 3\n v_readlane_b32 s22, %2, 3\n v_readlane_b32 s23, %3, 3\n v_readlane_b32 s24, %4, 3\n v_readlane_b32 s25, %5, 3\n v_readlane_b32 s26, %6, 3\n v_readlane_b32 s27, %7, 3"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "s20","s21","s22","s23","s24","s25","s26","s27");
+		}
+		else if (MODE == 11) {  // 8 x v_add_u32 (int)
+			asm volatile("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+		}
+		else if (MODE == 12) {  // 8 x v_add_f32 vgpr operands
+			asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+		}
 	}
 	out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0.x + b1.y + b2.x + b3.y + b4.x + b5.y + b6.x + b7.y + cnt;
 }
@@ -59,5 +83,6 @@ int main()
 	float* d; hipMalloc(&d, 256 * 8 * 256 * 4);
 	run<0>("v_mul_f32", d); run<1>("v_pk_mul_f32", d); run<2>("v_fma_f32", d); run<3>("v_pk_fma_f32", d);
 	run<4>("v_cmp_ge_f32 -> sgpr", d); run<5>("v_pk_add_f32 sgpr bcast operand", d); run<6>("v_sub_f32 sgpr operand", d);
+	run<7>("v_cmp_ge_f32 e32 -> vcc", d); run<8>("v_mbcnt_lo/hi (per instr)", d); run<9>("v_cndmask_b32 vcc", d); run<10>("v_readlane_b32", d); run<11>("v_add_u32", d); run<12>("v_add_f32 vgpr", d);
 	return 0;
 }

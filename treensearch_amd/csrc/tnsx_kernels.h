@@ -68,6 +68,9 @@ struct QueryArgs {
 	uint64_t pool_capacity;            // ints available in `records`
 	uint32_t pool_slab;                // ints a wave takes from the cursor per atomic
 	unsigned long long* hit_total;     // += number of neighbour indices emitted
+	uint32_t* tickets;                 // [8] per-XCD ticket counters of the fast kernel (zeroed before the launch)
+	uint2* heavy;                      // worklist {first sorted position, key} of the cells the fast kernel skipped
+	uint32_t* n_heavy;                 // its length (zeroed before the launch)
 };
 enum { QUERY_COUNT = 0, QUERY_FILL = 1, QUERY_POOL = 2 };
 struct QueryConfig {

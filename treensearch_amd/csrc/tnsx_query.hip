@@ -157,13 +157,13 @@ __device__ __forceinline__ void lookup_cell(const QueryArgs& a, uint32_t key, bo
 	const int cx = (int)(key % nx);
 	const int cy = (int)((key / nx) % ny);
 	const int cz = (int)(key / (nx * ny));
-	if (valid && lane < 27) {
-		const int x = cx + (lane % 3) - 1, y = cy + ((lane / 3) % 3) - 1, z = cz + (lane / 9) - 1;
-		if (x >= 0 && x < (int)nx && y >= 0 && y < (int)ny && z >= 0 && z < (int)nz) {
-			const uint2 r = a.table_j[((size_t)z * ny + y) * nx + x];
-			s = r.x; e = r.y;
-		}
-	}
+	// branch-free (a load inside an exec region would be waited for inside it): lanes without a neighbour cell read entry 0
+	const int x = cx + (lane % 3) - 1, y = cy + ((lane / 3) % 3) - 1, z = cz + (lane / 9) - 1;
+	const bool use = valid && lane < 27 && x >= 0 && x < (int)nx && y >= 0 && y < (int)ny && z >= 0 && z < (int)nz;
+	const size_t idx = use ? ((size_t)z * ny + y) * nx + x : 0;
+	const uint2 r = a.table_j[idx];
+	s = use ? r.x : 0u;
+	e = use ? r.y : 0u;
 }
 
 enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_POOL = 2 };
@@ -171,21 +171,61 @@ enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_POOL = 2 };
 // Per-wave bump allocator over the record pool (MODE_POOL): a wave owns a slab of POOL_SLAB ints at a time and takes a
 // new one from the global cursor with ONE atomic when the next record does not fit.  Slab remainders stay unused, so
 // the pool has holes; every record is still contiguous and exact.
-struct PoolState { uint64_t cur, end; };
+// All fast-path bookkeeping is 32-bit scalar work: gfx9 has no 64-bit scalar magnitude compare, so a `cur + len > end`
+// test on 64-bit values would be done on the VALU (with copies back and forth) for every single query.
+struct PoolState {
+	uint32_t cur_lo, cur_hi;   // next free int of the wave's slab
+	uint32_t left;             // ints left in the slab
+	uint32_t ok;               // 1 when the whole slab lies inside the pool (else: count, but do not write)
+};
 
-__device__ __forceinline__ uint64_t pool_alloc(const QueryArgs& a, PoolState& ps, uint32_t len, int lane)
+// rare path, deliberately out of line so that the per-query fast path stays a handful of scalar instructions
+__device__ __attribute__((noinline)) unsigned long long pool_take_slab(unsigned long long* cursor, uint32_t sz)
 {
-	if (ps.cur + len > ps.end) {
-		const uint64_t sz = len > a.pool_slab ? (uint64_t)len : (uint64_t)a.pool_slab;
-		unsigned long long old = 0;
-		if (lane == 0) old = atomicAdd(a.pool_cursor, (unsigned long long)sz);
-		const uint32_t lo = readfirstlane_u32((uint32_t)old), hi = readfirstlane_u32((uint32_t)(old >> 32));
-		ps.cur = ((uint64_t)hi << 32) | lo;
-		ps.end = ps.cur + sz;
+	unsigned long long old = 0;
+	if (lane_id() == 0) old = atomicAdd(cursor, (unsigned long long)sz);
+	return old;   // valid in lane 0
+}
+
+__device__ __forceinline__ uint64_t pool_alloc(const QueryArgs& a, PoolState& ps, uint32_t len, int lane, bool& ok)
+{
+	(void)lane;
+	if (len > ps.left) {
+		const uint32_t sz = len > a.pool_slab ? len : a.pool_slab;
+		const unsigned long long old = pool_take_slab(a.pool_cursor, sz);
+		ps.cur_lo = readfirstlane_u32((uint32_t)old);
+		ps.cur_hi = readfirstlane_u32((uint32_t)(old >> 32));
+		ps.left = sz;
+		const uint64_t slab_end = (((uint64_t)ps.cur_hi << 32) | ps.cur_lo) + sz;
+		ps.ok = readfirstlane_u32(slab_end <= a.pool_capacity ? 1u : 0u);
 	}
-	const uint64_t off = ps.cur;
-	ps.cur += len;
+	const uint64_t off = ((uint64_t)ps.cur_hi << 32) | ps.cur_lo;
+	const uint64_t nxt = off + len;
+	ps.cur_lo = (uint32_t)nxt;
+	ps.cur_hi = (uint32_t)(nxt >> 32);
+	ps.left -= len;
+	ok = ps.ok != 0u;
 	return off;
+}
+
+// Appends the set lanes of mask m (their value v) to dst[pos...] in lane order.  Hand-scheduled: exec is loaded from
+// the mask and restored to all-ones (every lane of the wave is active wherever this is called), which costs two
+// scalar instructions instead of the compiler's s_and_saveexec / s_cbranch_execz / s_or triple -- the scalar unit is
+// the scarce resource of this kernel.  The store is younger than every load the compiler tracks, so its untracked
+// vmcnt increment can only make the compiler's waits longer, never shorter.
+__device__ __forceinline__ void emit_chunk(const int* dst, uint32_t pos, uint64_t m, uint32_t v)
+{
+	uint32_t tmp;
+	asm volatile(
+		"s_mov_b64 exec, %[m]\n\t"
+		"v_mbcnt_lo_u32_b32 %[t], %[mlo], 0\n\t"
+		"v_mbcnt_hi_u32_b32 %[t], %[mhi], %[t]\n\t"
+		"v_add_lshl_u32 %[t], %[t], %[pos], 2\n\t"
+		"global_store_dword %[t], %[v], %[base]\n\t"
+		"s_mov_b64 exec, -1"
+		: [t] "=&v"(tmp)
+		: [m] "s"(m), [mlo] "s"((uint32_t)m), [mhi] "s"((uint32_t)(m >> 32)), [pos] "s"(pos), [v] "v"(v), [base] "s"(dst)
+		: "memory");
 }
 
 // One batch of <= NC*64 candidates (register resident) against the nq query points held one per lane in qv.
@@ -203,15 +243,30 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 	v2f cx[NP], cy[NP], cz[NP];
 	uint32_t cid[2 * NP];
 	float cr2[2 * NP];
+	//      Branch-free on purpose: a load inside `if (slot < total)` gets its own exec region and its own
+	//      s_waitcnt, which serialises the round trips.  Out-of-range slots read a clamped (valid) address instead and
+	//      are overwritten with padding afterwards.
+	float4 craw[2 * NP];
+	float r2raw[2 * NP];
 	#pragma unroll
 	for (int k = 0; k < 2 * NP; k++) {
-		const uint32_t slot = wb + (uint32_t)(k * WAVE + lane);
+		if (k < NC) {
+			const uint32_t slot = wb + (uint32_t)(k * WAVE + lane);
+			const uint32_t src = slot < R.total ? slot_to_src(slot, R) : R.d0;   // R.d0 = first candidate of the cell
+			craw[k] = a.xyzi_j[src];
+			if (SYM) r2raw[k] = a.r2_j[src];
+		}
+	}
+	#pragma unroll
+	for (int k = 0; k < 2 * NP; k++) {
 		float4 c = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, __uint_as_float(0xffffffffu));
 		float r2c = -1.0f;
-		if (k < NC && slot < R.total) {
-			const uint32_t src = slot_to_src(slot, R);
-			c = a.xyzi_j[src];
-			if (SYM) r2c = a.r2_j[src];
+		if (k < NC) {
+			const uint32_t slot = wb + (uint32_t)(k * WAVE + lane);
+			const bool valid = slot < R.total;
+			c.x = valid ? craw[k].x : FLT_MAX; c.y = valid ? craw[k].y : FLT_MAX; c.z = valid ? craw[k].z : FLT_MAX;
+			c.w = valid ? craw[k].w : __uint_as_float(0xffffffffu);
+			if (SYM) r2c = valid ? r2raw[k] : -1.0f;
 		}
 		cx[k >> 1][k & 1] = c.x; cy[k >> 1][k & 1] = c.y; cz[k >> 1][k & 1] = c.z;
 		cid[k] = __float_as_uint(c.w);
@@ -221,6 +276,7 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 	for (uint32_t t = 0; t < nq; t++) {
 		const float qx = readlane_f32(qv.x, (int)t), qy = readlane_f32(qv.y, (int)t), qz = readlane_f32(qv.z, (int)t);
 		const float r2 = VARIABLE ? readlane_f32(qr2, (int)t) : a.r2_fixed;
+		const uint32_t qi = readlane_u32(__float_as_uint(qv.w), (int)t);
 		// hit masks of all chunks first: every compare writes its lane mask to an SGPR pair, the rest is scalar work
 		uint64_t m[NC];
 		#pragma unroll
@@ -232,15 +288,11 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 				if (k < NC) {
 					m[k] = __builtin_amdgcn_ballot_w64(d2[u] <= r2);
 					if (SYM) m[k] |= __builtin_amdgcn_ballot_w64(d2[u] <= cr2[k]);
+					// self exclusion by index: one VALU compare + one s_and per chunk.  (Clearing the one self bit with
+					// scalar ops costs 4-5 SALU per chunk, and the CU's single scalar unit is as scarce as its 4 SIMDs.)
+					if (SELF) m[k] &= __builtin_amdgcn_ballot_w64(cid[k] != qi);
 				}
 			}
-		}
-		if (SELF) {
-			// the query itself is always a hit (d2 == 0) and sits in the centre run (run 4) at slot qpos - d4:
-			// clear that one bit on the scalar unit instead of comparing indices in every lane
-			const uint32_t ss = (qb + t) - RR.d4 - wb;
-			#pragma unroll
-			for (int k = 0; k < NC; k++) m[k] &= ~(((ss >> 6) == (uint32_t)k) ? (1ull << (ss & 63u)) : 0ull);
 		}
 		uint32_t cnt = 0;
 		#pragma unroll
@@ -250,20 +302,19 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 			uint64_t off;
 			bool ok = true;
 			if (MODE == MODE_POOL) {
-				off = pool_alloc(a, ps, cnt + 1u, lane);
-				ok = off + cnt + 1u <= a.pool_capacity;
-				if ((uint32_t)lane == t) my_off = off;
+				off = pool_alloc(a, ps, cnt + 1u, lane, ok);
+				if ((uint32_t)lane == t) my_off = ok ? off : ~0ull;
 			}
 			else {
 				const uint32_t lo = readlane_u32((uint32_t)my_off, (int)t), hi = readlane_u32((uint32_t)(my_off >> 32), (int)t);
 				off = (((uint64_t)hi << 32) | lo) + readlane_u32(run_cnt, (int)t);
 			}
 			if (ok) {
-				int* dst = a.records + off + 1u;
+				const int* dst = a.records + off + 1u;
 				uint32_t pos = 0;
 				#pragma unroll
 				for (int k = 0; k < NC; k++) {
-					if (__builtin_amdgcn_inverse_ballot_w64(m[k])) dst[pos + mbcnt64(m[k])] = (int)cid[k];
+					emit_chunk(dst, pos, m[k], cid[k]);
 					pos += (uint32_t)__popcll(m[k]);
 				}
 			}
@@ -302,7 +353,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 	const uint32_t lo = (uint32_t)(((uint64_t)n_occ * xcd) >> 3), hi = (uint32_t)(((uint64_t)n_occ * (xcd + 1u)) >> 3);
 	const uint32_t stride = (gridDim.x >> 3) * Q_WAVES;
 	uint32_t ci = lo + (blockIdx.x >> 3) * Q_WAVES + w;
-	PoolState ps = { 0, 0 };
+	PoolState ps = { 0u, 0u, 0u, 0u };
 	uint32_t wave_hits = 0;
 
 	// software pipeline: occ entry two cells ahead, 27 lookups one cell ahead
@@ -354,8 +405,9 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 				else if (MODE == MODE_POOL) {
 					// no candidates at all: every query still gets its (empty) record
 					for (uint32_t t = 0; t < nq; t++) {
-						const uint64_t off = pool_alloc(a, ps, 1u, lane);
-						if ((uint32_t)lane == t) my_off = off;
+						bool ok1;
+						const uint64_t off = pool_alloc(a, ps, 1u, lane, ok1);
+						if ((uint32_t)lane == t) my_off = ok1 ? off : ~0ull;
 					}
 				}
 			}
@@ -376,10 +428,11 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 				#pragma unroll
 				for (int o = 1; o < WAVE; o <<= 1) { const uint32_t tv = __shfl_up(inc, o, WAVE); if (lane >= o) inc += tv; }
 				const uint32_t total_len = readlane_u32(inc, WAVE - 1);
-				const uint64_t base = pool_alloc(a, ps, total_len, lane);
-				my_off = base + (inc - len);
+				bool okm;
+				const uint64_t base = pool_alloc(a, ps, total_len, lane, okm);
+				my_off = okm ? base + (inc - len) : ~0ull;
 				run_cnt = 0;
-				if (base + total_len <= a.pool_capacity) {
+				if (okm) {
 					for (uint32_t wb = 0; wb < RR.total; wb += Q_SLOTS) {
 						process_batch_nc<ARITH, VARIABLE, SYM, SELF, MODE_FILL, false>(a, RR, wb, Q_SLOTS, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits);
 					}
@@ -389,7 +442,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 				if (MODE == MODE_COUNT) {
 					a.counts[qb + lane] = run_cnt + 1u;
 				}
-				else if (MODE == MODE_FILL || my_off + run_cnt + 1u <= a.pool_capacity) {
+				else if (MODE == MODE_FILL || my_off != ~0ull) {
 					a.records[my_off] = (int)run_cnt;
 					a.offs_by_orig[__float_as_uint(qv.w)] = my_off;
 				}
@@ -402,39 +455,136 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 	}
 }
 
+// =====================================================================================================
+// pool-mode FAST kernel: the steady-state hot path.
+//   * dynamic scheduling: every XCD owns one contiguous eighth of the occupied-cell list and hands it out in tickets of
+//     Q_TICKET consecutive cells through its own atomic counter, so any number of resident waves stays busy to the end
+//     (no static-partition tail, clustered clouds balance themselves);
+//   * handles only "simple" cells (all candidates in one register batch, at most 64 query points); the others are
+//     appended to a worklist that the general kernel above processes afterwards -- this keeps registers low.
+// =====================================================================================================
+static constexpr uint32_t Q_TICKET = 8;
+
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF>
+__global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a)
+{
+	const int lane = lane_id();
+	const uint32_t n_occ = *a.n_occ_i;
+	const uint32_t xcd = blockIdx.x & 7u;
+	const uint32_t lo = (uint32_t)(((uint64_t)n_occ * xcd) >> 3), hi = (uint32_t)(((uint64_t)n_occ * (xcd + 1u)) >> 3);
+	PoolState ps = { 0u, 0u, 0u, 0u };
+	uint32_t wave_hits = 0;
+
+	for (;;) {
+		uint32_t ticket = 0;
+		if (lane == 0) ticket = atomicAdd(a.tickets + xcd, 1u);
+		ticket = readfirstlane_u32(ticket);
+		const uint32_t first = lo + ticket * Q_TICKET;
+		if (first >= hi) break;
+		const uint32_t ncell = (hi - first) < Q_TICKET ? (hi - first) : Q_TICKET;
+		// the ticket's occupied-cell entries, one per lane
+		uint2 ocv = make_uint2(0u, 0u);
+		if ((uint32_t)lane < ncell) ocv = a.occ_i[first + lane];
+		// lookups of the first cell; afterwards always one cell ahead
+		uint32_t s, e;
+		uint32_t key = readlane_u32(ocv.y, 0);
+		lookup_cell(a, key, true, lane, s, e);
+		uint2 qrange = a.table_i[key];
+
+		for (uint32_t c = 0; c < ncell; c++) {
+			const uint32_t s1 = __shfl_down(s, 1, WAVE), e1 = __shfl_down(e, 1, WAVE);
+			const uint32_t s2 = __shfl_down(s, 2, WAVE), e2 = __shfl_down(e, 2, WAVE);
+			RunRef RR;
+			RR.run_start = (e > s) ? s : ((e1 > s1) ? s1 : s2);
+			const uint32_t run_end = (e2 > s2) ? e2 : ((e1 > s1) ? e1 : e);
+			RR.run_len = run_end > RR.run_start ? run_end - RR.run_start : 0u;
+			{
+				const Runs R0 = extract_runs(RR.run_start, RR.run_len);
+				RR.total = R0.total;
+				RR.d4 = R0.d4;
+			}
+			const uint2 cur_q = qrange;
+			const uint32_t cur_key = key;
+			const uint32_t cur_p0 = readlane_u32(ocv.x, (int)c);
+			if (c + 1 < ncell) {
+				key = readlane_u32(ocv.y, (int)(c + 1));
+				lookup_cell(a, key, true, lane, s, e);
+				qrange = a.table_i[key];
+			}
+			const uint32_t nq = cur_q.y - cur_q.x;
+			if (RR.total > (uint32_t)Q_SLOTS || nq > (uint32_t)WAVE) {
+				// not simple: leave it to the general kernel
+				if (lane == 0) { const uint32_t h = atomicAdd(a.n_heavy, 1u); a.heavy[h] = make_uint2(cur_p0, cur_key); }
+				continue;
+			}
+			float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
+			float qr2 = a.r2_fixed;
+			uint64_t my_off = 0;
+			if ((uint32_t)lane < nq) {
+				qv = a.xyzi_i[cur_q.x + lane];
+				if (VARIABLE) qr2 = a.r2_i[cur_q.x + lane];
+			}
+			uint32_t run_cnt = 0;
+			if (RR.total > 0) {
+				process_batch_nc<ARITH, VARIABLE, SYM, SELF, MODE_POOL, true>(a, RR, 0u, RR.total, lane, qv, qr2, cur_q.x, nq, my_off, run_cnt, ps, wave_hits);
+			}
+			else {
+				for (uint32_t t = 0; t < nq; t++) {
+					bool ok1;
+					const uint64_t off = pool_alloc(a, ps, 1u, lane, ok1);
+					if ((uint32_t)lane == t) my_off = ok1 ? off : ~0ull;
+				}
+			}
+			if ((uint32_t)lane < nq && my_off != ~0ull) {
+				a.records[my_off] = (int)run_cnt;
+				a.offs_by_orig[__float_as_uint(qv.w)] = my_off;
+			}
+		}
+	}
+	if (lane == 0 && wave_hits) atomicAdd(a.hit_total, (unsigned long long)wave_hits);
+}
+
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int MODE>
 static void launch_query_t(const QueryArgs& a, int blocks, hipStream_t s)
 {
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<ARITH, VARIABLE, SYM, SELF, MODE>), dim3(blocks), dim3(Q_THREADS), 0, s, a);
 }
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF>
-static void launch_query_3(const QueryArgs& a, const QueryConfig& c, int blocks, hipStream_t s)
+static void launch_pool_t(const QueryArgs& a, int blocks_fast, int blocks_heavy, hipStream_t s)
 {
+	// fast kernel over all occupied cells, then the general kernel over the worklist of non-simple cells
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_pool_fast<ARITH, VARIABLE, SYM, SELF>), dim3(blocks_fast), dim3(Q_THREADS), 0, s, a);
+	QueryArgs h = a;
+	h.occ_i = a.heavy;
+	h.n_occ_i = a.n_heavy;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<ARITH, VARIABLE, SYM, SELF, MODE_POOL>), dim3(blocks_heavy), dim3(Q_THREADS), 0, s, h);
+}
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF>
+static void launch_query_3(const QueryArgs& a, const QueryConfig& c, int n_cus, hipStream_t s)
+{
+	int per_cu = 7;
+	if (const char* e = getenv("TNSX_QUERY_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) per_cu = v; }   // tuning knob
+	// a multiple of 8 workgroups so that every XCD gets the same number (workgroup b runs on XCD b % 8)
+	const int blocks = ((n_cus * per_cu + 7) / 8) * 8;
 	if (c.mode == QUERY_COUNT) launch_query_t<ARITH, VARIABLE, SYM, SELF, MODE_COUNT>(a, blocks, s);
 	else if (c.mode == QUERY_FILL) launch_query_t<ARITH, VARIABLE, SYM, SELF, MODE_FILL>(a, blocks, s);
-	else launch_query_t<ARITH, VARIABLE, SYM, SELF, MODE_POOL>(a, blocks, s);
+	else launch_pool_t<ARITH, VARIABLE, SYM, SELF>(a, ((n_cus * 8 + 7) / 8) * 8, ((n_cus * 2 + 7) / 8) * 8, s);
 }
 template <int ARITH, bool VARIABLE, bool SYM>
-static void launch_query_2(const QueryArgs& a, const QueryConfig& c, int blocks, hipStream_t s)
+static void launch_query_2(const QueryArgs& a, const QueryConfig& c, int n_cus, hipStream_t s)
 {
-	if (c.self) launch_query_3<ARITH, VARIABLE, SYM, true>(a, c, blocks, s); else launch_query_3<ARITH, VARIABLE, SYM, false>(a, c, blocks, s);
+	if (c.self) launch_query_3<ARITH, VARIABLE, SYM, true>(a, c, n_cus, s); else launch_query_3<ARITH, VARIABLE, SYM, false>(a, c, n_cus, s);
 }
 template <int ARITH>
-static void launch_query_1(const QueryArgs& a, const QueryConfig& c, int blocks, hipStream_t s)
+static void launch_query_1(const QueryArgs& a, const QueryConfig& c, int n_cus, hipStream_t s)
 {
-	if (!c.variable) launch_query_2<ARITH, false, false>(a, c, blocks, s);
-	else if (c.symmetric) launch_query_2<ARITH, true, true>(a, c, blocks, s);
-	else launch_query_2<ARITH, true, false>(a, c, blocks, s);
+	if (!c.variable) launch_query_2<ARITH, false, false>(a, c, n_cus, s);
+	else if (c.symmetric) launch_query_2<ARITH, true, true>(a, c, n_cus, s);
+	else launch_query_2<ARITH, true, false>(a, c, n_cus, s);
 }
 void launch_query(const QueryArgs& a, const QueryConfig& c, int n_compute_units, hipStream_t s)
 {
-	// persistent grid (a multiple of 8 workgroups so that every XCD gets the same number): waves stride over their
-	// XCD's share of the occupied-cell list, whose length lives in device memory
-	int per_cu = 7;
-	if (const char* e = getenv("TNSX_QUERY_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) per_cu = v; }   // tuning knob
-	int blocks = n_compute_units * per_cu;
-	blocks = ((blocks + 7) / 8) * 8;
-	if (c.arith == 0) launch_query_1<0>(a, c, blocks, s); else launch_query_1<1>(a, c, blocks, s);
+	if (c.arith == 0) launch_query_1<0>(a, c, n_compute_units, s); else launch_query_1<1>(a, c, n_compute_units, s);
 }
 
 }  // namespace tnsx
