@@ -106,6 +106,7 @@ typedef struct tnsx_stats {
 	float ms_total, ms_upload, ms_bounds, ms_keys, ms_sort, ms_gather, ms_cells, ms_count, ms_scan, ms_fill, ms_mirror;
 	int n_pool_pairs;             /* pairs built in single-pass pool mode in the last run */
 	int pool_retries;             /* pool passes repeated because the pool was too small */
+	int n_fast_builds;            /* point sets binned with the counting-sort build (vs the stable radix build) */
 	/* world box of the reference semantics (TreeNSearch.cpp:415-522) */
 	float world_bottom[3], world_top[3];
 	int world_cells_pow2;

@@ -1,0 +1,112 @@
+"""world_size-2 test (gloo, CPU) of the slab decomposition + ghost-halo exchange of treensearch_amd/multi.py.
+
+The product has no CPU search path, so the per-rank search backend is injected: a stand-in with the TreeNSearch API
+whose run() calls the CPU oracle.  What is under test is the distributed logic: which points are exchanged, the
+64-bit global-id transport, the (owned -> owned) + (owned -> ghost) pair set-up and the translation back to global
+ids -- the union of the ranks' results must equal the single-process result on the union of the slabs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+class OracleEngine:
+    """TreeNSearch-shaped stand-in backed by oracle/tns_oracle.c (test infrastructure only)."""
+
+    def __init__(self):
+        from oracle import oracle as O
+        self.orc = O.Oracle()
+        self.sets, self.active, self.radius, self.res = [], set(), None, {}
+
+    def set_search_radius(self, r): self.radius = np.float32(r)
+    def add_point_set(self, pts, radii=None): self.sets.append(pts); return len(self.sets) - 1
+    def resize_point_set(self, s, pts, radii=None): self.sets[s] = pts
+    def set_active_search(self, i, j, on=True): (self.active.add if on else self.active.discard)((i, j))
+
+    def run(self):
+        self.res = {}
+        for (i, j) in self.active:
+            a = self.sets[i].cpu().numpy().reshape(-1, 3)
+            b = self.sets[j].cpu().numpy().reshape(-1, 3)
+            self.res[(i, j)] = self.orc.pair_search(a, b, radius=self.radius, same_set=(i == j))
+
+    def neighbor_csr(self, i, j): return self.res[(i, j)]
+
+
+def _worker(rank, world, port, n_per_rank, radius, tmpdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from treensearch_amd import datagen as D
+        from treensearch_amd.multi import SlabSearch
+        pts = D.uniform_cloud(n_per_rank, 4711, start=rank * n_per_rank)
+        pts[:, 0] += np.float32(rank)                      # slab k = unit cube [k, k+1) x [0,1)^2
+        gids = torch.arange(rank * n_per_rank, (rank + 1) * n_per_rank, dtype=torch.int64)
+        slab = SlabSearch(float(rank), float(rank + 1), float(radius), OracleEngine)
+        t_pts = torch.from_numpy(pts)
+        for step in range(2):                              # second step exercises the resize path
+            slab.step(t_pts, gids)
+        offs, nbr = slab.global_neighbors()
+        np.save(os.path.join(tmpdir, f"offs_{rank}.npy"), offs)
+        np.save(os.path.join(tmpdir, f"nbr_{rank}.npy"), nbr)
+        np.save(os.path.join(tmpdir, f"nghost_{rank}.npy"), np.array([len(slab.ghost_gids), slab.ex.bytes_sent]))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_halo_exchange_matches_single_process(world, tmp_path, oracle):
+    from treensearch_amd import datagen as D
+    n_per_rank, radius = 4000, np.float32(0.09)
+    mp.spawn(_worker, args=(world, _free_port(), n_per_rank, radius, str(tmp_path)), nprocs=world, join=True)
+    # single-process truth on the union of all slabs
+    allp = []
+    for k in range(world):
+        p = D.uniform_cloud(n_per_rank, 4711, start=k * n_per_rank)
+        p[:, 0] += np.float32(k)
+        allp.append(p)
+    allp = np.concatenate(allp)
+    offs, idx = oracle.pair_search(allp, allp, radius=radius, same_set=True)
+    for k in range(world):
+        o = np.load(tmp_path / f"offs_{k}.npy")
+        nb = np.load(tmp_path / f"nbr_{k}.npy")
+        lo = k * n_per_rank
+        ref_o = offs[lo:lo + n_per_rank + 1] - offs[lo]
+        ref_i = idx[offs[lo]:offs[lo + n_per_rank]].astype(np.int64)
+        assert np.array_equal(o, ref_o), f"rank {k}: neighbour counts differ"
+        assert np.array_equal(nb, ref_i), f"rank {k}: global neighbour ids differ"
+        n_ghost, _ = np.load(tmp_path / f"nghost_{k}.npy")
+        assert n_ghost > 0
+        # only a thin halo travels: ~radius/1.0 of each neighbouring slab
+        n_faces = (1 if k > 0 else 0) + (1 if k < world - 1 else 0)
+        assert n_ghost < n_faces * n_per_rank * float(radius) * 1.5
+
+
+def test_halo_masks():
+    from treensearch_amd.multi import slab_halo_masks
+    x = torch.tensor([0.0, 0.04, 0.5, 0.96, 0.999])
+    left, right = slab_halo_masks(x, 0.0, 1.0, 0.05, True, True)
+    assert left.tolist() == [True, True, False, False, False]
+    assert right.tolist() == [False, False, False, True, True]
+    left, right = slab_halo_masks(x, 0.0, 1.0, 0.05, False, True)
+    assert not left.any() and right.sum() == 2

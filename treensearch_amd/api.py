@@ -51,7 +51,7 @@ class Stats(C.Structure):
                 ("ms_total", C.c_float), ("ms_upload", C.c_float), ("ms_bounds", C.c_float), ("ms_keys", C.c_float),
                 ("ms_sort", C.c_float), ("ms_gather", C.c_float), ("ms_cells", C.c_float), ("ms_count", C.c_float),
                 ("ms_scan", C.c_float), ("ms_fill", C.c_float), ("ms_mirror", C.c_float),
-                ("n_pool_pairs", C.c_int), ("pool_retries", C.c_int),
+                ("n_pool_pairs", C.c_int), ("pool_retries", C.c_int), ("n_fast_builds", C.c_int),
                 ("world_bottom", C.c_float * 3), ("world_top", C.c_float * 3), ("world_cells_pow2", C.c_int)]
 
     def as_dict(self):

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libtnsx.so")
-SOURCES = ["tnsx_kernels.hip", "tnsx_query.hip", "tnsx_engine.cpp"]
+SOURCES = ["tnsx_kernels.hip", "tnsx_build.hip", "tnsx_query.hip", "tnsx_engine.cpp"]
 HEADERS = ["tnsx_kernels.h", "tnsx_device.h", os.path.join(ROOT, "include", "tnsx.h")]
 
 # -ffp-contract=off: the neighbour predicate must not be re-associated or fused behind our back
@@ -46,7 +46,8 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc()] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, src), "-o", obj]
+        extra = os.environ.get("TNSX_EXTRA_FLAGS", "").split()     # experiments, e.g. -DTNSX_F4_LAYOUT=1
+        cmd = [hipcc()] + FLAGS + extra + ["-I" + os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -48,6 +48,12 @@ void launch_gather_sorted(const float* xyz, const float* radii, const uint32_t* 
 //      occupied cell (order of blocks of 4096 points is arbitrary), *n_occ = their number (must be zeroed before) ----
 void launch_cell_table(const uint32_t* keys_sorted, int n, uint2* table, uint2* occ, uint32_t* n_occ, hipStream_t s);
 
+// ---- fast build: counting sort by cell (tnsx_build.hip); point order inside a cell = arrival order of the atomics ----
+void launch_bin_count(const float* xyz, int n, GridParams g, uint32_t* count /*zeroed, n_cells+1*/, uint2* keyrank, hipStream_t s);
+void launch_bin_scatter(const float* xyz, const float* radii, const uint2* keyrank, const uint32_t* start, int n, float4* xyzi, float* r2,
+                        hipStream_t s);
+void launch_cells_from_counts(const uint32_t* start /*n_cells+1*/, uint32_t n_cells, uint2* table, uint2* occ, uint32_t* n_occ, hipStream_t s);
+
 // ---- the query ----------------------------------------------------------------------------------
 struct QueryArgs {
 	// query set i

@@ -85,6 +85,10 @@ void launch_cell_table(const uint32_t* keys_sorted, int n, uint2* table, uint2* 
 // =====================================================================================================
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+#ifndef TNSX_F4_LAYOUT
+#define TNSX_F4_LAYOUT 0   // candidate register layout, see process_batch
+#endif
+
 static constexpr int Q_THREADS = 256;
 static constexpr int Q_WAVES = Q_THREADS / WAVE;
 static constexpr int Q_MAXPAIRS = 4;                       // chunk pairs per batch
@@ -102,6 +106,21 @@ __device__ __forceinline__ v2f dist_sq2(float qx, float qy, float qz, v2f cx, v2
 	}
 	else {
 		return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));   // CONTRACTED
+	}
+}
+
+// squared distance of one query to one candidate kept in its float4 (x,y handled as one packed pair)
+template <int ARITH>
+__device__ __forceinline__ float dist_sq1(float qx, float qy, float qz, const float4& c)
+{
+	const v2f dxy = (v2f){ qx, qy } - (v2f){ c.x, c.y };
+	const float dz = __fsub_rn(qz, c.z);
+	if (ARITH == 0) {
+		const v2f sq = dxy * dxy;
+		return __fadd_rn(__fadd_rn(sq.x, sq.y), __fmul_rn(dz, dz));                                 // STRICT
+	}
+	else {
+		return __fmaf_rn(dz, dz, __fmaf_rn(dxy.x, dxy.x, __fmul_rn(dxy.y, dxy.y)));                   // CONTRACTED
 	}
 }
 
@@ -232,7 +251,7 @@ __device__ __forceinline__ void emit_chunk(const int* dst, uint32_t pos, uint64_
 //   MODE_COUNT: run_cnt (lane t) += hits of query t
 //   MODE_FILL : record of query t starts at my_off (lane t); indices appended at my_off + 1 + run_cnt
 //   MODE_POOL : record allocated here (single-batch cells only); my_off (lane t) receives its offset
-template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int MODE, int NC>
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int MODE, int NC, bool EXACT_NC>
 __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef RR, uint32_t wb, int lane, const float4& qv, float qr2, uint32_t qb,
                                               uint32_t nq, uint64_t& my_off, uint32_t& run_cnt, PoolState& ps, uint32_t& wave_hits)
 {
@@ -240,12 +259,35 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 	// the 18 run scalars live only during the load phase (SGPR pressure); the query loop needs just d4 and total
 	const Runs R = extract_runs(RR.run_start, RR.run_len);
 	// ---- candidates of this batch -> registers (all loads independent, issued back to back)
-	v2f cx[NP], cy[NP], cz[NP];
-	uint32_t cid[2 * NP];
-	float cr2[2 * NP];
 	//      Branch-free on purpose: a load inside `if (slot < total)` gets its own exec region and its own
 	//      s_waitcnt, which serialises the round trips.  Out-of-range slots read a clamped (valid) address instead and
 	//      are overwritten with padding afterwards.
+#if TNSX_F4_LAYOUT
+	// layout A: every chunk stays in the float4 it was loaded into (x,y packed per candidate); no repacking, fewer registers
+	float4 c4[NC];
+	float cr2[NC];
+	#pragma unroll
+	for (int k = 0; k < NC; k++) {
+		const uint32_t slot = wb + (uint32_t)(k * WAVE + lane);
+		const uint32_t src = slot < R.total ? slot_to_src(slot, R) : R.d0;   // R.d0 = first candidate of the cell
+		c4[k] = a.xyzi_j[src];
+		cr2[k] = SYM ? a.r2_j[src] : 0.f;
+	}
+	#pragma unroll
+	for (int k = 0; k < NC; k++) {
+		const uint32_t slot = wb + (uint32_t)(k * WAVE + lane);
+		if (!EXACT_NC || k == NC - 1) {      // with an exact chunk count only the last chunk can be partial
+			const bool valid = slot < R.total;
+			c4[k].x = valid ? c4[k].x : FLT_MAX; c4[k].y = valid ? c4[k].y : FLT_MAX; c4[k].z = valid ? c4[k].z : FLT_MAX;
+			c4[k].w = valid ? c4[k].w : __uint_as_float(0xffffffffu);
+			if (SYM) cr2[k] = valid ? cr2[k] : -1.0f;
+		}
+	}
+#else
+	// layout B: chunks paired as (x_k, x_k+1) so that one packed instruction serves two chunks
+	v2f cx[NP], cy[NP], cz[NP];
+	uint32_t cid[2 * NP];
+	float cr2[2 * NP];
 	float4 craw[2 * NP];
 	float r2raw[2 * NP];
 	#pragma unroll
@@ -272,6 +314,7 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 		cid[k] = __float_as_uint(c.w);
 		cr2[k] = r2c;
 	}
+#endif
 	// ---- every query of the cell against them
 	for (uint32_t t = 0; t < nq; t++) {
 		const float qx = readlane_f32(qv.x, (int)t), qy = readlane_f32(qv.y, (int)t), qz = readlane_f32(qv.z, (int)t);
@@ -279,6 +322,15 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 		const uint32_t qi = readlane_u32(__float_as_uint(qv.w), (int)t);
 		// hit masks of all chunks first: every compare writes its lane mask to an SGPR pair, the rest is scalar work
 		uint64_t m[NC];
+#if TNSX_F4_LAYOUT
+		#pragma unroll
+		for (int k = 0; k < NC; k++) {
+			const float d2 = dist_sq1<ARITH>(qx, qy, qz, c4[k]);
+			m[k] = __builtin_amdgcn_ballot_w64(d2 <= r2);
+			if (SYM) m[k] |= __builtin_amdgcn_ballot_w64(d2 <= cr2[k]);
+			if (SELF) m[k] &= __builtin_amdgcn_ballot_w64(__float_as_uint(c4[k].w) != qi);
+		}
+#else
 		#pragma unroll
 		for (int h = 0; h < NP; h++) {
 			const v2f d2 = dist_sq2<ARITH>(qx, qy, qz, cx[h], cy[h], cz[h]);
@@ -294,6 +346,7 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 				}
 			}
 		}
+#endif
 		uint32_t cnt = 0;
 		#pragma unroll
 		for (int k = 0; k < NC; k++) cnt += (uint32_t)__popcll(m[k]);
@@ -314,7 +367,11 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 				uint32_t pos = 0;
 				#pragma unroll
 				for (int k = 0; k < NC; k++) {
+#if TNSX_F4_LAYOUT
+					emit_chunk(dst, pos, m[k], __float_as_uint(c4[k].w));
+#else
 					emit_chunk(dst, pos, m[k], cid[k]);
+#endif
 					pos += (uint32_t)__popcll(m[k]);
 				}
 			}
@@ -331,14 +388,14 @@ __device__ __forceinline__ void process_batch_nc(const QueryArgs& a, const RunRe
 {
 	const uint32_t nc = FULL ? (nb + WAVE - 1) / WAVE : 8u;
 	switch (nc) {
-	case 1: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 1>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
-	case 2: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 2>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
-	case 3: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 3>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
-	case 4: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 4>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
-	case 5: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 5>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
-	case 6: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 6>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
-	case 7: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 7>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
-	default: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 8>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
+	case 1: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 1, FULL>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
+	case 2: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 2, FULL>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
+	case 3: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 3, FULL>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
+	case 4: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 4, FULL>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
+	case 5: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 5, FULL>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
+	case 6: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 6, FULL>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
+	case 7: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 7, FULL>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
+	default: process_batch<ARITH, VARIABLE, SYM, SELF, MODE, 8, FULL>(a, RR, wb, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits); break;
 	}
 }
 
@@ -373,7 +430,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 		RunRef RR;
 		RR.run_start = (e > s) ? s : ((e1 > s1) ? s1 : s2);
 		const uint32_t run_end = (e2 > s2) ? e2 : ((e1 > s1) ? e1 : e);
-		RR.run_len = run_end > RR.run_start ? run_end - RR.run_start : 0u;
+		RR.run_len = ((e > s) || (e1 > s1) || (e2 > s2)) ? run_end - RR.run_start : 0u;   // empty entries may hold any (s,s)
 		{
 			const Runs R0 = extract_runs(RR.run_start, RR.run_len);
 			RR.total = R0.total;
@@ -497,7 +554,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 			RunRef RR;
 			RR.run_start = (e > s) ? s : ((e1 > s1) ? s1 : s2);
 			const uint32_t run_end = (e2 > s2) ? e2 : ((e1 > s1) ? e1 : e);
-			RR.run_len = run_end > RR.run_start ? run_end - RR.run_start : 0u;
+			RR.run_len = ((e > s) || (e1 > s1) || (e2 > s2)) ? run_end - RR.run_start : 0u;   // empty entries may hold any (s,s)
 			{
 				const Runs R0 = extract_runs(RR.run_start, RR.run_len);
 				RR.total = R0.total;
