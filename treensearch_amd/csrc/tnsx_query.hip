@@ -136,7 +136,7 @@ struct Runs {
 struct RunRef {
 	uint32_t run_start, run_len;   // per lane; lanes 0,3,..,24 hold run 0..8
 	uint32_t total;                // wave-uniform: number of candidates
-	uint32_t d4;                   // wave-uniform: delta of the centre run (the one holding the query cell itself)
+	uint32_t d_self;               // wave-uniform: sorted position of slot 0 = start of the centre run (holds the query cell itself)
 };
 
 __device__ __forceinline__ Runs extract_runs(uint32_t run_start, uint32_t run_len)
@@ -146,7 +146,9 @@ __device__ __forceinline__ Runs extract_runs(uint32_t run_start, uint32_t run_le
 #define TNSX_RUN(r, P, D)                                                       \
 	rs = readlane_u32(run_start, 3 * r); rn = readlane_u32(run_len, 3 * r); \
 	P = acc; D = rs - acc; acc += rn;
-	TNSX_RUN(0, p0_unused, R.d0) TNSX_RUN(1, R.p1, R.d1) TNSX_RUN(2, R.p2, R.d2) TNSX_RUN(3, R.p3, R.d3) TNSX_RUN(4, R.p4, R.d4)
+	// slot order: the CENTRE row (physical run 4, it contains the query cell itself) first, then the other eight.  The query
+	// cell's own points therefore sit at slots [len(cell x-1), len(cell x-1) + nq), i.e. in chunk 0 or 1 for simple cells.
+	TNSX_RUN(4, p0_unused, R.d0) TNSX_RUN(0, R.p1, R.d1) TNSX_RUN(1, R.p2, R.d2) TNSX_RUN(2, R.p3, R.d3) TNSX_RUN(3, R.p4, R.d4)
 	TNSX_RUN(5, R.p5, R.d5) TNSX_RUN(6, R.p6, R.d6) TNSX_RUN(7, R.p7, R.d7) TNSX_RUN(8, R.p8, R.d8)
 #undef TNSX_RUN
 	(void)p0_unused;
@@ -227,12 +229,12 @@ __device__ __forceinline__ uint64_t pool_alloc(const QueryArgs& a, PoolState& ps
 	return off;
 }
 
-// Appends the set lanes of mask m (their value v) to dst[pos...] in lane order.  Hand-scheduled: exec is loaded from
+// Appends the set lanes of mask m (their value v) to rec[1 + pos...] in lane order (rec[0] is the record's count word).  Hand-scheduled: exec is loaded from
 // the mask and restored to all-ones (every lane of the wave is active wherever this is called), which costs two
 // scalar instructions instead of the compiler's s_and_saveexec / s_cbranch_execz / s_or triple -- the scalar unit is
 // the scarce resource of this kernel.  The store is younger than every load the compiler tracks, so its untracked
 // vmcnt increment can only make the compiler's waits longer, never shorter.
-__device__ __forceinline__ void emit_chunk(const int* dst, uint32_t pos, uint64_t m, uint32_t v)
+__device__ __forceinline__ void emit_chunk(const int* rec, uint32_t pos, uint64_t m, uint32_t v)
 {
 	uint32_t tmp;
 	asm volatile(
@@ -240,10 +242,10 @@ __device__ __forceinline__ void emit_chunk(const int* dst, uint32_t pos, uint64_
 		"v_mbcnt_lo_u32_b32 %[t], %[mlo], 0\n\t"
 		"v_mbcnt_hi_u32_b32 %[t], %[mhi], %[t]\n\t"
 		"v_add_lshl_u32 %[t], %[t], %[pos], 2\n\t"
-		"global_store_dword %[t], %[v], %[base]\n\t"
+		"global_store_dword %[t], %[v], %[base] offset:4\n\t"
 		"s_mov_b64 exec, -1"
 		: [t] "=&v"(tmp)
-		: [m] "s"(m), [mlo] "s"((uint32_t)m), [mhi] "s"((uint32_t)(m >> 32)), [pos] "s"(pos), [v] "v"(v), [base] "s"(dst)
+		: [m] "s"(m), [mlo] "s"((uint32_t)m), [mhi] "s"((uint32_t)(m >> 32)), [pos] "s"(pos), [v] "v"(v), [base] "s"(rec)
 		: "memory");
 }
 
@@ -251,7 +253,9 @@ __device__ __forceinline__ void emit_chunk(const int* dst, uint32_t pos, uint64_
 //   MODE_COUNT: run_cnt (lane t) += hits of query t
 //   MODE_FILL : record of query t starts at my_off (lane t); indices appended at my_off + 1 + run_cnt
 //   MODE_POOL : record allocated here (single-batch cells only); my_off (lane t) receives its offset
-template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int MODE, int NC, bool EXACT_NC>
+// SELF: 0 = other set, 1 = exclude the query itself with an index compare in every chunk,
+//       2 = clear the query's own bit in chunk 0/1 with scalar ops (only legal when its slot is < 128, see the fast kernel)
+template <int ARITH, bool VARIABLE, bool SYM, int SELF, int MODE, int NC, bool EXACT_NC>
 __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef RR, uint32_t wb, int lane, const float4& qv, float qr2, uint32_t qb,
                                               uint32_t nq, uint64_t& my_off, uint32_t& run_cnt, PoolState& ps, uint32_t& wave_hits)
 {
@@ -328,7 +332,7 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 			const float d2 = dist_sq1<ARITH>(qx, qy, qz, c4[k]);
 			m[k] = __builtin_amdgcn_ballot_w64(d2 <= r2);
 			if (SYM) m[k] |= __builtin_amdgcn_ballot_w64(d2 <= cr2[k]);
-			if (SELF) m[k] &= __builtin_amdgcn_ballot_w64(__float_as_uint(c4[k].w) != qi);
+			if (SELF == 1) m[k] &= __builtin_amdgcn_ballot_w64(__float_as_uint(c4[k].w) != qi);
 		}
 #else
 		#pragma unroll
@@ -342,11 +346,18 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 					if (SYM) m[k] |= __builtin_amdgcn_ballot_w64(d2[u] <= cr2[k]);
 					// self exclusion by index: one VALU compare + one s_and per chunk.  (Clearing the one self bit with
 					// scalar ops costs 4-5 SALU per chunk, and the CU's single scalar unit is as scarce as its 4 SIMDs.)
-					if (SELF) m[k] &= __builtin_amdgcn_ballot_w64(cid[k] != qi);
+					if (SELF == 1) m[k] &= __builtin_amdgcn_ballot_w64(cid[k] != qi);
 				}
 			}
 		}
 #endif
+		if (SELF == 2) {
+			// the query is always a hit of itself (d2 == 0); its slot is its sorted position minus the start of the centre run
+			const uint32_t ss = (qb + t) - RR.d_self - wb;
+			const uint64_t bit = 1ull << (ss & 63u);
+			m[0] &= ~(ss < 64u ? bit : 0ull);
+			if (NC > 1) m[1] &= ~((ss >= 64u && ss < 128u) ? bit : 0ull);
+		}
 		uint32_t cnt = 0;
 		#pragma unroll
 		for (int k = 0; k < NC; k++) cnt += (uint32_t)__popcll(m[k]);
@@ -363,7 +374,7 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 				off = (((uint64_t)hi << 32) | lo) + readlane_u32(run_cnt, (int)t);
 			}
 			if (ok) {
-				const int* dst = a.records + off + 1u;
+				const int* dst = a.records + off;   // record start; emit_chunk skips the count word
 				uint32_t pos = 0;
 				#pragma unroll
 				for (int k = 0; k < NC; k++) {
@@ -382,7 +393,7 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 }
 
 // FULL = false: only the 8-chunk body is instantiated (used on the rare multi-batch path to keep the code small)
-template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int MODE, bool FULL>
+template <int ARITH, bool VARIABLE, bool SYM, int SELF, int MODE, bool FULL>
 __device__ __forceinline__ void process_batch_nc(const QueryArgs& a, const RunRef RR, uint32_t wb, uint32_t nb, int lane, const float4& qv, float qr2,
                                                  uint32_t qb, uint32_t nq, uint64_t& my_off, uint32_t& run_cnt, PoolState& ps, uint32_t& wave_hits)
 {
@@ -434,7 +445,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 		{
 			const Runs R0 = extract_runs(RR.run_start, RR.run_len);
 			RR.total = R0.total;
-			RR.d4 = R0.d4;
+			RR.d_self = R0.d0;
 		}
 		const uint2 cur_q = qrange;
 
@@ -522,7 +533,153 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 // =====================================================================================================
 static constexpr uint32_t Q_TICKET = 8;
 
+// Instruction budget notes (tools/ubench/issue_model.hip, MI355X): a scalar instruction costs ~4.3 SIMD cycles -- as much
+// as a v_cmp or a packed-fp32 op, more than a plain VALU op (2.6) -- and overlaps only partly with VALU work of other
+// waves.  The fast path below therefore minimises the TOTAL instruction count per query point:
+//   * the allocator state lives in three scalars (record pointer, ints left, slab-inside-pool flag): one 32-bit compare
+//     and a pointer bump per query;
+//   * no 64-bit compares or offset/pointer conversions inside the loop; the per-lane record pointer is turned into an
+//     offset once per cell.
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int NC>
+__device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits)
+{
+	constexpr int NP = (NC + 1) / 2;
+	const uint32_t nq = cur_q.y - cur_q.x;
+	const Runs R = extract_runs(RR.run_start, RR.run_len);
+	// ---- candidates -> registers (branch-free, see process_batch)
+	v2f cx[NP], cy[NP], cz[NP];
+	uint32_t cid[2 * NP];
+	float cr2[2 * NP];
+	float4 craw[2 * NP];
+	float r2raw[2 * NP];
+	#pragma unroll
+	for (int k = 0; k < 2 * NP; k++) {
+		if (k < NC) {
+			const uint32_t slot = (uint32_t)(k * WAVE + lane);
+			const uint32_t src = (k < NC - 1 || slot < R.total) ? slot_to_src(slot, R) : R.d0;
+			craw[k] = a.xyzi_j[src];
+			if (SYM) r2raw[k] = a.r2_j[src];
+		}
+	}
+	// the cell's query points, one per lane (clamped, branch-free load)
+	const uint32_t qsrc = cur_q.x + ((uint32_t)lane < nq ? (uint32_t)lane : 0u);
+	const float4 qv = a.xyzi_i[qsrc];
+	float qr2 = a.r2_fixed;
+	if (VARIABLE) qr2 = a.r2_i[qsrc];
+	const uint32_t qidx = __float_as_uint(qv.w);
+	#pragma unroll
+	for (int k = 0; k < 2 * NP; k++) {
+		float4 c = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, __uint_as_float(0xffffffffu));
+		float r2c = -1.0f;
+		if (k < NC) {
+			c = craw[k];
+			if (SYM) r2c = r2raw[k];
+			if (k == NC - 1) {   // the chunk count is exact: only the last chunk can be partial
+				const bool valid = (uint32_t)(k * WAVE + lane) < R.total;
+				c.x = valid ? c.x : FLT_MAX; c.y = valid ? c.y : FLT_MAX; c.z = valid ? c.z : FLT_MAX;
+				c.w = valid ? c.w : __uint_as_float(0xffffffffu);
+				if (SYM) r2c = valid ? r2c : -1.0f;
+			}
+		}
+		cx[k >> 1][k & 1] = c.x; cy[k >> 1][k & 1] = c.y; cz[k >> 1][k & 1] = c.z;
+		cid[k] = __float_as_uint(c.w);
+		cr2[k] = r2c;
+	}
+
+	// ---- allocator state in plain scalars: byte pointer of the next record, ints left in the slab, slab-inside-pool flag
+	uint32_t left = readfirstlane_u32(ps.left);
+	bool ok = readfirstlane_u32(ps.ok) != 0u;        // (explicitly uniform: otherwise `if (ok)` becomes an exec-masked region)
+	const int* rec = a.records + (((uint64_t)readfirstlane_u32(ps.cur_hi) << 32) | readfirstlane_u32(ps.cur_lo));
+
+	// ---- the query loop.  (Fetching the query point with a scalar load one iteration ahead instead of v_readlane was
+	//      tried and dropped: the compiler is free to copy the destination SGPRs before the asynchronous load has landed.)
+	uint32_t run_cnt = 0, hits = 0;
+	const int* my_rec = nullptr;                     // lane t: start of the record of query t (nullptr: not written)
+	for (uint32_t t = 0; t < nq; t++) {
+		const float qx = readlane_f32(qv.x, (int)t), qy = readlane_f32(qv.y, (int)t), qz = readlane_f32(qv.z, (int)t);
+		const float r2q = VARIABLE ? readlane_f32(qr2, (int)t) : a.r2_fixed;
+		uint64_t m[NC];
+		#pragma unroll
+		for (int h = 0; h < NP; h++) {
+			const v2f d2 = dist_sq2<ARITH>(qx, qy, qz, cx[h], cy[h], cz[h]);
+			#pragma unroll
+			for (int u = 0; u < 2; u++) {
+				const int k = 2 * h + u;
+				if (k < NC) {
+					m[k] = __builtin_amdgcn_ballot_w64(d2[u] <= r2q);
+					if (SYM) m[k] |= __builtin_amdgcn_ballot_w64(d2[u] <= cr2[k]);
+				}
+			}
+		}
+		if (SELF) {
+			// the query is always a hit of itself (d2 == 0); its slot is its sorted position minus the start of the centre run
+			const uint32_t ss = (cur_q.x + t) - RR.d_self;
+			const uint64_t bit = 1ull << (ss & 63u);
+			m[0] &= ~(ss < 64u ? bit : 0ull);
+			if (NC > 1) m[1] &= ~(ss >= 64u ? bit : 0ull);
+		}
+		uint32_t cnt = 0;
+		#pragma unroll
+		for (int k = 0; k < NC; k++) cnt += (uint32_t)__popcll(m[k]);
+		const uint32_t len = cnt + 1u;
+		if (len > left) {
+			// rare: new slab (one atomic on the global cursor)
+			const uint32_t sz = len > a.pool_slab ? len : a.pool_slab;
+			const unsigned long long old = pool_take_slab(a.pool_cursor, sz);
+			const uint64_t base = ((uint64_t)readfirstlane_u32((uint32_t)(old >> 32)) << 32) | readfirstlane_u32((uint32_t)old);
+			rec = a.records + base;
+			left = sz;
+			ok = readfirstlane_u32(base + sz <= a.pool_capacity ? 1u : 0u) != 0u;
+		}
+		if (ok) {
+			uint32_t pos = 0;
+			#pragma unroll
+			for (int k = 0; k < NC; k++) {
+				emit_chunk(rec, pos, m[k], cid[k]);
+				pos += (uint32_t)__popcll(m[k]);
+			}
+		}
+		if ((uint32_t)lane == t) { run_cnt = cnt; my_rec = ok ? rec : nullptr; }
+		rec += len;
+		left -= len;
+		hits += cnt;
+	}
+	wave_hits += hits;
+	{
+		const uint64_t cur = (uint64_t)(rec - a.records);
+		ps.cur_lo = (uint32_t)cur; ps.cur_hi = (uint32_t)(cur >> 32);
+		ps.left = left;
+		ps.ok = ok ? 1u : 0u;
+	}
+	if ((uint32_t)lane < nq && my_rec != nullptr) {
+		const uint64_t my_off = (uint64_t)(my_rec - a.records);
+		a.records[my_off] = (int)run_cnt;
+		a.offs_by_orig[qidx] = my_off;
+	}
+}
+
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF>
+__device__ __forceinline__ void fast_cell_nc(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits)
+{
+	switch ((RR.total + WAVE - 1) / WAVE) {
+	case 1: fast_cell<ARITH, VARIABLE, SYM, SELF, 1>(a, RR, lane, cur_q, ps, wave_hits); break;
+	case 2: fast_cell<ARITH, VARIABLE, SYM, SELF, 2>(a, RR, lane, cur_q, ps, wave_hits); break;
+	case 3: fast_cell<ARITH, VARIABLE, SYM, SELF, 3>(a, RR, lane, cur_q, ps, wave_hits); break;
+	case 4: fast_cell<ARITH, VARIABLE, SYM, SELF, 4>(a, RR, lane, cur_q, ps, wave_hits); break;
+	case 5: fast_cell<ARITH, VARIABLE, SYM, SELF, 5>(a, RR, lane, cur_q, ps, wave_hits); break;
+	case 6: fast_cell<ARITH, VARIABLE, SYM, SELF, 6>(a, RR, lane, cur_q, ps, wave_hits); break;
+	case 7: fast_cell<ARITH, VARIABLE, SYM, SELF, 7>(a, RR, lane, cur_q, ps, wave_hits); break;
+	default: fast_cell<ARITH, VARIABLE, SYM, SELF, 8>(a, RR, lane, cur_q, ps, wave_hits); break;
+	}
+}
+
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF>
+#ifndef TNSX_FAST_WAVES_PER_EU
+#define TNSX_FAST_WAVES_PER_EU 0   // 0 = let the compiler choose
+#endif
+#if TNSX_FAST_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(TNSX_FAST_WAVES_PER_EU, TNSX_FAST_WAVES_PER_EU)))
+#endif
 __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a)
 {
 	const int lane = lane_id();
@@ -558,7 +715,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 			{
 				const Runs R0 = extract_runs(RR.run_start, RR.run_len);
 				RR.total = R0.total;
-				RR.d4 = R0.d4;
+				RR.d_self = R0.d0;
 			}
 			const uint2 cur_q = qrange;
 			const uint32_t cur_key = key;
@@ -569,33 +726,13 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 				qrange = a.table_i[key];
 			}
 			const uint32_t nq = cur_q.y - cur_q.x;
-			if (RR.total > (uint32_t)Q_SLOTS || nq > (uint32_t)WAVE) {
+			// (cells without any candidate -- possible when set_j is another, sparser or empty set -- also take the general path)
+			if (RR.total == 0u || RR.total > (uint32_t)Q_SLOTS || nq > (uint32_t)WAVE || (SELF && (cur_q.y - RR.d_self) > 2u * WAVE)) {
 				// not simple: leave it to the general kernel
 				if (lane == 0) { const uint32_t h = atomicAdd(a.n_heavy, 1u); a.heavy[h] = make_uint2(cur_p0, cur_key); }
 				continue;
 			}
-			float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
-			float qr2 = a.r2_fixed;
-			uint64_t my_off = 0;
-			if ((uint32_t)lane < nq) {
-				qv = a.xyzi_i[cur_q.x + lane];
-				if (VARIABLE) qr2 = a.r2_i[cur_q.x + lane];
-			}
-			uint32_t run_cnt = 0;
-			if (RR.total > 0) {
-				process_batch_nc<ARITH, VARIABLE, SYM, SELF, MODE_POOL, true>(a, RR, 0u, RR.total, lane, qv, qr2, cur_q.x, nq, my_off, run_cnt, ps, wave_hits);
-			}
-			else {
-				for (uint32_t t = 0; t < nq; t++) {
-					bool ok1;
-					const uint64_t off = pool_alloc(a, ps, 1u, lane, ok1);
-					if ((uint32_t)lane == t) my_off = ok1 ? off : ~0ull;
-				}
-			}
-			if ((uint32_t)lane < nq && my_off != ~0ull) {
-				a.records[my_off] = (int)run_cnt;
-				a.offs_by_orig[__float_as_uint(qv.w)] = my_off;
-			}
+			fast_cell_nc<ARITH, VARIABLE, SYM, SELF>(a, RR, lane, cur_q, ps, wave_hits);
 		}
 	}
 	if (lane == 0 && wave_hits) atomicAdd(a.hit_total, (unsigned long long)wave_hits);
