@@ -95,7 +95,7 @@ struct PairResult {
 	uint64_t n_neighbors = 0;
 	uint64_t need_hint = 0;      // neighbours + points of the previous run: sizes the pool of the next one
 	uint32_t pool_slab = 16384;
-	DevBuf counts, offs_sorted, offs_orig, records, heavy;
+	DevBuf counts, offs_sorted, offs_orig, records, heavy, heavy2;
 	PinnedBuf h_offs, h_records;
 	bool mirrored = false;
 };
@@ -624,7 +624,7 @@ tnsx_status tnsx_run(tnsx_context* c)
 	HIPCHK(c, c->h_small.reserve(sizeof(uint64_t) * (2 * jobs.size() + 2) + sizeof(uint32_t) * (size_t)(n_sets + 1) + 64));
 	uint64_t* h_ctrl = c->h_small.as<uint64_t>();                       // per job: {cursor | total, hit_total}
 	uint32_t* h_nocc = reinterpret_cast<uint32_t*>(h_ctrl + 2 * jobs.size() + 2);
-	HIPCHK(c, c->pool_ctrl.reserve(sizeof(uint64_t) * 8 * (jobs.size() + 1)));   // per job: cursor, hit_total, 8 tickets, n_heavy
+	HIPCHK(c, c->pool_ctrl.reserve(sizeof(uint64_t) * 16 * (jobs.size() + 1)));   // per job: cursor, hit_total, 2 x (8 tickets, n_heavy)
 	unsigned long long* d_ctrl = c->pool_ctrl.as<unsigned long long>();
 	const int query_waves = c->n_cus * 8 * 4;
 
@@ -642,11 +642,14 @@ tnsx_status tnsx_run(tnsx_context* c)
 		a.offs_sorted = pr.offs_sorted.as<uint64_t>();
 		a.records = pr.records.as<int>();
 		a.offs_by_orig = pr.offs_orig.as<uint64_t>();
-		a.pool_cursor = d_ctrl + 8 * k;
-		a.hit_total = d_ctrl + 8 * k + 1;
-		a.tickets = reinterpret_cast<uint32_t*>(d_ctrl + 8 * k + 2);
-		a.n_heavy = reinterpret_cast<uint32_t*>(d_ctrl + 8 * k + 6);
+		a.pool_cursor = d_ctrl + 16 * k;
+		a.hit_total = d_ctrl + 16 * k + 1;
+		a.tickets = reinterpret_cast<uint32_t*>(d_ctrl + 16 * k + 2);
+		a.n_heavy = reinterpret_cast<uint32_t*>(d_ctrl + 16 * k + 6);
+		a.tickets2 = reinterpret_cast<uint32_t*>(d_ctrl + 16 * k + 8);
+		a.n_heavy2 = reinterpret_cast<uint32_t*>(d_ctrl + 16 * k + 12);
 		a.heavy = pr.heavy.as<uint2>();
+		a.heavy2 = pr.heavy2.as<uint2>();
 		a.pool_capacity = c->debug_nostore ? 0 : pr.records.cap / sizeof(int);
 		a.pool_slab = pr.pool_slab;
 		return a;
@@ -659,7 +662,7 @@ tnsx_status tnsx_run(tnsx_context* c)
 	auto launch_pool = [&](size_t k) -> tnsx_status {
 		const Job& jb = jobs[k];
 		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
-		HIPCHK(c, hipMemsetAsync(d_ctrl + 8 * k, 0, 8 * sizeof(uint64_t), st));
+		HIPCHK(c, hipMemsetAsync(d_ctrl + 16 * k, 0, 16 * sizeof(uint64_t), st));
 		const int t0 = tm.mark();
 		if (pr.n_i > 0) {
 			qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_POOL;
@@ -667,7 +670,7 @@ tnsx_status tnsx_run(tnsx_context* c)
 		}
 		const int t1 = tm.mark();
 		span(ST_FILL, t0, t1);
-		HIPCHK(c, hipMemcpyAsync(h_ctrl + 2 * k, d_ctrl + 8 * k, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+		HIPCHK(c, hipMemcpyAsync(h_ctrl + 2 * k, d_ctrl + 16 * k, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
 		return TNSX_OK;
 	};
 
@@ -685,7 +688,10 @@ tnsx_status tnsx_run(tnsx_context* c)
 			slab = std::min<uint64_t>(16384, std::max<uint64_t>(256, slab));
 			pr.pool_slab = (uint32_t)slab;
 			HIPCHK(c, pr.records.reserve((expect + (uint64_t)query_waves * slab * 2) * sizeof(int)));
-			HIPCHK(c, pr.heavy.reserve((size_t)std::max(n_i, 1) * sizeof(uint2)));
+			// worklists of the cells the fast / fat kernels pass on (at most one entry per occupied cell)
+			const size_t max_cells = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_i, n_cells));
+			HIPCHK(c, pr.heavy.reserve(max_cells * sizeof(uint2)));
+			HIPCHK(c, pr.heavy2.reserve(max_cells * sizeof(uint2)));
 			const tnsx_status r = launch_pool(k);
 			if (r != TNSX_OK) return r;
 		}

@@ -77,6 +77,7 @@ struct QueryArgs {
 	uint32_t* tickets;                 // [8] per-XCD ticket counters of the fast kernel (zeroed before the launch)
 	uint2* heavy;                      // worklist {first sorted position, key} of the cells the fast kernel skipped
 	uint32_t* n_heavy;                 // its length (zeroed before the launch)
+	uint32_t* tickets2; uint2* heavy2; uint32_t* n_heavy2;   // the same for the second tier (fat kernel -> general kernel)
 };
 enum { QUERY_COUNT = 0, QUERY_FILL = 1, QUERY_POOL = 2 };
 struct QueryConfig {

@@ -658,32 +658,55 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 	}
 }
 
-template <int ARITH, bool VARIABLE, bool SYM, bool SELF>
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF, bool FAT>
 __device__ __forceinline__ void fast_cell_nc(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits)
 {
-	switch ((RR.total + WAVE - 1) / WAVE) {
-	case 1: fast_cell<ARITH, VARIABLE, SYM, SELF, 1>(a, RR, lane, cur_q, ps, wave_hits); break;
-	case 2: fast_cell<ARITH, VARIABLE, SYM, SELF, 2>(a, RR, lane, cur_q, ps, wave_hits); break;
-	case 3: fast_cell<ARITH, VARIABLE, SYM, SELF, 3>(a, RR, lane, cur_q, ps, wave_hits); break;
-	case 4: fast_cell<ARITH, VARIABLE, SYM, SELF, 4>(a, RR, lane, cur_q, ps, wave_hits); break;
-	case 5: fast_cell<ARITH, VARIABLE, SYM, SELF, 5>(a, RR, lane, cur_q, ps, wave_hits); break;
-	case 6: fast_cell<ARITH, VARIABLE, SYM, SELF, 6>(a, RR, lane, cur_q, ps, wave_hits); break;
-	case 7: fast_cell<ARITH, VARIABLE, SYM, SELF, 7>(a, RR, lane, cur_q, ps, wave_hits); break;
-	default: fast_cell<ARITH, VARIABLE, SYM, SELF, 8>(a, RR, lane, cur_q, ps, wave_hits); break;
+	const uint32_t nc = (RR.total + WAVE - 1) / WAVE;
+	if (!FAT) {
+		switch (nc) {
+		case 1: fast_cell<ARITH, VARIABLE, SYM, SELF, 1>(a, RR, lane, cur_q, ps, wave_hits); break;
+		case 2: fast_cell<ARITH, VARIABLE, SYM, SELF, 2>(a, RR, lane, cur_q, ps, wave_hits); break;
+		case 3: fast_cell<ARITH, VARIABLE, SYM, SELF, 3>(a, RR, lane, cur_q, ps, wave_hits); break;
+		case 4: fast_cell<ARITH, VARIABLE, SYM, SELF, 4>(a, RR, lane, cur_q, ps, wave_hits); break;
+		case 5: fast_cell<ARITH, VARIABLE, SYM, SELF, 5>(a, RR, lane, cur_q, ps, wave_hits); break;
+		case 6: fast_cell<ARITH, VARIABLE, SYM, SELF, 6>(a, RR, lane, cur_q, ps, wave_hits); break;
+		case 7: fast_cell<ARITH, VARIABLE, SYM, SELF, 7>(a, RR, lane, cur_q, ps, wave_hits); break;
+		default: fast_cell<ARITH, VARIABLE, SYM, SELF, 8>(a, RR, lane, cur_q, ps, wave_hits); break;
+		}
+	}
+	else {
+		// 513..1024 candidates (dense cells, or h = r_max much larger than most radii): same single pass, more registers
+		switch (nc) {
+		case 9: fast_cell<ARITH, VARIABLE, SYM, SELF, 9>(a, RR, lane, cur_q, ps, wave_hits); break;
+		case 10: fast_cell<ARITH, VARIABLE, SYM, SELF, 10>(a, RR, lane, cur_q, ps, wave_hits); break;
+		case 11: fast_cell<ARITH, VARIABLE, SYM, SELF, 11>(a, RR, lane, cur_q, ps, wave_hits); break;
+		case 12: fast_cell<ARITH, VARIABLE, SYM, SELF, 12>(a, RR, lane, cur_q, ps, wave_hits); break;
+		case 13: fast_cell<ARITH, VARIABLE, SYM, SELF, 13>(a, RR, lane, cur_q, ps, wave_hits); break;
+		case 14: fast_cell<ARITH, VARIABLE, SYM, SELF, 14>(a, RR, lane, cur_q, ps, wave_hits); break;
+		case 15: fast_cell<ARITH, VARIABLE, SYM, SELF, 15>(a, RR, lane, cur_q, ps, wave_hits); break;
+		default: fast_cell<ARITH, VARIABLE, SYM, SELF, 16>(a, RR, lane, cur_q, ps, wave_hits); break;
+		}
 	}
 }
 
-template <int ARITH, bool VARIABLE, bool SYM, bool SELF>
 #ifndef TNSX_FAST_WAVES_PER_EU
 #define TNSX_FAST_WAVES_PER_EU 0   // 0 = let the compiler choose
 #endif
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF, bool FAT>
 #if TNSX_FAST_WAVES_PER_EU
 __attribute__((amdgpu_waves_per_eu(TNSX_FAST_WAVES_PER_EU, TNSX_FAST_WAVES_PER_EU)))
 #endif
 __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a)
 {
+	// FAT = false: cells from the occupied-cell list, 1..8 chunks; the rest -> a.heavy.
+	// FAT = true : cells from a.heavy, 9..16 chunks; the rest -> a.heavy2 (general kernel).
+	constexpr uint32_t MAX_SLOTS = FAT ? 2u * Q_SLOTS : (uint32_t)Q_SLOTS;
+	const uint2* __restrict__ cell_list = FAT ? a.heavy : a.occ_i;
+	uint2* __restrict__ reject_list = FAT ? a.heavy2 : a.heavy;
+	uint32_t* reject_count = FAT ? a.n_heavy2 : a.n_heavy;
+	uint32_t* tickets = FAT ? a.tickets2 : a.tickets;
 	const int lane = lane_id();
-	const uint32_t n_occ = *a.n_occ_i;
+	const uint32_t n_occ = FAT ? *a.n_heavy : *a.n_occ_i;
 	const uint32_t xcd = blockIdx.x & 7u;
 	const uint32_t lo = (uint32_t)(((uint64_t)n_occ * xcd) >> 3), hi = (uint32_t)(((uint64_t)n_occ * (xcd + 1u)) >> 3);
 	PoolState ps = { 0u, 0u, 0u, 0u };
@@ -691,19 +714,20 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 
 	for (;;) {
 		uint32_t ticket = 0;
-		if (lane == 0) ticket = atomicAdd(a.tickets + xcd, 1u);
+		if (lane == 0) ticket = atomicAdd(tickets + xcd, 1u);
 		ticket = readfirstlane_u32(ticket);
 		const uint32_t first = lo + ticket * Q_TICKET;
 		if (first >= hi) break;
 		const uint32_t ncell = (hi - first) < Q_TICKET ? (hi - first) : Q_TICKET;
 		// the ticket's occupied-cell entries, one per lane
 		uint2 ocv = make_uint2(0u, 0u);
-		if ((uint32_t)lane < ncell) ocv = a.occ_i[first + lane];
+		if ((uint32_t)lane < ncell) ocv = cell_list[first + lane];
 		// lookups of the first cell; afterwards always one cell ahead
 		uint32_t s, e;
 		uint32_t key = readlane_u32(ocv.y, 0);
 		lookup_cell(a, key, true, lane, s, e);
 		uint2 qrange = a.table_i[key];
+		uint32_t heavy_mask = 0;
 
 		for (uint32_t c = 0; c < ncell; c++) {
 			const uint32_t s1 = __shfl_down(s, 1, WAVE), e1 = __shfl_down(e, 1, WAVE);
@@ -718,21 +742,35 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 				RR.d_self = R0.d0;
 			}
 			const uint2 cur_q = qrange;
-			const uint32_t cur_key = key;
-			const uint32_t cur_p0 = readlane_u32(ocv.x, (int)c);
 			if (c + 1 < ncell) {
 				key = readlane_u32(ocv.y, (int)(c + 1));
 				lookup_cell(a, key, true, lane, s, e);
 				qrange = a.table_i[key];
 			}
 			const uint32_t nq = cur_q.y - cur_q.x;
-			// (cells without any candidate -- possible when set_j is another, sparser or empty set -- also take the general path)
-			if (RR.total == 0u || RR.total > (uint32_t)Q_SLOTS || nq > (uint32_t)WAVE || (SELF && (cur_q.y - RR.d_self) > 2u * WAVE)) {
-				// not simple: leave it to the general kernel
-				if (lane == 0) { const uint32_t h = atomicAdd(a.n_heavy, 1u); a.heavy[h] = make_uint2(cur_p0, cur_key); }
+			if (RR.total > MAX_SLOTS || nq > (uint32_t)WAVE || (SELF && (cur_q.y - RR.d_self) > 2u * WAVE)) {
+				heavy_mask |= 1u << c;      // not simple: leave it to the general kernel (appended after the ticket's loop)
 				continue;
 			}
-			fast_cell_nc<ARITH, VARIABLE, SYM, SELF>(a, RR, lane, cur_q, ps, wave_hits);
+			if (RR.total == 0u) {
+				// no candidate at all (set_j is another, sparser or empty set): nq empty records, one int each
+				bool okz;
+				const uint64_t off = pool_alloc(a, ps, nq, lane, okz);
+				if ((uint32_t)lane < nq && okz) {
+					a.records[off + lane] = 0;
+					a.offs_by_orig[__float_as_uint(a.xyzi_i[cur_q.x + lane].w)] = off + lane;
+				}
+				continue;
+			}
+			fast_cell_nc<ARITH, VARIABLE, SYM, SELF, FAT>(a, RR, lane, cur_q, ps, wave_hits);
+		}
+		if (heavy_mask) {
+			// one atomic per ticket; lane c still holds the {first position, key} entry of the ticket's cell c
+			const uint32_t nh = (uint32_t)__popc(heavy_mask);
+			uint32_t hb = 0;
+			if (lane == 0) hb = atomicAdd(reject_count, nh);
+			hb = readfirstlane_u32(hb);
+			if ((uint32_t)lane < ncell && ((heavy_mask >> lane) & 1u)) reject_list[hb + (uint32_t)__popc(heavy_mask & ((1u << lane) - 1u))] = ocv;
 		}
 	}
 	if (lane == 0 && wave_hits) atomicAdd(a.hit_total, (unsigned long long)wave_hits);
@@ -746,11 +784,13 @@ static void launch_query_t(const QueryArgs& a, int blocks, hipStream_t s)
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF>
 static void launch_pool_t(const QueryArgs& a, int blocks_fast, int blocks_heavy, hipStream_t s)
 {
-	// fast kernel over all occupied cells, then the general kernel over the worklist of non-simple cells
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_pool_fast<ARITH, VARIABLE, SYM, SELF>), dim3(blocks_fast), dim3(Q_THREADS), 0, s, a);
+	// three tiers: fast kernel (<= 512 candidates per cell) over all occupied cells -> fat kernel (<= 1024) over its rejects ->
+	// general kernel over what is left (more candidates, > 64 query points per cell, ...)
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_pool_fast<ARITH, VARIABLE, SYM, SELF, false>), dim3(blocks_fast), dim3(Q_THREADS), 0, s, a);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_pool_fast<ARITH, VARIABLE, SYM, SELF, true>), dim3(blocks_fast), dim3(Q_THREADS), 0, s, a);
 	QueryArgs h = a;
-	h.occ_i = a.heavy;
-	h.n_occ_i = a.n_heavy;
+	h.occ_i = a.heavy2;
+	h.n_occ_i = a.n_heavy2;
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<ARITH, VARIABLE, SYM, SELF, MODE_POOL>), dim3(blocks_heavy), dim3(Q_THREADS), 0, s, h);
 }
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF>
