@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--arith", choices=["strict", "contracted"], default="strict")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact-layout", action="store_true", help="two-pass count/scan/fill result layout instead of the single pass")
     ap.add_argument("--sorted-input", action="store_true", help="z-sort the cloud first (reported separately in DESIGN.md)")
     args = ap.parse_args()
 
@@ -108,7 +109,7 @@ def main():
     arith = T.ARITH_STRICT if args.arith == "strict" else T.ARITH_CONTRACTED
 
     def make_engine():
-        return T.TreeNSearch(arith=arith, stream=stream.cuda_stream, collect_stage_times=True)
+        return T.TreeNSearch(arith=arith, stream=stream.cuda_stream, collect_stage_times=True, exact_layout=args.exact_layout)
 
     if distributed:
         from treensearch_amd.multi import SlabSearch
@@ -165,11 +166,14 @@ def main():
     total_points = n * world
     value = total_points / (elapsed / steps) / 1e6
 
-    # ---- roofline of the dominant kernel (k_query fill pass), this rank.  Algorithmic bytes per launch:
-    #      16 B per candidate point read once (sorted float4) + 8 B per query (record offset) in,
-    #      4 B per emitted index + 4 B count word per query + 8 B per query (offset by original index) out.
+    # ---- roofline of the dominant kernel, this rank: the single-pass query (k_query_pool_fast; its two follow-up tiers
+    #      run on empty worklists for this workload and are inside the same event bracket).  Algorithmic bytes per launch
+    #      (DESIGN.md section 4): 16 B per candidate point read once (sorted float4) in, 4 B per emitted index + 4 B count
+    #      word per query + 8 B per query (record offset by original index) out.  The exact two-pass layout
+    #      (--exact-layout) additionally reads the 8 B scanned record offset per query in its fill pass.
     n_pts, Q, E = st["n_points"], st["n_queries"], st["n_neighbors"]
-    fill_bytes = 16 * n_pts + 8 * Q + 4 * (E + Q) + 8 * Q
+    pooled = st.get("n_pool_pairs", 0) > 0
+    fill_bytes = 16 * n_pts + 4 * (E + Q) + 8 * Q + (0 if pooled else 8 * Q)
     fill_ms = acc["ms_fill"] / steps
     achieved = fill_bytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0
     run_bytes = st["bytes_build"] + st["bytes_query"]
@@ -183,7 +187,7 @@ def main():
                                + ("" if world == 1 else f"; {world} slabs along x with one-radius ghost halos over RCCL"),
                    "points_per_gpu": n, "arith": args.arith, "input_order": "z-sorted" if args.sorted_input else "as generated (random)",
                    "neighbors_total_rank0": int(E), "grid": st["grid_dims"], "parallelism": f"slab{world}"},
-        "roofline": {"bound": "hbm", "kernel": "k_query<fill>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "k_query_pool_fast" if pooled else "k_query<fill>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "bytes_per_launch": int(fill_bytes), "avg_launch_ms": round(fill_ms, 4),
                      "whole_run": {"algorithmic_bytes": int(run_bytes), "bytes_per_point": round(run_bytes / max(n_pts, 1), 1),
