@@ -142,30 +142,30 @@ def test_c2_10m_pool_mode_matches_reference_digest(oracle):
 
 
 def test_exact_layout_is_bitwise_reproducible():
-    """exact_layout=1: stable radix build + count/scan/fill => identical bytes from run to run."""
+    """exact_layout=1: stable cell sort + count/scan/fill => identical bytes from run to run."""
     case = CS.by_name("two_set_asym_80000_20000")
     ns = P.make_engine(case, 0, exact_layout=True)
     ns.run()
     a = {pr: tuple(x.copy() for x in ns.neighbor_records(*pr)) for pr in case.active}
     ns.run()
-    assert ns.get_stats()["n_fast_builds"] == 0
     for pr in case.active:
         b = ns.neighbor_records(*pr)
         assert np.array_equal(a[pr][0], b[0]) and np.array_equal(a[pr][1], b[1])
 
 
-@pytest.mark.parametrize("name", ["dam_break_sym_100000", "lattice_mixed_double_10000", "edge_far_outlier", "edge_empty_and_tiny"])
-def test_counting_build_sets_are_exact(name, oracle, monkeypatch):
-    """Opt-in counting-sort build (TNSX_COUNTING_BUILD=1; point order inside a cell is the arrival order of the atomics,
-    empty cells hold (s,s) instead of (0,0) in the table) -- neighbour sets still bit-exact, in exact and pool mode."""
-    monkeypatch.setenv("TNSX_COUNTING_BUILD", "1")
+@pytest.mark.parametrize("max_cells", [1 << 9, 1 << 13, 1 << 17, 1 << 26])
+@pytest.mark.parametrize("name", ["dam_break_sym_100000", "uniform_fixed_100000", "random_var_sym_30000_10000"])
+def test_cell_sort_digit_plans(name, max_cells, oracle):
+    """The build sorts the points by cell key with digits of 8..11 bits in 1..3 passes, depending on the number of grid
+    cells.  max_dense_cells forces coarser grids => other key widths => other digit plans; the sets never change."""
     case = CS.by_name(name)
-    ns = P.make_engine(case, 0)
+    ns = P.make_engine(case, 0, max_dense_cells=max_cells)
     ns.run()
     res1 = {pr: ns.neighbor_csr(*pr) for pr in case.active}
     ns.run()
     st = ns.get_stats()
-    assert st["n_fast_builds"] == sum(1 for p in case.points if len(p) > 0)
+    assert st["n_grid_cells"] <= max_cells
+    assert st["radix_passes"] == (st["key_bits"] + 10) // 11
     res2 = {pr: ns.neighbor_csr(*pr) for pr in case.active}
-    P.assert_matches_golden(res1, load_golden(case.name), 0, oracle, "counting build (exact pass)")
-    P.assert_matches_golden(res2, load_golden(case.name), 0, oracle, "counting build (pool pass)")
+    P.assert_matches_golden(res1, load_golden(case.name), 0, oracle, f"{name} max_cells={max_cells} (exact pass)")
+    P.assert_matches_golden(res2, load_golden(case.name), 0, oracle, f"{name} max_cells={max_cells} (pool pass)")

@@ -17,7 +17,7 @@ from typing import Optional
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libtnsx.so")
+LIB_PATH = os.environ.get("TNSX_LIB") or os.path.join(_PKG, "lib", "libtnsx.so")   # TNSX_LIB: A/B builds of the same ABI
 
 ARITH_STRICT = 0
 ARITH_CONTRACTED = 1

@@ -1,117 +1,352 @@
-// gfx950 kernels: the FAST build of the search structure -- a counting sort by cell.
+// gfx950 kernels: the BUILD of the search structure -- binning of one point set by grid cell, then the cell table.
 //
-//   k_bin_count    key(p) and rank(p) = atomicAdd(count[key], 1)            12 B read + 8 B written per point
-//   scan           start = exclusive scan of count over the grid cells       (tnsx_kernels.hip)
-//   k_bin_scatter  xyzi[start[key] + rank] = (x, y, z, original index)       20 B read + 16 B written per point
-//   k_cells_from_counts  table[c] = (start[c], start[c+1]) and the KEY-ORDERED list of occupied cells
+// An LSD radix sort on the cell key that moves THE POINT ITSELF (x, y, z, original index [, r*r]) and nothing else: no key
+// array and no index array exist.  Every kernel recomputes the key of a point from its position (six fp32 ops and two
+// integer multiply-adds) -- cheaper than the traffic of a key array, and MUCH cheaper than its scattered 4-byte stores:
+// measured on MI355X (tools/ubench/cellsort_bench.hip, 10 M points, two passes) the scattered 4-byte key stores cost 0.17 ms
+// of a 0.45 ms sort, the scattered 16-byte point stores 0.05 ms.
 //
-// Compared with the radix-sort build (cell keys -> 3 LSD passes over (key, idx) pairs -> random gather -> cell table) this
-// moves every point twice instead of eight times.  The price: the order of the points INSIDE one cell (and therefore the
-// order of the indices inside a neighbour list) is the arrival order of the atomics and differs from run to run.  The
-// neighbour SETS do not depend on it.  `exact_layout = 1` selects the radix build, which is stable and reproducible.
+//   k_cs_hist<FIRST>     per-tile histogram of one digit               12 B (user xyz) or 16 B read per point
+//   k_cs_scan_bins       per digit value: exclusive scan over the tiles (one workgroup per digit value) + its total
+//   k_cs_scatter<FIRST>  ranked, stable scatter of the points          12|16 B read, 16 B written per point
+//   k_cell_table         table[key] = (first, one past last) sorted position, list of occupied cells
+//
+// Digits are up to 11 bits wide, so the 20-bit keys of a 10 M-point cloud need TWO passes: every point is moved twice.
+// Stable: wave w of a workgroup owns CS_ITEMS*64 consecutive elements and walks them in rounds of 64, so (wave, round, lane)
+// order is index order; the point order inside a cell is therefore the input order -- reproducible from run to run.
 #include "tnsx_kernels.h"
 #include "tnsx_device.h"
 
 namespace tnsx {
 
+#ifndef TNSX_CS_THREADS
+#define TNSX_CS_THREADS 256
+#endif
+static constexpr int CS_THREADS = TNSX_CS_THREADS;
+static constexpr int CS_WAVES = CS_THREADS / WAVE;
+static constexpr int CS_ITEMS = 16;
+static constexpr int CS_TILE = CS_THREADS * CS_ITEMS;
+
+static int cs_num_tiles(int n) { return (n + CS_TILE - 1) / CS_TILE; }
+// Workgroup b runs on XCD b % 8.  Tiles are handed out so that every XCD owns a CONTIGUOUS range of tiles: the output runs of
+// neighbouring tiles are adjacent in memory (same digit, next tile), so the cache lines they share are completed inside one
+// XCD's L2 instead of leaving two XCDs as partial-line writes (measured: -20 % on the scatter).
+static int cs_grid(int ntiles) { return ((ntiles + 7) / 8) * 8; }
+__device__ __forceinline__ int cs_tile_of_block(int ntiles) { return (int)(blockIdx.x & 7u) * ((ntiles + 7) / 8) + (int)(blockIdx.x >> 3); }
+
+CellSortPlan cell_sort_plan(int key_bits)
+{
+	CellSortPlan p{};
+	if (key_bits < 1) key_bits = 1;
+	p.passes = (key_bits + CS_MAX_BITS - 1) / CS_MAX_BITS;
+	int left = key_bits;
+	for (int i = 0; i < p.passes; i++) {
+		const int b = (left + (p.passes - i) - 1) / (p.passes - i);   // spread the bits evenly
+		p.bits[i] = b < 8 ? 8 : b;
+		left -= b;
+	}
+	return p;
+}
+size_t cell_sort_temp_bytes(int n)
+{
+	const size_t hist_elems = ((size_t)1 << CS_MAX_BITS) * (size_t)cs_num_tiles(n > 0 ? n : 1);
+	return ((hist_elems * sizeof(uint32_t) + 255) / 256) * 256 + ((size_t)1 << CS_MAX_BITS) * sizeof(uint32_t) + 256;
+}
+
+struct F3 { float x, y, z; };   // 12-byte AoS point of the user array (4-byte aligned)
+
 __device__ __forceinline__ int bin_coord(float p, float o, float inv_h, int n)
 {
-	// identical to cell_coord() of tnsx_kernels.hip: fp32 sub, mul, truncate, clamp
+	// fp32 sub, mul, truncate, clamp -- the quantisation form of TreeNSearch.cpp:713-715
 	const float f = __fmul_rn(__fsub_rn(p, o), inv_h);
 	int c = (int)f;
 	c = c < 0 ? 0 : c;
 	return c > n - 1 ? n - 1 : c;
 }
-
-__global__ void __launch_bounds__(256) k_bin_count(const float* __restrict__ xyz, int n, GridParams g, uint32_t* __restrict__ count,
-                                                  uint2* __restrict__ keyrank)
+// row-major cell key, x fastest: the three x-neighbours of a row are contiguous in sorted order
+__device__ __forceinline__ uint32_t cell_key(float x, float y, float z, const GridParams& g)
 {
-	const int i = blockIdx.x * 256 + threadIdx.x;
-	if (i >= n) return;
-	const int ix = bin_coord(xyz[3 * (size_t)i], g.ox, g.inv_h, g.nx);
-	const int iy = bin_coord(xyz[3 * (size_t)i + 1], g.oy, g.inv_h, g.ny);
-	const int iz = bin_coord(xyz[3 * (size_t)i + 2], g.oz, g.inv_h, g.nz);
-	const uint32_t key = (uint32_t)((iz * g.ny + iy) * g.nx + ix);
-	const uint32_t rank = atomicAdd(count + key, 1u);
-	keyrank[i] = make_uint2(key, rank);
-}
-void launch_bin_count(const float* xyz, int n, GridParams g, uint32_t* count, uint2* keyrank, hipStream_t s)
-{
-	if (n <= 0) return;
-	hipLaunchKernelGGL(k_bin_count, dim3((n + 255) / 256), dim3(256), 0, s, xyz, n, g, count, keyrank);
+	const int ix = bin_coord(x, g.ox, g.inv_h, g.nx);
+	const int iy = bin_coord(y, g.oy, g.inv_h, g.ny);
+	const int iz = bin_coord(z, g.oz, g.inv_h, g.nz);
+	return (uint32_t)((iz * g.ny + iy) * g.nx + ix);
 }
 
-__global__ void __launch_bounds__(256) k_bin_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, const uint2* __restrict__ keyrank,
-                                                    const uint32_t* __restrict__ start, int n, float4* __restrict__ xyzi, float* __restrict__ r2)
+// ---- per-tile histogram of one digit -----------------------------------------------------------------------------
+template <int BITS, bool FIRST>
+__global__ void __launch_bounds__(CS_THREADS) k_cs_hist(const float* __restrict__ xyz, const float4* __restrict__ xyzi, int n, GridParams g, int shift,
+                                                        uint32_t* __restrict__ hist, int ntiles)
 {
-	const int i = blockIdx.x * 256 + threadIdx.x;
-	if (i >= n) return;
-	const uint2 kr = keyrank[i];
-	const uint32_t pos = start[kr.x] + kr.y;
-	float4 v;
-	v.x = xyz[3 * (size_t)i]; v.y = xyz[3 * (size_t)i + 1]; v.z = xyz[3 * (size_t)i + 2];
-	v.w = __uint_as_float((uint32_t)i);
-	xyzi[pos] = v;
-	if (radii) { const float r = radii[i]; r2[pos] = __fmul_rn(r, r); }   // radii_sq = r*r in fp32, TreeNSearch.cpp:2352
-}
-void launch_bin_scatter(const float* xyz, const float* radii, const uint2* keyrank, const uint32_t* start, int n, float4* xyzi, float* r2, hipStream_t s)
-{
-	if (n <= 0) return;
-	hipLaunchKernelGGL(k_bin_scatter, dim3((n + 255) / 256), dim3(256), 0, s, xyz, radii, keyrank, start, n, xyzi, r2);
+	constexpr int RADIX = 1 << BITS;
+	__shared__ uint32_t h[RADIX];
+	for (int b = threadIdx.x; b < RADIX; b += CS_THREADS) h[b] = 0;
+	__syncthreads();
+	const size_t base = (size_t)blockIdx.x * CS_TILE;
+	#pragma unroll 8
+	for (int i = 0; i < CS_ITEMS; i++) {
+		const size_t e = base + (size_t)i * CS_THREADS + threadIdx.x;
+		if (e < (size_t)n) {
+			uint32_t key;
+			if (FIRST) { const F3 q = reinterpret_cast<const F3*>(xyz)[e]; key = cell_key(q.x, q.y, q.z, g); }
+			else { const float4 q = xyzi[e]; key = cell_key(q.x, q.y, q.z, g); }
+			atomicAdd(&h[(key >> shift) & (RADIX - 1)], 1u);
+		}
+	}
+	__syncthreads();
+	for (int b = threadIdx.x; b < RADIX; b += CS_THREADS) hist[(size_t)b * ntiles + blockIdx.x] = h[b];
 }
 
-// table + occupied-cell list from the scanned counts.  One block per 4096 cells; blocks append their occupied cells in
-// key order, the order between blocks follows the (nearly monotone) order of their atomics.
-static constexpr int CC_THREADS = 256;
-static constexpr int CC_ITEMS = 16;
-static constexpr int CC_TILE = CC_THREADS * CC_ITEMS;
-
-__global__ void __launch_bounds__(CC_THREADS) k_cells_from_counts(const uint32_t* __restrict__ start, uint32_t n_cells, uint2* __restrict__ table,
-                                                                 uint2* __restrict__ occ, uint32_t* __restrict__ n_occ)
+// ---- one workgroup per digit value: exclusive scan of its tile counts in place, total -> totals[value] ------------
+static constexpr int SB_THREADS = 256;
+__global__ void __launch_bounds__(SB_THREADS) k_cs_scan_bins(uint32_t* __restrict__ hist, int ntiles, uint32_t* __restrict__ totals)
 {
-	__shared__ uint32_t wcnt[CC_ITEMS * (CC_THREADS / WAVE)];
+	__shared__ uint32_t wsum[SB_THREADS / WAVE];
+	uint32_t* row = hist + (size_t)blockIdx.x * ntiles;
+	uint32_t carry = 0;
+	for (int base = 0; base < ntiles; base += SB_THREADS * 4) {
+		const int e = base + (int)threadIdx.x * 4;
+		uint32_t v[4];
+		#pragma unroll
+		for (int k = 0; k < 4; k++) v[k] = (e + k < ntiles) ? row[e + k] : 0u;
+		const uint32_t t = v[0] + v[1] + v[2] + v[3];
+		uint32_t inc = t;
+		#pragma unroll
+		for (int o = 1; o < WAVE; o <<= 1) { const uint32_t u = __shfl_up(inc, o, WAVE); if (lane_id() >= o) inc += u; }
+		__syncthreads();   // wsum reuse
+		if (lane_id() == WAVE - 1) wsum[threadIdx.x / WAVE] = inc;
+		__syncthreads();
+		uint32_t woff = 0, chunk_total = 0;
+		#pragma unroll
+		for (int w = 0; w < SB_THREADS / WAVE; w++) { if (w < (int)(threadIdx.x / WAVE)) woff += wsum[w]; chunk_total += wsum[w]; }
+		uint32_t ex = carry + woff + inc - t;
+		#pragma unroll
+		for (int k = 0; k < 4; k++) { if (e + k < ntiles) row[e + k] = ex; ex += v[k]; }
+		carry += chunk_total;
+	}
+	if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+// ---- ranked scatter of the points --------------------------------------------------------------------------------
+// FIRST: the point comes from the user's arrays (xyz AoS, radii) and gets its original index attached; r2 = r*r in fp32
+// (TreeNSearch.cpp:2352).  Otherwise it comes from the previous pass.
+template <int BITS, bool FIRST, bool VARIABLE>
+__global__ void __launch_bounds__(CS_THREADS) __attribute__((amdgpu_waves_per_eu(TNSX_CS_THREADS / 256, 4)))
+k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, const float4* __restrict__ xyzi_in, const float* __restrict__ r2_in,
+             float4* __restrict__ xyzi_out, float* __restrict__ r2_out, int n, GridParams g, int shift, const uint32_t* __restrict__ hist_scanned,
+             const uint32_t* __restrict__ totals, int ntiles)
+{
+	constexpr int RADIX = 1 << BITS;
+	constexpr int PER = RADIX / CS_THREADS;   // digit values per thread in the prefix steps
+	static_assert(RADIX % CS_THREADS == 0 && PER >= 1, "digit values must divide among the threads");
+	__shared__ uint32_t wcount[CS_WAVES][RADIX];
+	__shared__ uint32_t gbase[RADIX];
+	__shared__ uint32_t wsum[CS_WAVES];
+	const int w = threadIdx.x / WAVE, lane = lane_id();
+	const int tile = cs_tile_of_block(ntiles);
+	if (tile >= ntiles) return;
+
+	float px[CS_ITEMS], py[CS_ITEMS], pz[CS_ITEMS], pw[CS_ITEMS];   // (scalar arrays: a float4 array ends up in scratch)
+	float rr[CS_ITEMS];
+	const size_t wbase = (size_t)tile * CS_TILE + (size_t)w * (CS_ITEMS * WAVE);
+	const size_t last = (size_t)n - 1;
+	// all loads of the tile up front, branch-free (clamped index), so that they are in flight during the set-up below
+	#pragma unroll
+	for (int i = 0; i < CS_ITEMS; i++) {
+		const size_t e = wbase + (size_t)i * WAVE + lane;
+		const size_t ec = e < last ? e : last;
+		if (FIRST) {
+			const F3 q = reinterpret_cast<const F3*>(xyz)[ec];
+			px[i] = q.x; py[i] = q.y; pz[i] = q.z; pw[i] = __uint_as_float((uint32_t)ec);
+			if (VARIABLE) { const float r = radii[ec]; rr[i] = __fmul_rn(r, r); }
+		}
+		else {
+			const float4 q = xyzi_in[ec];
+			px[i] = q.x; py[i] = q.y; pz[i] = q.z; pw[i] = q.w;
+			if (VARIABLE) rr[i] = r2_in[ec];
+		}
+	}
+
+	// global base of every digit value for this tile = (exclusive scan of the totals) + (scanned tile count).  Thread t owns the
+	// PER consecutive values [t*PER, t*PER + PER).
+	{
+		uint32_t tot[PER], sum = 0;
+		#pragma unroll
+		for (int k = 0; k < PER; k++) { tot[k] = totals[threadIdx.x * PER + k]; sum += tot[k]; }
+		uint32_t inc = sum;
+		#pragma unroll
+		for (int o = 1; o < WAVE; o <<= 1) { const uint32_t u = __shfl_up(inc, o, WAVE); if (lane >= o) inc += u; }
+		if (lane == WAVE - 1) wsum[w] = inc;
+		#pragma unroll
+		for (int k = 0; k < PER; k++) {
+			#pragma unroll
+			for (int ww = 0; ww < CS_WAVES; ww++) wcount[ww][threadIdx.x * PER + k] = 0;
+		}
+		__syncthreads();
+		uint32_t ex = inc - sum;
+		#pragma unroll
+		for (int ww = 0; ww < CS_WAVES; ww++) if (ww < w) ex += wsum[ww];
+		#pragma unroll
+		for (int k = 0; k < PER; k++) {
+			const int b = threadIdx.x * PER + k;
+			gbase[b] = ex + hist_scanned[(size_t)b * ntiles + tile];
+			ex += tot[k];
+		}
+	}
+
+	uint32_t dig[CS_ITEMS];
+	uint32_t rank[CS_ITEMS];
+	#pragma unroll
+	for (int i = 0; i < CS_ITEMS; i++) {
+		const size_t e = wbase + (size_t)i * WAVE + lane;
+		const bool valid = e < (size_t)n;
+		const uint32_t d = (cell_key(px[i], py[i], pz[i], g) >> shift) & (RADIX - 1);
+		dig[i] = d;
+		uint64_t peers = __ballot(valid);
+		#pragma unroll
+		for (int b = 0; b < BITS; b++) {
+			const bool bit = (d >> b) & 1u;
+			const uint64_t m = __ballot(valid && bit);
+			peers &= bit ? m : ~m;
+		}
+		const uint32_t r = mbcnt64(peers);                 // peers in lower lanes
+		const uint32_t cnt = (uint32_t)__popcll(peers);
+		uint32_t prev = 0;
+		if (valid) prev = wcount[w][d];
+		wave_lds_fence();
+		if (valid && r == 0) wcount[w][d] = prev + cnt;
+		wave_lds_fence();
+		rank[i] = prev + r;
+	}
+	__syncthreads();
+	#pragma unroll
+	for (int k = 0; k < PER; k++) {
+		const int b = threadIdx.x * PER + k;
+		uint32_t s = gbase[b];
+		#pragma unroll
+		for (int ww = 0; ww < CS_WAVES; ww++) { const uint32_t t = wcount[ww][b]; wcount[ww][b] = s; s += t; }
+	}
+	__syncthreads();
+	#pragma unroll
+	for (int i = 0; i < CS_ITEMS; i++) {
+		const size_t e = wbase + (size_t)i * WAVE + lane;
+		if (e < (size_t)n) {
+			const uint32_t pos = wcount[w][dig[i]] + rank[i];
+			xyzi_out[pos] = make_float4(px[i], py[i], pz[i], pw[i]);
+			if (VARIABLE) r2_out[pos] = rr[i];
+		}
+	}
+}
+
+template <int BITS>
+static void cs_hist(bool first, const float* xyz, const float4* xyzi, int n, const GridParams& g, int shift, uint32_t* hist, int ntiles, hipStream_t s)
+{
+	if (first) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_hist<BITS, true>), dim3(ntiles), dim3(CS_THREADS), 0, s, xyz, xyzi, n, g, shift, hist, ntiles);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_hist<BITS, false>), dim3(ntiles), dim3(CS_THREADS), 0, s, xyz, xyzi, n, g, shift, hist, ntiles);
+}
+template <int BITS>
+static void cs_scatter(bool first, bool variable, const float* xyz, const float* radii, const float4* xyzi_in, const float* r2_in, float4* xyzi_out,
+                       float* r2_out, int n, const GridParams& g, int shift, const uint32_t* hs, const uint32_t* totals, int ntiles, hipStream_t s)
+{
+#define TNSX_CS_GO(F, V)                                                                                                                       \
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_scatter<BITS, F, V>), dim3(cs_grid(ntiles)), dim3(CS_THREADS), 0, s, xyz, radii, xyzi_in, r2_in, xyzi_out, \
+	                   r2_out, n, g, shift, hs, totals, ntiles)
+	if (first) { if (variable) TNSX_CS_GO(true, true); else TNSX_CS_GO(true, false); }
+	else       { if (variable) TNSX_CS_GO(false, true); else TNSX_CS_GO(false, false); }
+#undef TNSX_CS_GO
+}
+
+#define TNSX_CS_DISPATCH(bits, call)                  \
+	switch (bits) {                                   \
+	case 8:  { constexpr int B = 8;  call; } break;   \
+	case 9:  { constexpr int B = 9;  call; } break;   \
+	case 10: { constexpr int B = 10; call; } break;   \
+	default: { constexpr int B = 11; call; } break;   \
+	}
+
+int launch_cell_sort(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, hipStream_t s)
+{
+	const CellSortPlan plan = cell_sort_plan(key_bits);
+	if (n <= 0) return plan.passes & 1;
+	const int ntiles = cs_num_tiles(n);
+	const size_t hist_cap = ((size_t)1 << CS_MAX_BITS) * (size_t)ntiles;
+	uint32_t* hist = (uint32_t*)temp;
+	uint32_t* totals = (uint32_t*)((char*)temp + ((hist_cap * sizeof(uint32_t) + 255) / 256) * 256);
+	const bool variable = radii != nullptr;
+	int cur = 0, shift = 0;
+	for (int p = 0; p < plan.passes; p++) {
+		const int bits = plan.bits[p];
+		TNSX_CS_DISPATCH(bits, cs_hist<B>(p == 0, xyz, b.xyzi[cur], n, g, shift, hist, ntiles, s));
+		hipLaunchKernelGGL(k_cs_scan_bins, dim3(1u << bits), dim3(SB_THREADS), 0, s, hist, ntiles, totals);
+		TNSX_CS_DISPATCH(bits, cs_scatter<B>(p == 0, variable, xyz, radii, b.xyzi[cur], b.r2[cur], b.xyzi[cur ^ 1], b.r2[cur ^ 1], n, g, shift, hist,
+		                                     totals, ntiles, s));
+		cur ^= 1;
+		shift += bits;
+	}
+	return cur;
+}
+
+// =====================================================================================================
+// cell table + list of occupied cells from the sorted points.  One block per tile of 4096 sorted points, ONE atomic per block.
+// =====================================================================================================
+static constexpr int CT_THREADS = 256;
+static constexpr int CT_ITEMS = 16;
+static constexpr int CT_TILE = CT_THREADS * CT_ITEMS;
+
+__global__ void __launch_bounds__(CT_THREADS) k_cell_table(const float4* __restrict__ xyzi, int n, GridParams g, uint2* __restrict__ table,
+                                                          uint2* __restrict__ occ, uint32_t* __restrict__ n_occ)
+{
+	__shared__ uint32_t sk[CT_TILE + 2];                        // keys of the tile, one halo entry on either side
+	__shared__ uint32_t wcnt[CT_ITEMS * (CT_THREADS / WAVE)];   // [round][wave] -> exclusive prefix
 	__shared__ uint32_t block_base;
 	const int w = threadIdx.x / WAVE;
-	const uint32_t base = blockIdx.x * CC_TILE;
-	uint32_t first[CC_ITEMS];
+	const size_t base = (size_t)blockIdx.x * CT_TILE;
+	#pragma unroll
+	for (int i = 0; i < CT_ITEMS; i++) {
+		const size_t p = base + (size_t)i * CT_THREADS + threadIdx.x;
+		if (p < (size_t)n) { const float4 q = xyzi[p]; sk[1 + i * CT_THREADS + threadIdx.x] = cell_key(q.x, q.y, q.z, g); }
+	}
+	if (threadIdx.x == 0 && base > 0) { const float4 q = xyzi[base - 1]; sk[0] = cell_key(q.x, q.y, q.z, g); }
+	if (threadIdx.x == 64 && base + CT_TILE < (size_t)n) { const float4 q = xyzi[base + CT_TILE]; sk[CT_TILE + 1] = cell_key(q.x, q.y, q.z, g); }
+	__syncthreads();
 	uint32_t flags = 0;
 	#pragma unroll
-	for (int i = 0; i < CC_ITEMS; i++) {
-		const uint32_t c = base + (uint32_t)i * CC_THREADS + threadIdx.x;
-		bool occupied = false;
-		first[i] = 0;
-		if (c < n_cells) {
-			const uint32_t s0 = start[c], s1 = start[c + 1];
-			table[c] = make_uint2(s0, s1);
-			first[i] = s0;
-			occupied = s1 > s0;
+	for (int i = 0; i < CT_ITEMS; i++) {
+		const int t = i * CT_THREADS + (int)threadIdx.x;
+		const size_t p = base + (size_t)t;
+		bool is_start = false;
+		if (p < (size_t)n) {
+			const uint32_t k = sk[1 + t];
+			is_start = (p == 0) || (sk[t] != k);
+			const bool is_end = (p == (size_t)n - 1) || (sk[2 + t] != k);
+			if (is_start) table[k].x = (uint32_t)p;
+			if (is_end) table[k].y = (uint32_t)p + 1u;
 		}
-		flags |= (occupied ? 1u : 0u) << i;
-		const uint64_t m = __builtin_amdgcn_ballot_w64(occupied);
-		if (lane_id() == 0) wcnt[i * (CC_THREADS / WAVE) + w] = (uint32_t)__popcll(m);
+		flags |= (is_start ? 1u : 0u) << i;
+		const uint64_t m = __builtin_amdgcn_ballot_w64(is_start);
+		if (lane_id() == 0) wcnt[i * (CT_THREADS / WAVE) + w] = (uint32_t)__popcll(m);
 	}
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		uint32_t s = 0;
-		for (int q = 0; q < CC_ITEMS * (CC_THREADS / WAVE); q++) { const uint32_t t = wcnt[q]; wcnt[q] = s; s += t; }
+		for (int q = 0; q < CT_ITEMS * (CT_THREADS / WAVE); q++) { const uint32_t t = wcnt[q]; wcnt[q] = s; s += t; }
 		block_base = s ? atomicAdd(n_occ, s) : 0u;
 	}
 	__syncthreads();
 	const uint32_t bb = block_base;
 	#pragma unroll
-	for (int i = 0; i < CC_ITEMS; i++) {
-		const bool occupied = (flags >> i) & 1u;
-		const uint64_t m = __builtin_amdgcn_ballot_w64(occupied);
-		if (occupied) {
-			const uint32_t c = base + (uint32_t)i * CC_THREADS + threadIdx.x;
-			occ[bb + wcnt[i * (CC_THREADS / WAVE) + w] + mbcnt64(m)] = make_uint2(first[i], c);
+	for (int i = 0; i < CT_ITEMS; i++) {
+		const bool is_start = (flags >> i) & 1u;
+		const uint64_t m = __builtin_amdgcn_ballot_w64(is_start);
+		if (is_start) {
+			const int t = i * CT_THREADS + (int)threadIdx.x;
+			occ[bb + wcnt[i * (CT_THREADS / WAVE) + w] + mbcnt64(m)] = make_uint2((uint32_t)(base + (size_t)t), sk[1 + t]);
 		}
 	}
 }
-void launch_cells_from_counts(const uint32_t* start, uint32_t n_cells, uint2* table, uint2* occ, uint32_t* n_occ, hipStream_t s)
+void launch_cell_table(const float4* xyzi_sorted, int n, GridParams g, uint2* table, uint2* occ, uint32_t* n_occ, hipStream_t s)
 {
-	if (n_cells == 0) return;
-	hipLaunchKernelGGL(k_cells_from_counts, dim3((n_cells + CC_TILE - 1) / CC_TILE), dim3(CC_THREADS), 0, s, start, n_cells, table, occ, n_occ);
+	if (n <= 0) return;
+	hipLaunchKernelGGL(k_cell_table, dim3((n + CT_TILE - 1) / CT_TILE), dim3(CT_THREADS), 0, s, xyzi_sorted, n, g, table, occ, n_occ);
 }
 
 }  // namespace tnsx

@@ -79,8 +79,9 @@ struct PointSet {
 	const float* d_xyz = nullptr;    // what the kernels read this run
 	const float* d_radii = nullptr;
 	// search structures
-	DevBuf keys[2], idx[2];
-	DevBuf xyzi, r2, table, occ;
+	DevBuf xyzi[2], r2[2];             // ping-pong of the cell sort; [sorted_buf] holds the sorted points of this run
+	DevBuf idx[2];                     // zsort scratch
+	DevBuf table, occ;
 	int sorted_buf = 0;
 	// zsort
 	std::vector<int> zsort_host;
@@ -125,9 +126,6 @@ struct tnsx_context {
 	int world_cells_pow2 = 0;
 	bool ran = false;
 	bool debug_nostore = std::getenv("TNSX_DEBUG_NOSTORE") != nullptr;   // timing experiments only: pool pass without its stores
-	// experimental counting-sort build (tnsx_build.hip).  Measured on MI355X at 10 M random points it is NOT faster than the
-	// radix build (0.75 vs 0.70 ms: 10 M returning L2 atomics cost 0.43 ms) and it gives up reproducible order, so it is opt-in.
-	bool counting_build = std::getenv("TNSX_COUNTING_BUILD") != nullptr;
 
 	// scratch
 	DevBuf bounds_partials, bounds_out, sort_temp, scan_temp, n_occ, permute_tmp, pool_ctrl;
@@ -556,7 +554,7 @@ tnsx_status tnsx_run(tnsx_context* c)
 	S.n_grid_cells = n_cells;
 	const int key_bits = std::max(1, ceil_log2_u64(n_cells));
 	S.key_bits = key_bits;
-	S.radix_passes = (key_bits + 7) / 8;
+	S.radix_passes = tnsx::cell_sort_plan(key_bits).passes;
 
 	// ---- per set: keys -> sort -> gather -> cell table
 	HIPCHK(c, c->n_occ.reserve(sizeof(uint32_t) * (size_t)std::max(n_sets, 1)));
@@ -566,53 +564,22 @@ tnsx_status tnsx_run(tnsx_context* c)
 		// the table is needed even for empty sets (they can be searched into)
 		HIPCHK(c, s.table.reserve(n_cells * sizeof(uint2)));
 		HIPCHK(c, s.occ.reserve((size_t)std::max(s.n, 1) * sizeof(uint2)));
-		HIPCHK(c, s.keys[0].reserve((size_t)std::max(s.n, 1) * sizeof(uint32_t)));
 		const int t0 = tm.mark();
-		// optional counting-sort build (never when a reproducible point order is requested or the grid is so coarse that
-		// thousands of points would fight for one counter)
-		const bool fast_build = c->counting_build && !c->opt.exact_layout && s.n > 0 && (uint64_t)s.n <= n_cells * 2048;
-		if (fast_build) {
-			HIPCHK(c, s.xyzi.reserve((size_t)s.n * sizeof(float4)));
-			if (variable) HIPCHK(c, s.r2.reserve((size_t)s.n * sizeof(float)));
-			HIPCHK(c, s.keys[1].reserve((n_cells + 1) * sizeof(uint32_t)));      // per-cell counts
-			HIPCHK(c, s.idx[1].reserve((n_cells + 1) * sizeof(uint32_t)));       // their exclusive scan
-			HIPCHK(c, s.idx[0].reserve((size_t)s.n * sizeof(uint2)));            // (key, rank) per point
-			HIPCHK(c, c->scan_temp.reserve(tnsx::scan_temp_bytes(n_cells + 1)));
-			uint32_t* cnt = s.keys[1].as<uint32_t>();
-			uint32_t* start = s.idx[1].as<uint32_t>();
-			uint2* keyrank = s.idx[0].as<uint2>();
-			HIPCHK(c, hipMemsetAsync(cnt, 0, (n_cells + 1) * sizeof(uint32_t), st));
-			tnsx::launch_bin_count(s.d_xyz, s.n, g, cnt, keyrank, st);
-			const int t1 = tm.mark();
-			tnsx::exclusive_scan_u32(cnt, start, n_cells + 1, c->scan_temp.p, st);
-			const int t2 = tm.mark();
-			tnsx::launch_bin_scatter(s.d_xyz, variable ? s.d_radii : nullptr, keyrank, start, s.n, s.xyzi.as<float4>(),
-			                         variable ? s.r2.as<float>() : nullptr, st);
-			const int t3 = tm.mark();
-			tnsx::launch_cells_from_counts(start, (uint32_t)n_cells, s.table.as<uint2>(), s.occ.as<uint2>(), c->n_occ.as<uint32_t>() + si, st);
-			const int t4 = tm.mark();
-			span(ST_KEYS, t0, t1); span(ST_SORT, t1, t2); span(ST_GATHER, t2, t3); span(ST_CELLS, t3, t4);
-			S.n_fast_builds++;
-			continue;
-		}
 		HIPCHK(c, hipMemsetAsync(s.table.p, 0, n_cells * sizeof(uint2), st));
 		if (s.n == 0) continue;
-		for (int k = 0; k < 2; k++) { HIPCHK(c, s.keys[k].reserve((size_t)s.n * sizeof(uint32_t))); HIPCHK(c, s.idx[k].reserve((size_t)s.n * sizeof(uint32_t))); }
-		HIPCHK(c, s.xyzi.reserve((size_t)s.n * sizeof(float4)));
-		if (variable) HIPCHK(c, s.r2.reserve((size_t)s.n * sizeof(float)));
-		HIPCHK(c, c->sort_temp.reserve(tnsx::radix_temp_bytes(s.n)));
-		tnsx::launch_cell_keys(s.d_xyz, s.n, g, s.keys[0].as<uint32_t>(), s.idx[0].as<uint32_t>(), st);
+		for (int k = 0; k < 2; k++) {
+			HIPCHK(c, s.xyzi[k].reserve((size_t)s.n * sizeof(float4)));
+			if (variable) HIPCHK(c, s.r2[k].reserve((size_t)s.n * sizeof(float)));
+		}
+		HIPCHK(c, c->sort_temp.reserve(tnsx::cell_sort_temp_bytes(s.n)));
+		tnsx::CellSortBuffers cb;
+		for (int k = 0; k < 2; k++) { cb.xyzi[k] = s.xyzi[k].as<float4>(); cb.r2[k] = s.r2[k].as<float>(); }
 		const int t1 = tm.mark();
-		uint32_t* kk[2] = { s.keys[0].as<uint32_t>(), s.keys[1].as<uint32_t>() };
-		uint32_t* vv[2] = { s.idx[0].as<uint32_t>(), s.idx[1].as<uint32_t>() };
-		s.sorted_buf = tnsx::radix_sort_pairs_u32(kk, vv, s.n, key_bits, c->sort_temp.p, st);
+		s.sorted_buf = tnsx::launch_cell_sort(s.d_xyz, variable ? s.d_radii : nullptr, s.n, g, key_bits, cb, c->sort_temp.p, st);
 		const int t2 = tm.mark();
-		tnsx::launch_gather_sorted(s.d_xyz, variable ? s.d_radii : nullptr, vv[s.sorted_buf], s.n, s.xyzi.as<float4>(),
-		                           variable ? s.r2.as<float>() : nullptr, st);
+		tnsx::launch_cell_table(cb.xyzi[s.sorted_buf], s.n, g, s.table.as<uint2>(), s.occ.as<uint2>(), c->n_occ.as<uint32_t>() + si, st);
 		const int t3 = tm.mark();
-		tnsx::launch_cell_table(kk[s.sorted_buf], s.n, s.table.as<uint2>(), s.occ.as<uint2>(), c->n_occ.as<uint32_t>() + si, st);
-		const int t4 = tm.mark();
-		span(ST_KEYS, t0, t1); span(ST_SORT, t1, t2); span(ST_GATHER, t2, t3); span(ST_CELLS, t3, t4);
+		span(ST_KEYS, t0, t1); span(ST_SORT, t1, t2); span(ST_CELLS, t2, t3);
 	}
 
 	// ---- per active pair: the query.
@@ -624,8 +591,8 @@ tnsx_status tnsx_run(tnsx_context* c)
 	HIPCHK(c, c->h_small.reserve(sizeof(uint64_t) * (2 * jobs.size() + 2) + sizeof(uint32_t) * (size_t)(n_sets + 1) + 64));
 	uint64_t* h_ctrl = c->h_small.as<uint64_t>();                       // per job: {cursor | total, hit_total}
 	uint32_t* h_nocc = reinterpret_cast<uint32_t*>(h_ctrl + 2 * jobs.size() + 2);
-	HIPCHK(c, c->pool_ctrl.reserve(sizeof(uint64_t) * 16 * (jobs.size() + 1)));   // per job: cursor, hit_total, 2 x (8 tickets, n_heavy)
-	unsigned long long* d_ctrl = c->pool_ctrl.as<unsigned long long>();
+	HIPCHK(c, c->pool_ctrl.reserve(tnsx::CTRL_BYTES * (jobs.size() + 1)));   // per job: cursor, hit_total, 2 x (8 tickets, n_heavy), spread out
+	auto ctrl_slot = [&](size_t k, int slot) { return c->pool_ctrl.as<uint32_t>() + (k * tnsx::CTRL_SLOTS + (size_t)slot) * tnsx::CTRL_STRIDE_U32; };
 	const int query_waves = c->n_cus * 8 * 4;
 
 	auto make_args = [&](const Job& jb, PairResult& pr, size_t k) {
@@ -634,20 +601,20 @@ tnsx_status tnsx_run(tnsx_context* c)
 		tnsx::QueryArgs a{};
 		a.occ_i = A.occ.as<uint2>(); a.n_occ_i = c->n_occ.as<uint32_t>() + jb.i;
 		a.table_i = A.table.as<uint2>();
-		a.xyzi_i = A.xyzi.as<float4>(); a.r2_i = A.r2.as<float>();
-		a.table_j = B.table.as<uint2>(); a.xyzi_j = B.xyzi.as<float4>(); a.r2_j = B.r2.as<float>();
+		a.xyzi_i = A.xyzi[A.sorted_buf].as<float4>(); a.r2_i = A.r2[A.sorted_buf].as<float>();
+		a.table_j = B.table.as<uint2>(); a.xyzi_j = B.xyzi[B.sorted_buf].as<float4>(); a.r2_j = B.r2[B.sorted_buf].as<float>();
 		a.r2_fixed = c->radius_sq;
 		a.g = g;
 		a.counts = pr.counts.as<uint32_t>();
 		a.offs_sorted = pr.offs_sorted.as<uint64_t>();
 		a.records = pr.records.as<int>();
 		a.offs_by_orig = pr.offs_orig.as<uint64_t>();
-		a.pool_cursor = d_ctrl + 16 * k;
-		a.hit_total = d_ctrl + 16 * k + 1;
-		a.tickets = reinterpret_cast<uint32_t*>(d_ctrl + 16 * k + 2);
-		a.n_heavy = reinterpret_cast<uint32_t*>(d_ctrl + 16 * k + 6);
-		a.tickets2 = reinterpret_cast<uint32_t*>(d_ctrl + 16 * k + 8);
-		a.n_heavy2 = reinterpret_cast<uint32_t*>(d_ctrl + 16 * k + 12);
+		a.pool_cursor = reinterpret_cast<unsigned long long*>(ctrl_slot(k, tnsx::CTRL_CURSOR));
+		a.hit_total = a.pool_cursor + 1;
+		a.tickets = ctrl_slot(k, tnsx::CTRL_TICKETS);
+		a.n_heavy = ctrl_slot(k, tnsx::CTRL_NHEAVY);
+		a.tickets2 = ctrl_slot(k, tnsx::CTRL_TICKETS2);
+		a.n_heavy2 = ctrl_slot(k, tnsx::CTRL_NHEAVY2);
 		a.heavy = pr.heavy.as<uint2>();
 		a.heavy2 = pr.heavy2.as<uint2>();
 		a.pool_capacity = c->debug_nostore ? 0 : pr.records.cap / sizeof(int);
@@ -662,7 +629,7 @@ tnsx_status tnsx_run(tnsx_context* c)
 	auto launch_pool = [&](size_t k) -> tnsx_status {
 		const Job& jb = jobs[k];
 		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
-		HIPCHK(c, hipMemsetAsync(d_ctrl + 16 * k, 0, 16 * sizeof(uint64_t), st));
+		HIPCHK(c, hipMemsetAsync(ctrl_slot(k, 0), 0, tnsx::CTRL_BYTES, st));
 		const int t0 = tm.mark();
 		if (pr.n_i > 0) {
 			qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_POOL;
@@ -670,7 +637,7 @@ tnsx_status tnsx_run(tnsx_context* c)
 		}
 		const int t1 = tm.mark();
 		span(ST_FILL, t0, t1);
-		HIPCHK(c, hipMemcpyAsync(h_ctrl + 2 * k, d_ctrl + 16 * k, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+		HIPCHK(c, hipMemcpyAsync(h_ctrl + 2 * k, ctrl_slot(k, tnsx::CTRL_CURSOR), 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
 		return TNSX_OK;
 	};
 

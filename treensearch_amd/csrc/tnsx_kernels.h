@@ -44,15 +44,19 @@ void exclusive_scan_u32_to_u64(const uint32_t* in, uint64_t* out, size_t n, void
 void launch_gather_sorted(const float* xyz, const float* radii, const uint32_t* idx_sorted, int n, float4* xyzi,
                           float* r2, hipStream_t s);
 
-// ---- cell table: table[key] = (first sorted position, one past last); occ = {first sorted position, key} of every
-//      occupied cell (order of blocks of 4096 points is arbitrary), *n_occ = their number (must be zeroed before) ----
-void launch_cell_table(const uint32_t* keys_sorted, int n, uint2* table, uint2* occ, uint32_t* n_occ, hipStream_t s);
-
-// ---- fast build: counting sort by cell (tnsx_build.hip); point order inside a cell = arrival order of the atomics ----
-void launch_bin_count(const float* xyz, int n, GridParams g, uint32_t* count /*zeroed, n_cells+1*/, uint2* keyrank, hipStream_t s);
-void launch_bin_scatter(const float* xyz, const float* radii, const uint2* keyrank, const uint32_t* start, int n, float4* xyzi, float* r2,
-                        hipStream_t s);
-void launch_cells_from_counts(const uint32_t* start /*n_cells+1*/, uint32_t n_cells, uint2* table, uint2* occ, uint32_t* n_occ, hipStream_t s);
+// ---- build of the search structure of one point set (tnsx_build.hip) ---------------------------------------
+// Cell sort: LSD radix sort on the cell key that moves the point itself, (x, y, z, bits(original index)) [+ r*r]; keys are
+// recomputed from the positions, digits have up to CS_MAX_BITS bits.  xyzi / r2 ping-pong between [0] and [1];
+// launch_cell_sort returns the index that holds the sorted points.
+static constexpr int CS_MAX_BITS = 11;
+struct CellSortPlan { int passes; int bits[8]; };
+CellSortPlan cell_sort_plan(int key_bits);
+struct CellSortBuffers { float4* xyzi[2]; float* r2[2]; };
+size_t cell_sort_temp_bytes(int n);
+int launch_cell_sort(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, hipStream_t s);
+// Cell table: table[key] = (first sorted position, one past last); occ = {first sorted position, key} of every occupied cell
+// (order of blocks of 4096 points is arbitrary), *n_occ = their number (must be zeroed before)
+void launch_cell_table(const float4* xyzi_sorted, int n, GridParams g, uint2* table, uint2* occ, uint32_t* n_occ, hipStream_t s);
 
 // ---- the query ----------------------------------------------------------------------------------
 struct QueryArgs {
@@ -74,11 +78,18 @@ struct QueryArgs {
 	uint64_t pool_capacity;            // ints available in `records`
 	uint32_t pool_slab;                // ints a wave takes from the cursor per atomic
 	unsigned long long* hit_total;     // += number of neighbour indices emitted
-	uint32_t* tickets;                 // [8] per-XCD ticket counters of the fast kernel (zeroed before the launch)
+	uint32_t* tickets;                 // per-XCD ticket counters of the fast kernel: tickets[x * CTRL_STRIDE_U32] (zeroed before the launch)
 	uint2* heavy;                      // worklist {first sorted position, key} of the cells the fast kernel skipped
 	uint32_t* n_heavy;                 // its length (zeroed before the launch)
 	uint32_t* tickets2; uint2* heavy2; uint32_t* n_heavy2;   // the same for the second tier (fat kernel -> general kernel)
 };
+// Control block of one pool pass.  Every hot counter sits CTRL_STRIDE_U32 words (4352 B) from the next: the L2 serialises
+// atomics that hit the same cache line (measured: ~88 atomics/us per line, whatever the word), and the stride also spreads
+// the counters over different L2 channels whether these interleave at 256 B or at 4 KiB.
+static constexpr size_t CTRL_STRIDE_U32 = 1088;
+enum { CTRL_CURSOR = 0 /* u64 cursor, u64 hit_total */, CTRL_TICKETS = 1 /* 8 slots */, CTRL_NHEAVY = 9, CTRL_TICKETS2 = 10 /* 8 slots */,
+       CTRL_NHEAVY2 = 18, CTRL_SLOTS = 19 };
+static constexpr size_t CTRL_BYTES = CTRL_SLOTS * CTRL_STRIDE_U32 * sizeof(uint32_t);
 enum { QUERY_COUNT = 0, QUERY_FILL = 1, QUERY_POOL = 2 };
 struct QueryConfig {
 	int arith;       // 0 strict, 1 contracted

@@ -1,4 +1,4 @@
-// gfx950 kernels: cell table and THE QUERY (count / fill passes of the 27-cell distance test).
+// gfx950 kernels: THE QUERY (27-cell distance test; single-pass pool mode and count / fill passes).
 //
 // Query design (one wave64 per occupied cell of the query set; no LDS, no MFMA):
 //   * the 27 neighbour cells of the candidate set are looked up by 27 lanes in one round trip and merged into 9
@@ -22,63 +22,6 @@
 #include <cstdlib>
 
 namespace tnsx {
-
-// =====================================================================================================
-// cell table + list of occupied cells.  One block per tile of 4096 sorted points, ONE atomic per block.
-// =====================================================================================================
-static constexpr int CT_THREADS = 256;
-static constexpr int CT_ITEMS = 16;
-static constexpr int CT_TILE = CT_THREADS * CT_ITEMS;
-
-__global__ void __launch_bounds__(CT_THREADS) k_cell_table(const uint32_t* __restrict__ keys, int n, uint2* __restrict__ table,
-                                                          uint2* __restrict__ occ, uint32_t* __restrict__ n_occ)
-{
-	__shared__ uint32_t wcnt[CT_ITEMS * (CT_THREADS / WAVE)];   // [round][wave] -> exclusive prefix
-	__shared__ uint32_t block_base;
-	const int w = threadIdx.x / WAVE;
-	const size_t base = (size_t)blockIdx.x * CT_TILE;
-	uint32_t key[CT_ITEMS];
-	uint32_t flags = 0;
-	#pragma unroll
-	for (int i = 0; i < CT_ITEMS; i++) {
-		const size_t p = base + (size_t)i * CT_THREADS + threadIdx.x;
-		bool is_start = false;
-		key[i] = 0;
-		if (p < (size_t)n) {
-			const uint32_t k = keys[p];
-			key[i] = k;
-			is_start = (p == 0) || (keys[p - 1] != k);
-			const bool is_end = (p == (size_t)n - 1) || (keys[p + 1] != k);
-			if (is_start) table[k].x = (uint32_t)p;
-			if (is_end) table[k].y = (uint32_t)p + 1u;
-		}
-		flags |= (is_start ? 1u : 0u) << i;
-		const uint64_t m = __builtin_amdgcn_ballot_w64(is_start);
-		if (lane_id() == 0) wcnt[i * (CT_THREADS / WAVE) + w] = (uint32_t)__popcll(m);
-	}
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		uint32_t s = 0;
-		for (int q = 0; q < CT_ITEMS * (CT_THREADS / WAVE); q++) { const uint32_t t = wcnt[q]; wcnt[q] = s; s += t; }
-		block_base = s ? atomicAdd(n_occ, s) : 0u;
-	}
-	__syncthreads();
-	const uint32_t bb = block_base;
-	#pragma unroll
-	for (int i = 0; i < CT_ITEMS; i++) {
-		const bool is_start = (flags >> i) & 1u;
-		const uint64_t m = __builtin_amdgcn_ballot_w64(is_start);
-		if (is_start) {
-			const size_t p = base + (size_t)i * CT_THREADS + threadIdx.x;
-			occ[bb + wcnt[i * (CT_THREADS / WAVE) + w] + mbcnt64(m)] = make_uint2((uint32_t)p, key[i]);
-		}
-	}
-}
-void launch_cell_table(const uint32_t* keys_sorted, int n, uint2* table, uint2* occ, uint32_t* n_occ, hipStream_t s)
-{
-	if (n <= 0) return;
-	hipLaunchKernelGGL(k_cell_table, dim3((n + CT_TILE - 1) / CT_TILE), dim3(CT_THREADS), 0, s, keys_sorted, n, table, occ, n_occ);
-}
 
 // =====================================================================================================
 // the query
@@ -709,15 +652,20 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 	const uint32_t n_occ = FAT ? *a.n_heavy : *a.n_occ_i;
 	const uint32_t xcd = blockIdx.x & 7u;
 	const uint32_t lo = (uint32_t)(((uint64_t)n_occ * xcd) >> 3), hi = (uint32_t)(((uint64_t)n_occ * (xcd + 1u)) >> 3);
+	// more waves than tickets (short worklists of the later tiers): the surplus leaves without touching the counter
+	if ((blockIdx.x >> 3) * Q_WAVES + threadIdx.x / WAVE >= (hi - lo + Q_TICKET - 1u) / Q_TICKET) return;
+	uint32_t* const my_tickets = tickets + xcd * CTRL_STRIDE_U32;
 	PoolState ps = { 0u, 0u, 0u, 0u };
 	uint32_t wave_hits = 0;
 
+	// the ticket is always fetched one round ahead, so that its round trip overlaps the previous ticket's cells
+	uint32_t next_ticket = 0;
+	if (lane == 0) next_ticket = atomicAdd(my_tickets, 1u);
 	for (;;) {
-		uint32_t ticket = 0;
-		if (lane == 0) ticket = atomicAdd(tickets + xcd, 1u);
-		ticket = readfirstlane_u32(ticket);
+		const uint32_t ticket = readfirstlane_u32(next_ticket);
 		const uint32_t first = lo + ticket * Q_TICKET;
 		if (first >= hi) break;
+		if (lane == 0) next_ticket = atomicAdd(my_tickets, 1u);
 		const uint32_t ncell = (hi - first) < Q_TICKET ? (hi - first) : Q_TICKET;
 		// the ticket's occupied-cell entries, one per lane
 		uint2 ocv = make_uint2(0u, 0u);
