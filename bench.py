@@ -91,7 +91,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # TNSX_BENCH_FORCE_SLAB=1: exercise the slab / process-group path with a single rank (a 1-GPU box can check it)
+    distributed = world > 1 or (os.environ.get("TNSX_BENCH_FORCE_SLAB") == "1" and "RANK" in os.environ)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU path)"
     torch.cuda.set_device(local_rank)
     if distributed:
@@ -113,9 +114,11 @@ def main():
 
     if distributed:
         from treensearch_amd.multi import SlabSearch
-        d_pts = torch.from_numpy(pts_h).cuda()
         gids = torch.arange(rank * n, (rank + 1) * n, dtype=torch.int64, device="cuda")
         slab = SlabSearch(float(rank), float(rank + 1), float(radius), make_engine)
+        # the owned points live in the slab's own buffer, the ghosts of every step are appended behind them
+        d_pts = slab.owned_buffer(n, "cuda", ghost_capacity=int(2.5 * n * float(radius)) + 4096)
+        d_pts.copy_(torch.from_numpy(pts_h))
         ns = slab.engine
 
         def step():

@@ -2,7 +2,7 @@
 
 The product has no CPU search path, so the per-rank search backend is injected: a stand-in with the TreeNSearch API
 whose run() calls the CPU oracle.  What is under test is the distributed logic: which points are exchanged, the
-64-bit global-id transport, the (owned -> owned) + (owned -> ghost) pair set-up and the translation back to global
+64-bit global-id transport, the [owned | ghosts] point set and the translation of its lists back to global
 ids -- the union of the ranks' results must equal the single-process result on the union of the slabs."""
 import os
 import socket
@@ -110,3 +110,23 @@ def test_halo_masks():
     assert right.tolist() == [False, False, False, True, True]
     left, right = slab_halo_masks(x, 0.0, 1.0, 0.05, False, True)
     assert not left.any() and right.sum() == 2
+
+
+def test_single_rank_has_no_ghosts():
+    """No process group / one rank: nothing to exchange, and the empty ghost arrays must still be well-formed."""
+    from treensearch_amd.multi import SlabExchange, SlabSearch
+    pts = torch.rand(100, 3)
+    gids = torch.arange(100, dtype=torch.int64)
+    for radii in (None, torch.full((100,), 0.1)):
+        gp, gg, gr = SlabExchange(0.0, 1.0, 0.1).exchange(pts, gids, radii)
+        assert gp.shape == (0, 3) and gg.shape == (0,) and gg.dtype == torch.int64
+        assert (gr is None) == (radii is None)
+    slab = SlabSearch(0.0, 1.0, 0.2, OracleEngine)
+    view = slab.owned_buffer(100, "cpu")
+    view.copy_(pts)
+    slab.step(view, gids)
+    slab.step(view, gids)
+    offs, nbr = slab.global_neighbors()
+    from oracle import oracle as O
+    ro, ri = O.Oracle().pair_search(pts.numpy(), pts.numpy(), radius=np.float32(0.2), same_set=True)
+    assert np.array_equal(offs, ro) and np.array_equal(nbr, ri.astype(np.int64))

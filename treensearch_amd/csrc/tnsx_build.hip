@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(SB_THREADS) k_cs_scan_bins(uint32_t* __restric
 // FIRST: the point comes from the user's arrays (xyz AoS, radii) and gets its original index attached; r2 = r*r in fp32
 // (TreeNSearch.cpp:2352).  Otherwise it comes from the previous pass.
 template <int BITS, bool FIRST, bool VARIABLE>
-__global__ void __launch_bounds__(CS_THREADS) __attribute__((amdgpu_waves_per_eu(TNSX_CS_THREADS / 256, 4)))
+__global__ void __launch_bounds__(CS_THREADS) __attribute__((amdgpu_waves_per_eu(BITS <= 10 ? 4 : 3, 4)))
 k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, const float4* __restrict__ xyzi_in, const float* __restrict__ r2_in,
              float4* __restrict__ xyzi_out, float* __restrict__ r2_out, int n, GridParams g, int shift, const uint32_t* __restrict__ hist_scanned,
              const uint32_t* __restrict__ totals, int ntiles)
@@ -141,28 +141,31 @@ k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, con
 	__shared__ uint32_t wcount[CS_WAVES][RADIX];
 	__shared__ uint32_t gbase[RADIX];
 	__shared__ uint32_t wsum[CS_WAVES];
-	const int w = threadIdx.x / WAVE, lane = lane_id();
+	const int w = (int)readfirstlane_u32(threadIdx.x / WAVE), lane = lane_id();
 	const int tile = cs_tile_of_block(ntiles);
 	if (tile >= ntiles) return;
 
 	float px[CS_ITEMS], py[CS_ITEMS], pz[CS_ITEMS], pw[CS_ITEMS];   // (scalar arrays: a float4 array ends up in scratch)
 	float rr[CS_ITEMS];
+	// this wave's CS_ITEMS*64 consecutive elements: wave-uniform 64-bit base + 32-bit lane offsets (scalar-base addressing)
 	const size_t wbase = (size_t)tile * CS_TILE + (size_t)w * (CS_ITEMS * WAVE);
-	const size_t last = (size_t)n - 1;
+	const uint32_t rem = wbase < (size_t)n ? (uint32_t)((size_t)n - wbase < (size_t)(CS_ITEMS * WAVE) ? (size_t)n - wbase : (size_t)(CS_ITEMS * WAVE)) : 0u;
+	const size_t lbase = rem ? wbase : 0;   // (waves past the end load element 0 and drop it)
+	const uint32_t lclamp = rem ? rem - 1u : 0u;
 	// all loads of the tile up front, branch-free (clamped index), so that they are in flight during the set-up below
 	#pragma unroll
 	for (int i = 0; i < CS_ITEMS; i++) {
-		const size_t e = wbase + (size_t)i * WAVE + lane;
-		const size_t ec = e < last ? e : last;
+		const uint32_t li = (uint32_t)(i * WAVE + lane);
+		const uint32_t lc = li < lclamp ? li : lclamp;
 		if (FIRST) {
-			const F3 q = reinterpret_cast<const F3*>(xyz)[ec];
-			px[i] = q.x; py[i] = q.y; pz[i] = q.z; pw[i] = __uint_as_float((uint32_t)ec);
-			if (VARIABLE) { const float r = radii[ec]; rr[i] = __fmul_rn(r, r); }
+			const F3 q = (reinterpret_cast<const F3*>(xyz) + lbase)[lc];
+			px[i] = q.x; py[i] = q.y; pz[i] = q.z; pw[i] = __uint_as_float((uint32_t)wbase + li);
+			if (VARIABLE) { const float r = (radii + lbase)[lc]; rr[i] = __fmul_rn(r, r); }
 		}
 		else {
-			const float4 q = xyzi_in[ec];
+			const float4 q = (xyzi_in + lbase)[lc];
 			px[i] = q.x; py[i] = q.y; pz[i] = q.z; pw[i] = q.w;
-			if (VARIABLE) rr[i] = r2_in[ec];
+			if (VARIABLE) rr[i] = (r2_in + lbase)[lc];
 		}
 	}
 
@@ -193,14 +196,11 @@ k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, con
 		}
 	}
 
-	uint32_t dig[CS_ITEMS];
-	uint32_t rank[CS_ITEMS];
+	uint32_t dig_rank[CS_ITEMS];   // digit | rank in the wave's sub-tile << 16 (both < 2^16)
 	#pragma unroll
 	for (int i = 0; i < CS_ITEMS; i++) {
-		const size_t e = wbase + (size_t)i * WAVE + lane;
-		const bool valid = e < (size_t)n;
+		const bool valid = (uint32_t)(i * WAVE + lane) < rem;
 		const uint32_t d = (cell_key(px[i], py[i], pz[i], g) >> shift) & (RADIX - 1);
-		dig[i] = d;
 		uint64_t peers = __ballot(valid);
 		#pragma unroll
 		for (int b = 0; b < BITS; b++) {
@@ -215,7 +215,7 @@ k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, con
 		wave_lds_fence();
 		if (valid && r == 0) wcount[w][d] = prev + cnt;
 		wave_lds_fence();
-		rank[i] = prev + r;
+		dig_rank[i] = d | ((prev + r) << 16);
 	}
 	__syncthreads();
 	#pragma unroll
@@ -228,9 +228,8 @@ k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, con
 	__syncthreads();
 	#pragma unroll
 	for (int i = 0; i < CS_ITEMS; i++) {
-		const size_t e = wbase + (size_t)i * WAVE + lane;
-		if (e < (size_t)n) {
-			const uint32_t pos = wcount[w][dig[i]] + rank[i];
+		if ((uint32_t)(i * WAVE + lane) < rem) {
+			const uint32_t pos = wcount[w][dig_rank[i] & 0xffffu] + (dig_rank[i] >> 16);
 			xyzi_out[pos] = make_float4(px[i], py[i], pz[i], pw[i]);
 			if (VARIABLE) r2_out[pos] = rr[i];
 		}

@@ -3,12 +3,12 @@
 One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI; "gloo" on CPU for the tests).  Rank k owns
 the points of slab k along x.  Per step there is exactly ONE exchange: every rank sends the points lying within one
 halo width (>= the search radius) of its left / right slab face to that neighbour (grouped isend/irecv of a count,
-then xyz(+r) payload and the global ids).  The received ghosts become a second point set, and the engine runs the
-pairs (owned -> owned) and (owned -> ghost) -- the multi-set machinery of the reference API is exactly what a halo
-needs, so the single-GPU engine is used unchanged and no collective touches the data path.
+then xyz(+r) payload and the global ids).  The received ghosts are appended to the owned points and the unchanged
+single-GPU engine runs one search over [owned | ghosts]; no collective touches the data path.
 
-Results: for every owned point two lists, indices local to `owned` resp. to `ghost`; `global_neighbors()` translates
-both to global ids, which makes the union identical to the single-device result on the union of all slabs.
+Results: for every owned point one list whose entries < n are owned points and entries >= n ghosts;
+`global_neighbors()` translates them to global ids, which makes the result identical to the single-device result on the
+union of all slabs.
 """
 from __future__ import annotations
 
@@ -41,7 +41,6 @@ class SlabExchange:
         -> (ghost_pts (m,3), ghost_gids (m,), ghost_radii (m,) or None)"""
         dev = pts.device
         has_l, has_r = self.rank > 0, self.rank < self.world - 1
-        ml, mr = slab_halo_masks(pts[:, 0], self.lo, self.hi, self.halo, has_l, has_r)
         cols = 4 if radii is None else 5
         # payload rows: x, y, z, [r], and the 64-bit global id bit-cast into two float32 columns
         def pack(mask):
@@ -55,9 +54,9 @@ class SlabExchange:
 
         send = {}
         if has_l:
-            send[self.rank - 1] = pack(ml)
+            send[self.rank - 1] = pack(pts[:, 0] < (self.lo + self.halo))
         if has_r:
-            send[self.rank + 1] = pack(mr)
+            send[self.rank + 1] = pack(pts[:, 0] >= (self.hi - self.halo))
         peers = sorted(send.keys())
         # 1) counts
         cnt_out = {p: torch.tensor([send[p].shape[0]], dtype=torch.int64, device=dev) for p in peers}
@@ -87,13 +86,19 @@ class SlabExchange:
             g = torch.empty((0, cols + 1), dtype=torch.float32, device=dev)
         ghost_pts = g[:, 0:3].contiguous()
         ghost_r = g[:, 3].contiguous() if radii is not None else None
-        ghost_gid = g[:, cols - 1:cols + 1].contiguous().view(torch.int64).view(-1)
+        # (clone, not contiguous(): an EMPTY slice counts as contiguous and keeps its odd storage offset, which int64 cannot view)
+        ghost_gid = g[:, cols - 1:cols + 1].clone(memory_format=torch.contiguous_format).view(torch.int64).view(-1)
         return ghost_pts, ghost_gid, ghost_r
 
 
 class SlabSearch:
     """Owned + ghost search of one slab.  `engine_factory()` must return an object with the TreeNSearch API
-    (treensearch_amd.TreeNSearch on a GPU; the CPU tests inject an oracle-backed stand-in)."""
+    (treensearch_amd.TreeNSearch on a GPU; the CPU tests inject an oracle-backed stand-in).
+
+    The ghosts are APPENDED to the owned points -- one point set [owned | ghosts], one active search set -> set -- so a
+    step costs one engine run over n + m points (m = a few per cent of n) instead of a second pair that would visit
+    every owned cell again only to find no ghost near it.  Lists of the ghost points themselves are computed and
+    ignored; list entries >= n refer to ghosts and are translated through `ghost_gids`."""
 
     def __init__(self, slab_lo: float, slab_hi: float, radius: float, engine_factory: Callable[[], object],
                  halo_margin: float = 1.0e-3, group=None):
@@ -101,45 +106,49 @@ class SlabSearch:
         self.ex = SlabExchange(slab_lo, slab_hi, self.radius * (1.0 + halo_margin), group)
         self.engine = engine_factory()
         self.engine.set_search_radius(radius)
-        self._owned_set = None
-        self._ghost_set = None
+        self._set = None
+        self._buf = None            # (capacity, 3) float32: owned points first, ghosts behind them
+        self.n_owned = 0
         self.ghost_gids = None
         self.owned_gids = None
-        self._ghost_buf = None
+
+    def owned_buffer(self, n: int, device, ghost_capacity: int = 0) -> torch.Tensor:
+        """(n,3) view of the internal point buffer.  A caller that keeps its positions in this view saves step() the copy
+        of the owned points (as long as the ghosts fit behind them; otherwise the buffer is re-allocated and step() copies)."""
+        cap = n + max(int(ghost_capacity), n // 16, 1024)
+        if self._buf is None or self._buf.shape[0] < cap or self._buf.device != torch.device(device):
+            self._buf = torch.empty((cap, 3), dtype=torch.float32, device=device)
+        return self._buf[:n]
 
     def step(self, pts: torch.Tensor, gids: torch.Tensor):
-        """One exchange + one run.  pts must stay alive (the engine keeps the pointer like the reference does)."""
+        """One exchange + one run.  pts (n,3) float32 owned points, gids (n,) int64 their global ids."""
         ghost_pts, ghost_gid, _ = self.ex.exchange(pts, gids)
-        self.owned_gids, self.ghost_gids = gids, ghost_gid
-        self._ghost_buf = ghost_pts
+        n, m = int(pts.shape[0]), int(ghost_pts.shape[0])
+        self.n_owned, self.owned_gids, self.ghost_gids = n, gids, ghost_gid
+        if self._buf is None or self._buf.shape[0] < n + m or self._buf.device != pts.device:
+            self._buf = torch.empty((n + m + max((n + m) // 16, 1024), 3), dtype=torch.float32, device=pts.device)
+        if pts.data_ptr() != self._buf.data_ptr():
+            self._buf[:n].copy_(pts)
+        if m:
+            self._buf[n:n + m].copy_(ghost_pts)
+        view = self._buf[:n + m]
         e = self.engine
-        if self._owned_set is None:
-            self._owned_set = e.add_point_set(pts)
-            self._ghost_set = e.add_point_set(ghost_pts)
-            e.set_active_search(self._owned_set, self._owned_set, True)
-            e.set_active_search(self._owned_set, self._ghost_set, True)
+        if self._set is None:
+            self._set = e.add_point_set(view)
+            e.set_active_search(self._set, self._set, True)
         else:
-            e.resize_point_set(self._owned_set, pts)
-            e.resize_point_set(self._ghost_set, ghost_pts)
+            e.resize_point_set(self._set, view)
         e.run()
 
     def global_neighbors(self):
         """(offsets int64[n+1], global ids int64[E]) of the owned points, every list ascending."""
-        e = self.engine
-        o0, i0 = e.neighbor_csr(self._owned_set, self._owned_set)
-        o1, i1 = e.neighbor_csr(self._owned_set, self._ghost_set)
-        og = self.owned_gids.cpu().numpy()
-        gg = self.ghost_gids.cpu().numpy()
-        n = len(o0) - 1
-        c0, c1 = np.diff(o0), np.diff(o1)
-        offs = np.zeros(n + 1, np.int64)
-        np.cumsum(c0 + c1, out=offs[1:])
-        out = np.empty(int(offs[-1]), np.int64)
-        # interleave the two lists per point
-        pos0 = np.repeat(offs[:-1] - o0[:-1], c0) + np.arange(len(i0))
-        pos1 = np.repeat(offs[:-1] + c0 - o1[:-1], c1) + np.arange(len(i1))
-        out[pos0] = og[i0]
-        out[pos1] = gg[i1] if len(gg) else np.zeros(0, np.int64)
-        lid = np.repeat(np.arange(n), c0 + c1)
+        offs, idx = self.engine.neighbor_csr(self._set, self._set)
+        n = self.n_owned
+        offs = np.asarray(offs[:n + 1], dtype=np.int64)
+        idx = np.asarray(idx[offs[0]:offs[n]], dtype=np.int64)
+        offs = offs - offs[0]
+        all_gids = np.concatenate([self.owned_gids.cpu().numpy(), self.ghost_gids.cpu().numpy()])
+        out = all_gids[idx]
+        lid = np.repeat(np.arange(n), np.diff(offs))
         order = np.lexsort((out, lid))
         return offs, out[order]
