@@ -70,6 +70,26 @@ def cpu_baseline(n_points: int, radius: float, seed: int):
             "host_cpus": cores, "sample": f"oracle/tns_oracle.c grid search on {n_s} uniform points, 1 run ({t:.2f} s)"}
 
 
+def pmc_traffic(arith: str, pooled: bool):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_latest.json,
+    written by tools/prof_gpu.sh on the SAME workload): counters cannot be collected inside a timed run.  Corrections as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KiB) counts 128-byte requests of wide coalesced
+    reads as 64 bytes -> doubled; WRITE_SIZE (KiB) is taken as reported (uncalibrated)."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not pooled or not os.path.exists(path):
+        return None, None
+    try:
+        prof = json.load(open(path))
+        name = f"k_query_pool_fast<{0 if arith == 'strict' else 1}, false, false, true, false>"
+        pmc = prof["kernels"][name]["pmc"]
+        fetch = 2.0 * pmc["FETCH_SIZE"] * 1024.0
+        write = pmc["WRITE_SIZE"] * 1024.0
+        return int(fetch + write), {"fetch_bytes": int(fetch), "write_bytes": int(write), "source": "profiles/pmc_latest.json (" + prof.get("source", "?") + ")",
+                                    "note": "L2<->fabric bytes (Infinity-Cache hits included); FETCH_SIZE x2 per the gfx950 guide, WRITE_SIZE uncalibrated"}
+    except (KeyError, ValueError, OSError):
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,6 +199,7 @@ def main():
     fill_bytes = 16 * n_pts + 4 * (E + Q) + 8 * Q + (0 if pooled else 8 * Q)
     fill_ms = acc["ms_fill"] / steps
     achieved = fill_bytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0
+    traffic, traffic_detail = pmc_traffic(args.arith, pooled)
     run_bytes = st["bytes_build"] + st["bytes_query"]
     dev_ms = acc["ms_total"] / steps
     out = {
@@ -191,7 +212,7 @@ def main():
                    "points_per_gpu": n, "arith": args.arith, "input_order": "z-sorted" if args.sorted_input else "as generated (random)",
                    "neighbors_total_rank0": int(E), "grid": st["grid_dims"], "parallelism": f"slab{world}"},
         "roofline": {"bound": "hbm", "kernel": "k_query_pool_fast" if pooled else "k_query<fill>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
                      "bytes_per_launch": int(fill_bytes), "avg_launch_ms": round(fill_ms, 4),
                      "whole_run": {"algorithmic_bytes": int(run_bytes), "bytes_per_point": round(run_bytes / max(n_pts, 1), 1),
                                    "device_ms": round(dev_ms, 4),

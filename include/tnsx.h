@@ -72,7 +72,7 @@ typedef struct tnsx_options {
 	                             (per-wave slabs from a device cursor; records exact and contiguous, order of records in
 	                             memory unspecified, pool has unused gaps).  1: always count -> scan -> fill, records laid
 	                             out in spatially sorted point order without gaps (deterministic, ~1.6x more query work) */
-	uint64_t max_dense_cells; /* upper bound of the dense cell table; 0 = default (2^26) */
+	uint64_t max_dense_cells; /* upper bound of the dense cell table (8 bytes per cell and point set); 0 = default = maximum (2^30) */
 	int reserved[7];
 } tnsx_options;
 
@@ -106,7 +106,7 @@ typedef struct tnsx_stats {
 	float ms_total, ms_upload, ms_bounds, ms_keys, ms_sort, ms_gather, ms_cells, ms_count, ms_scan, ms_fill, ms_mirror;
 	int n_pool_pairs;             /* pairs built in single-pass pool mode in the last run */
 	int pool_retries;             /* pool passes repeated because the pool was too small */
-	int n_fast_builds;            /* point sets binned with the counting-sort build (vs the stable radix build) */
+	int n_fast_builds;            /* reserved (always 0) */
 	/* world box of the reference semantics (TreeNSearch.cpp:415-522) */
 	float world_bottom[3], world_top[3];
 	int world_cells_pow2;

@@ -169,3 +169,31 @@ def test_cell_sort_digit_plans(name, max_cells, oracle):
     res2 = {pr: ns.neighbor_csr(*pr) for pr in case.active}
     P.assert_matches_golden(res1, load_golden(case.name), 0, oracle, f"{name} max_cells={max_cells} (exact pass)")
     P.assert_matches_golden(res2, load_golden(case.name), 0, oracle, f"{name} max_cells={max_cells} (pool pass)")
+
+
+def test_sparse_domain_and_lazy_table_clear(oracle):
+    """Two small clusters at opposite corners of a large box: > 2^26 grid cells, nearly all empty.  The dense cell table is
+    gigabytes large and is never memset per run -- the next run clears exactly the entries of the previous occupied-cell
+    list.  Moving the clusters (other cells, other grid dimensions) must therefore never leave stale cells behind."""
+    import treensearch_amd as T
+    rng = np.random.default_rng(7)
+    r = np.float32(0.002)
+    def cloud(shift, far):
+        a = rng.random((15000, 3), dtype=np.float32) * np.float32(0.03) + np.float32(shift)
+        b = rng.random((15000, 3), dtype=np.float32) * np.float32(0.03) + np.float32(far)
+        return np.ascontiguousarray(np.concatenate([a, b]))
+    pts = cloud(0.0, 1.2)
+    ns = T.TreeNSearch()
+    ns.set_search_radius(r)
+    ns.add_point_set(pts)
+    ns.set_active_search(0, 0, True)
+    ns.run()
+    st = ns.get_stats()
+    assert st["n_grid_cells"] > (1 << 26), st["n_grid_cells"]
+    assert abs(st["grid_cell_size"] / float(r) - 1.0) < 1e-3          # not coarsened
+    P.assert_same_csr(ns.neighbor_csr(0, 0), oracle.pair_search(pts, pts, radius=r, same_set=True), "sparse step 0")
+    for step, (shift, far) in enumerate([(0.011, 1.2), (0.0, 0.9), (0.3, 0.35), (0.0, 1.2)]):
+        pts[:] = cloud(shift, far)
+        ns.run()
+        P.assert_same_csr(ns.neighbor_csr(0, 0), oracle.pair_search(pts, pts, radius=r, same_set=True), f"sparse step {step + 1}")
+        assert ns.get_stats()["n_pool_pairs"] == 1

@@ -18,5 +18,5 @@ pass C FETCH_SIZE GRBM_GUI_ACTIVE
 pass D WRITE_SIZE GRBM_GUI_ACTIVE
 pass E TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum SQ_INSTS_BRANCH SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES
 find $OUT -name "*.csv" | head -40
-python tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1 < /dev/null
+python tools/prof_summary.py $OUT $OUT/pmc.json > $OUT/summary.txt 2>&1 < /dev/null
 cat $OUT/summary.txt

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Condenses a tools/prof_gpu.sh output directory into per-kernel averages (kernel-trace stats + PMC counters)."""
-import csv, glob, os, re, sys
+import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 d = sys.argv[1]
+json_out = sys.argv[2] if len(sys.argv) > 2 else None   # optional: per-kernel means as JSON (bench.py reads the HBM traffic from it)
+kt = {}
 def short(name):
     name = re.sub(r"\(.*", "", name)
     return name.replace("void tnsx::", "").replace("tnsx::", "")[:58]
@@ -11,6 +13,7 @@ def short(name):
 for f in glob.glob(os.path.join(d, "kt", "**", "*kernel_stats.csv"), recursive=True):
     print("== kernel-trace stats (us):", os.path.relpath(f, d))
     for r in csv.DictReader(open(f)):
+        kt[short(r['Name'])] = {"calls": int(r['Calls']), "avg_us": float(r['AverageNs']) / 1e3}
         print(f"  {short(r['Name']):58s} calls {r['Calls']:>5} avg_us {float(r['AverageNs'])/1e3:10.2f} total_us {float(r['TotalDurationNs'])/1e3:11.1f} {float(r['Percentage']):6.2f}%")
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
@@ -22,3 +25,9 @@ for k in sorted(acc):
     c = {n: sum(v) / len(v) for n, v in acc[k].items()}
     for n in sorted(c):
         print(f"      {n:32s} {c[n]:18.1f}")
+if json_out:
+    out = {"source": os.path.basename(os.path.normpath(d)), "note": "rocprofv3 --pmc passes of `bench.py --steps 3 --warmup 2`, mean per dispatch; "
+           "FETCH_SIZE / WRITE_SIZE are in KiB as reported (uncorrected)", "kernels": {}}
+    for k in sorted(set(acc) | set(kt)):
+        out["kernels"][k] = {"trace": kt.get(k), "pmc": {n: sum(v) / len(v) for n, v in acc.get(k, {}).items()}}
+    json.dump(out, open(json_out, "w"), indent=1, sort_keys=True)

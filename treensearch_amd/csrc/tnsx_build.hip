@@ -348,4 +348,15 @@ void launch_cell_table(const float4* xyzi_sorted, int n, GridParams g, uint2* ta
 	hipLaunchKernelGGL(k_cell_table, dim3((n + CT_TILE - 1) / CT_TILE), dim3(CT_THREADS), 0, s, xyzi_sorted, n, g, table, occ, n_occ);
 }
 
+__global__ void __launch_bounds__(256) k_table_clear(const uint2* __restrict__ occ, uint32_t n_occ, uint2* __restrict__ table)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < n_occ) table[occ[i].y] = make_uint2(0u, 0u);
+}
+void launch_table_clear(const uint2* occ, uint32_t n_occ, uint2* table, hipStream_t s)
+{
+	if (n_occ == 0) return;
+	hipLaunchKernelGGL(k_table_clear, dim3((n_occ + 255u) / 256u), dim3(256), 0, s, occ, n_occ, table);
+}
+
 }  // namespace tnsx

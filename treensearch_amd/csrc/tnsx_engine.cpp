@@ -83,6 +83,11 @@ struct PointSet {
 	DevBuf idx[2];                     // zsort scratch
 	DevBuf table, occ;
 	int sorted_buf = 0;
+	// The cell table is never memset per run (it may be gigabytes for a sparse domain): the entries a run sets are exactly the
+	// keys of its occupied-cell list, and the next run clears those first.  0 = all zero, 1 = `table_dirty` entries of `occ`
+	// are set, 2 = unknown (a run failed half way): full memset.
+	int table_state = 0;
+	uint32_t table_dirty = 0;
 	// zsort
 	std::vector<int> zsort_host;
 	DevBuf zsort_dev;
@@ -333,7 +338,8 @@ tnsx_status tnsx_create(const tnsx_options* opt, tnsx_context** out)
 	}
 	tnsx_context* c = new tnsx_context();
 	if (opt) c->opt = *opt; else tnsx_default_options(&c->opt);
-	if (c->opt.max_dense_cells == 0) c->opt.max_dense_cells = (uint64_t)1 << 26;
+	if (c->opt.max_dense_cells == 0) c->opt.max_dense_cells = (uint64_t)1 << 30;
+	if (c->opt.max_dense_cells > ((uint64_t)1 << 30)) c->opt.max_dense_cells = (uint64_t)1 << 30;   // 32-bit keys, int cell arithmetic
 	int dev = c->opt.device_id;
 	if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
 	if (dev >= n_dev) { g_create_error = "tnsx_create: device_id out of range"; delete c; return TNSX_ERR_NO_DEVICE; }
@@ -562,11 +568,17 @@ tnsx_status tnsx_run(tnsx_context* c)
 	for (int si = 0; si < n_sets; si++) {
 		PointSet& s = c->sets[si];
 		// the table is needed even for empty sets (they can be searched into)
-		HIPCHK(c, s.table.reserve(n_cells * sizeof(uint2)));
-		HIPCHK(c, s.occ.reserve((size_t)std::max(s.n, 1) * sizeof(uint2)));
 		const int t0 = tm.mark();
-		HIPCHK(c, hipMemsetAsync(s.table.p, 0, n_cells * sizeof(uint2), st));
+		{
+			const void* old_table = s.table.p;
+			HIPCHK(c, s.table.reserve(n_cells * sizeof(uint2)));
+			if (s.table.p != old_table || s.table_state == 2) HIPCHK(c, hipMemsetAsync(s.table.p, 0, s.table.cap, st));   // new or unknown: all of it
+			else if (s.table_state == 1 && s.table_dirty > 0) tnsx::launch_table_clear(s.occ.as<uint2>(), s.table_dirty, s.table.as<uint2>(), st);
+			s.table_state = 0; s.table_dirty = 0;
+		}
+		HIPCHK(c, s.occ.reserve((size_t)std::max(s.n, 1) * sizeof(uint2)));   // (after the clear: it reads the previous list)
 		if (s.n == 0) continue;
+		s.table_state = 2;   // until this run's occupied-cell count has reached the host
 		for (int k = 0; k < 2; k++) {
 			HIPCHK(c, s.xyzi[k].reserve((size_t)s.n * sizeof(float4)));
 			if (variable) HIPCHK(c, s.r2[k].reserve((size_t)s.n * sizeof(float)));
@@ -718,7 +730,10 @@ tnsx_status tnsx_run(tnsx_context* c)
 		S.n_neighbors += n_neighbors;
 		if (jb.pool) S.n_pool_pairs++;
 	}
-	for (int si = 0; si < n_sets; si++) S.n_occupied_cells += h_nocc[si];
+	for (int si = 0; si < n_sets; si++) {
+		S.n_occupied_cells += h_nocc[si];
+		if (c->sets[si].n > 0) { c->sets[si].table_state = 1; c->sets[si].table_dirty = h_nocc[si]; }
+	}
 
 	// ---- optional pinned host mirror (what get_neighborlist needs on the CPU side)
 	const int e_m0 = tm.mark();

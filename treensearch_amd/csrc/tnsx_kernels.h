@@ -24,7 +24,6 @@ void launch_bounds_partial(const float* xyz, const float* radii, int n, float* p
 void launch_bounds_final(const float* partials, int n_partials, float* out8, hipStream_t s);
 
 // ---- keys ---------------------------------------------------------------------------------------
-void launch_cell_keys(const float* xyz, int n, GridParams g, uint32_t* keys, uint32_t* idx, hipStream_t s);
 // Morton keys of the reference grid (TreeNSearch.cpp:713-715 quantisation, libmorton bit order)
 void launch_morton_keys(const float* xyz, int n, float bx, float by, float bz, float cell_size_inv, int max_coord,
                         uint64_t* keys, uint32_t* idx, hipStream_t s);
@@ -32,17 +31,12 @@ void launch_morton_keys(const float* xyz, int n, float bx, float by, float bz, f
 // ---- LSD radix sort of (key, value) pairs; stable ------------------------------------------------
 size_t radix_temp_bytes(int n);
 // sorts `key_bits` low bits.  Buffers ping-pong between [0] and [1]; returns the index holding the result.
-int radix_sort_pairs_u32(uint32_t* keys[2], uint32_t* vals[2], int n, int key_bits, void* temp, hipStream_t s);
 int radix_sort_pairs_u64(uint64_t* keys[2], uint32_t* vals[2], int n, int key_bits, void* temp, hipStream_t s);
 
 // ---- exclusive scans ----------------------------------------------------------------------------
 size_t scan_temp_bytes(size_t n);
 void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* temp, hipStream_t s);          // out[n]
 void exclusive_scan_u32_to_u64(const uint32_t* in, uint64_t* out, size_t n, void* temp, hipStream_t s);   // out[n+1], out[n]=total
-
-// ---- gather into sorted order: xyzi[p] = (x,y,z, bits(idx[p])), r2[p] = r*r ------------------------
-void launch_gather_sorted(const float* xyz, const float* radii, const uint32_t* idx_sorted, int n, float4* xyzi,
-                          float* r2, hipStream_t s);
 
 // ---- build of the search structure of one point set (tnsx_build.hip) ---------------------------------------
 // Cell sort: LSD radix sort on the cell key that moves the point itself, (x, y, z, bits(original index)) [+ r*r]; keys are
@@ -57,6 +51,8 @@ int launch_cell_sort(const float* xyz, const float* radii, int n, GridParams g, 
 // Cell table: table[key] = (first sorted position, one past last); occ = {first sorted position, key} of every occupied cell
 // (order of blocks of 4096 points is arbitrary), *n_occ = their number (must be zeroed before)
 void launch_cell_table(const float4* xyzi_sorted, int n, GridParams g, uint2* table, uint2* occ, uint32_t* n_occ, hipStream_t s);
+// zeroes the table entries of the first n_occ cells of an occupied-cell list (instead of a memset of the whole table)
+void launch_table_clear(const uint2* occ, uint32_t n_occ, uint2* table, hipStream_t s);
 
 // ---- the query ----------------------------------------------------------------------------------
 struct QueryArgs {

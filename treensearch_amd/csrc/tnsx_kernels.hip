@@ -107,23 +107,6 @@ __device__ __forceinline__ int cell_coord(float p, float o, float inv_h, int n)
 	c = c < 0 ? 0 : c;
 	return c > n - 1 ? n - 1 : c;
 }
-__global__ void __launch_bounds__(256) k_cell_keys(const float* __restrict__ xyz, int n, GridParams g, uint32_t* __restrict__ keys,
-                                                  uint32_t* __restrict__ idx)
-{
-	const int i = blockIdx.x * 256 + threadIdx.x;
-	if (i >= n) return;
-	const int ix = cell_coord(xyz[3 * (size_t)i], g.ox, g.inv_h, g.nx);
-	const int iy = cell_coord(xyz[3 * (size_t)i + 1], g.oy, g.inv_h, g.ny);
-	const int iz = cell_coord(xyz[3 * (size_t)i + 2], g.oz, g.inv_h, g.nz);
-	keys[i] = (uint32_t)((iz * g.ny + iy) * g.nx + ix);
-	idx[i] = (uint32_t)i;
-}
-void launch_cell_keys(const float* xyz, int n, GridParams g, uint32_t* keys, uint32_t* idx, hipStream_t s)
-{
-	if (n <= 0) return;
-	hipLaunchKernelGGL(k_cell_keys, dim3((n + 255) / 256), dim3(256), 0, s, xyz, n, g, keys, idx);
-}
-
 __device__ __forceinline__ uint64_t spread3(uint64_t v)
 {
 	v &= 0x1fffffull;
@@ -262,7 +245,8 @@ void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* temp,
 void exclusive_scan_u32_to_u64(const uint32_t* in, uint64_t* out, size_t n, void* temp, hipStream_t s) { scan_impl<uint64_t>(in, out, n, temp, s, 1); }
 
 // =====================================================================================================
-// LSD radix sort, 8-bit digits, stable.  Per pass: per-block digit histogram -> scan -> ranked scatter.
+// LSD radix sort of (key, value) pairs, 8-bit digits, stable (used by prepare_zsort; the search structure has its own
+// sort in tnsx_build.hip).  Per pass: per-block digit histogram -> scan -> ranked scatter.
 // A block owns a tile of 4096 consecutive elements; wave w owns the 1024-element sub-tile w and walks it
 // in 16 rounds of 64 consecutive elements, so (wave, round, lane) order == index order == stable order.
 // =====================================================================================================
@@ -375,30 +359,7 @@ static int radix_sort_impl(KeyT* keys[2], uint32_t* vals[2], int n, int key_bits
 	}
 	return cur;
 }
-int radix_sort_pairs_u32(uint32_t* keys[2], uint32_t* vals[2], int n, int key_bits, void* temp, hipStream_t s) { return radix_sort_impl<uint32_t>(keys, vals, n, key_bits, temp, s); }
 int radix_sort_pairs_u64(uint64_t* keys[2], uint32_t* vals[2], int n, int key_bits, void* temp, hipStream_t s) { return radix_sort_impl<uint64_t>(keys, vals, n, key_bits, temp, s); }
-
-// =====================================================================================================
-// gather into sorted order
-// =====================================================================================================
-__global__ void __launch_bounds__(256) k_gather_sorted(const float* __restrict__ xyz, const float* __restrict__ radii, const uint32_t* __restrict__ idx,
-                                                      int n, float4* __restrict__ xyzi, float* __restrict__ r2)
-{
-	const int p = blockIdx.x * 256 + threadIdx.x;
-	if (p >= n) return;
-	const uint32_t i = idx[p];
-	float4 v;
-	v.x = xyz[3 * (size_t)i]; v.y = xyz[3 * (size_t)i + 1]; v.z = xyz[3 * (size_t)i + 2];
-	v.w = __uint_as_float(i);
-	xyzi[p] = v;
-	if (radii) { const float r = radii[i]; r2[p] = __fmul_rn(r, r); }   // radii_sq = r*r in fp32, TreeNSearch.cpp:2352
-}
-void launch_gather_sorted(const float* xyz, const float* radii, const uint32_t* idx_sorted, int n, float4* xyzi, float* r2, hipStream_t s)
-{
-	if (n <= 0) return;
-	hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, s, xyz, radii, idx_sorted, n, xyzi, r2);
-}
-
 
 // =====================================================================================================
 // permutation of fixed-size byte records (device-side apply_zsort, TreeNSearch.h:465-480)

@@ -474,7 +474,10 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 //   * handles only "simple" cells (all candidates in one register batch, at most 64 query points); the others are
 //     appended to a worklist that the general kernel above processes afterwards -- this keeps registers low.
 // =====================================================================================================
-static constexpr uint32_t Q_TICKET = 8;
+#ifndef TNSX_Q_TICKET
+#define TNSX_Q_TICKET 8   // cells per ticket (<= 32: one bit per cell in the ticket's reject mask)
+#endif
+static constexpr uint32_t Q_TICKET = TNSX_Q_TICKET;
 
 // Instruction budget notes (tools/ubench/issue_model.hip, MI355X): a scalar instruction costs ~4.3 SIMD cycles -- as much
 // as a v_cmp or a packed-fp32 op, more than a plain VALU op (2.6) -- and overlaps only partly with VALU work of other
@@ -750,7 +753,11 @@ static void launch_query_3(const QueryArgs& a, const QueryConfig& c, int n_cus, 
 	const int blocks = ((n_cus * per_cu + 7) / 8) * 8;
 	if (c.mode == QUERY_COUNT) launch_query_t<ARITH, VARIABLE, SYM, SELF, MODE_COUNT>(a, blocks, s);
 	else if (c.mode == QUERY_FILL) launch_query_t<ARITH, VARIABLE, SYM, SELF, MODE_FILL>(a, blocks, s);
-	else launch_pool_t<ARITH, VARIABLE, SYM, SELF>(a, ((n_cus * 8 + 7) / 8) * 8, ((n_cus * 2 + 7) / 8) * 8, s);
+	else {
+		int fast_per_cu = 8;
+		if (const char* e = getenv("TNSX_FAST_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) fast_per_cu = v; }   // tuning knob
+		launch_pool_t<ARITH, VARIABLE, SYM, SELF>(a, ((n_cus * fast_per_cu + 7) / 8) * 8, ((n_cus * 2 + 7) / 8) * 8, s);
+	}
 }
 template <int ARITH, bool VARIABLE, bool SYM>
 static void launch_query_2(const QueryArgs& a, const QueryConfig& c, int n_cus, hipStream_t s)
