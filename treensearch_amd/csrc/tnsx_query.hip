@@ -185,7 +185,7 @@ __device__ __forceinline__ void emit_chunk(const int* rec, uint32_t pos, uint64_
 		"v_mbcnt_lo_u32_b32 %[t], %[mlo], 0\n\t"
 		"v_mbcnt_hi_u32_b32 %[t], %[mhi], %[t]\n\t"
 		"v_add_lshl_u32 %[t], %[t], %[pos], 2\n\t"
-		"global_store_dword %[t], %[v], %[base] offset:4\n\t"
+		"global_store_dword %[t], %[v], %[base] offset:4\n\t"   // (nt / sc1 stores were tried: 1.79 -> 2.45..2.70 ms, the L2 must merge these partial lines)
 		"s_mov_b64 exec, -1"
 		: [t] "=&v"(tmp)
 		: [m] "s"(m), [mlo] "s"((uint32_t)m), [mhi] "s"((uint32_t)(m >> 32)), [pos] "s"(pos), [v] "v"(v), [base] "s"(rec)
@@ -468,16 +468,12 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 
 // =====================================================================================================
 // pool-mode FAST kernel: the steady-state hot path.
-//   * dynamic scheduling: every XCD owns one contiguous eighth of the occupied-cell list and hands it out in tickets of
-//     Q_TICKET consecutive cells through its own atomic counter, so any number of resident waves stays busy to the end
-//     (no static-partition tail, clustered clouds balance themselves);
+//   * dynamic scheduling: every XCD owns one contiguous eighth of the occupied-cell list and hands it out cell by cell
+//     through its own atomic counter, so any number of resident waves stays busy to the end (no static-partition tail,
+//     clustered clouds balance themselves) and the waves of an XCD always work on neighbouring cells;
 //   * handles only "simple" cells (all candidates in one register batch, at most 64 query points); the others are
 //     appended to a worklist that the general kernel above processes afterwards -- this keeps registers low.
 // =====================================================================================================
-#ifndef TNSX_Q_TICKET
-#define TNSX_Q_TICKET 8   // cells per ticket (<= 32: one bit per cell in the ticket's reject mask)
-#endif
-static constexpr uint32_t Q_TICKET = TNSX_Q_TICKET;
 
 // Instruction budget notes (tools/ubench/issue_model.hip, MI355X): a scalar instruction costs ~4.3 SIMD cycles -- as much
 // as a v_cmp or a packed-fp32 op, more than a plain VALU op (2.6) -- and overlaps only partly with VALU work of other
@@ -655,74 +651,76 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 	const uint32_t n_occ = FAT ? *a.n_heavy : *a.n_occ_i;
 	const uint32_t xcd = blockIdx.x & 7u;
 	const uint32_t lo = (uint32_t)(((uint64_t)n_occ * xcd) >> 3), hi = (uint32_t)(((uint64_t)n_occ * (xcd + 1u)) >> 3);
-	// more waves than tickets (short worklists of the later tiers): the surplus leaves without touching the counter
-	if ((blockIdx.x >> 3) * Q_WAVES + threadIdx.x / WAVE >= (hi - lo + Q_TICKET - 1u) / Q_TICKET) return;
+	// more waves than cells (short worklists of the later tiers): the surplus leaves without touching the counter
+	if ((blockIdx.x >> 3) * Q_WAVES + threadIdx.x / WAVE >= hi - lo) return;
 	uint32_t* const my_tickets = tickets + xcd * CTRL_STRIDE_U32;
 	PoolState ps = { 0u, 0u, 0u, 0u };
 	uint32_t wave_hits = 0;
 
-	// the ticket is always fetched one round ahead, so that its round trip overlaps the previous ticket's cells
-	uint32_t next_ticket = 0;
-	if (lane == 0) next_ticket = atomicAdd(my_tickets, 1u);
-	for (;;) {
-		const uint32_t ticket = readfirstlane_u32(next_ticket);
-		const uint32_t first = lo + ticket * Q_TICKET;
-		if (first >= hi) break;
-		if (lane == 0) next_ticket = atomicAdd(my_tickets, 1u);
-		const uint32_t ncell = (hi - first) < Q_TICKET ? (hi - first) : Q_TICKET;
-		// the ticket's occupied-cell entries, one per lane
-		uint2 ocv = make_uint2(0u, 0u);
-		if ((uint32_t)lane < ncell) ocv = cell_list[first + lane];
-		// lookups of the first cell; afterwards always one cell ahead
-		uint32_t s, e;
-		uint32_t key = readlane_u32(ocv.y, 0);
-		lookup_cell(a, key, true, lane, s, e);
-		uint2 qrange = a.table_i[key];
-		uint32_t heavy_mask = 0;
+	// One cell per ticket (measured: 1.79 ms against 1.99 ms with tickets of 8 cells -- the waves of an XCD then work inside a
+	// narrow window of the key-ordered cell list and share their 27-neighbourhoods in the L2), fetched through a three-deep
+	// software pipeline so that only the candidate loads of a cell are ever waited for:
+	//   ticket (atomic) two cells ahead -> occupied-cell entry one cell ahead -> its 27 lookups issued before the current
+	//   cell is processed.
+	auto take = [&]() { uint32_t t = 0; if (lane == 0) t = atomicAdd(my_tickets, 1u); return t; };
+	auto entry = [&](uint32_t first) { return cell_list[first < hi ? first : lo]; };   // uniform address; clamped, never out of range
+	uint32_t tk_pending = take();
+	uint32_t first_cur = lo + readfirstlane_u32(tk_pending);
+	if (first_cur >= hi) return;
+	tk_pending = take();
+	uint2 oc = entry(first_cur);
+	uint32_t first_next = lo + readfirstlane_u32(tk_pending);
+	tk_pending = take();
+	uint2 oc_next = entry(first_next);
+	uint32_t key = readfirstlane_u32(oc.y), p0 = readfirstlane_u32(oc.x);
+	uint32_t s, e;
+	lookup_cell(a, key, true, lane, s, e);
+	uint2 qrange = a.table_i[key];
 
-		for (uint32_t c = 0; c < ncell; c++) {
-			const uint32_t s1 = __shfl_down(s, 1, WAVE), e1 = __shfl_down(e, 1, WAVE);
-			const uint32_t s2 = __shfl_down(s, 2, WAVE), e2 = __shfl_down(e, 2, WAVE);
-			RunRef RR;
-			RR.run_start = (e > s) ? s : ((e1 > s1) ? s1 : s2);
-			const uint32_t run_end = (e2 > s2) ? e2 : ((e1 > s1) ? e1 : e);
-			RR.run_len = ((e > s) || (e1 > s1) || (e2 > s2)) ? run_end - RR.run_start : 0u;   // empty entries may hold any (s,s)
-			{
-				const Runs R0 = extract_runs(RR.run_start, RR.run_len);
-				RR.total = R0.total;
-				RR.d_self = R0.d0;
-			}
-			const uint2 cur_q = qrange;
-			if (c + 1 < ncell) {
-				key = readlane_u32(ocv.y, (int)(c + 1));
-				lookup_cell(a, key, true, lane, s, e);
-				qrange = a.table_i[key];
-			}
-			const uint32_t nq = cur_q.y - cur_q.x;
-			if (RR.total > MAX_SLOTS || nq > (uint32_t)WAVE || (SELF && (cur_q.y - RR.d_self) > 2u * WAVE)) {
-				heavy_mask |= 1u << c;      // not simple: leave it to the general kernel (appended after the ticket's loop)
-				continue;
-			}
-			if (RR.total == 0u) {
-				// no candidate at all (set_j is another, sparser or empty set): nq empty records, one int each
-				bool okz;
-				const uint64_t off = pool_alloc(a, ps, nq, lane, okz);
-				if ((uint32_t)lane < nq && okz) {
-					a.records[off + lane] = 0;
-					a.offs_by_orig[__float_as_uint(a.xyzi_i[cur_q.x + lane].w)] = off + lane;
-				}
-				continue;
-			}
-			fast_cell_nc<ARITH, VARIABLE, SYM, SELF, FAT>(a, RR, lane, cur_q, ps, wave_hits);
+	for (;;) {
+		// ---- advance the pipeline: ticket of cell +2 has arrived, entry of cell +1 has arrived
+		const uint32_t first_next2 = lo + readfirstlane_u32(tk_pending);
+		tk_pending = take();
+		const bool have_next = first_next < hi;
+		const uint32_t key_next = readfirstlane_u32(oc_next.y), p0_next = readfirstlane_u32(oc_next.x);
+		oc_next = entry(first_next2);
+
+		// ---- current cell: merge the x-triples of its 27 lookups into 9 runs
+		const uint32_t s1 = __shfl_down(s, 1, WAVE), e1 = __shfl_down(e, 1, WAVE);
+		const uint32_t s2 = __shfl_down(s, 2, WAVE), e2 = __shfl_down(e, 2, WAVE);
+		RunRef RR;
+		RR.run_start = (e > s) ? s : ((e1 > s1) ? s1 : s2);
+		const uint32_t run_end = (e2 > s2) ? e2 : ((e1 > s1) ? e1 : e);
+		RR.run_len = ((e > s) || (e1 > s1) || (e2 > s2)) ? run_end - RR.run_start : 0u;   // empty entries may hold any (s,s)
+		{
+			const Runs R0 = extract_runs(RR.run_start, RR.run_len);
+			RR.total = R0.total;
+			RR.d_self = R0.d0;
 		}
-		if (heavy_mask) {
-			// one atomic per ticket; lane c still holds the {first position, key} entry of the ticket's cell c
-			const uint32_t nh = (uint32_t)__popc(heavy_mask);
-			uint32_t hb = 0;
-			if (lane == 0) hb = atomicAdd(reject_count, nh);
-			hb = readfirstlane_u32(hb);
-			if ((uint32_t)lane < ncell && ((heavy_mask >> lane) & 1u)) reject_list[hb + (uint32_t)__popc(heavy_mask & ((1u << lane) - 1u))] = ocv;
+		const uint2 cur_q = qrange;
+		// ---- lookups of the next cell: in flight while this one is processed
+		lookup_cell(a, key_next, have_next, lane, s, e);
+		qrange = a.table_i[have_next ? key_next : key];
+
+		const uint32_t nq = cur_q.y - cur_q.x;
+		if (RR.total > MAX_SLOTS || nq > (uint32_t)WAVE || (SELF && (cur_q.y - RR.d_self) > 2u * WAVE)) {
+			// not for this tier: append the cell to the next tier's worklist
+			if (lane == 0) reject_list[atomicAdd(reject_count, 1u)] = make_uint2(p0, key);
 		}
+		else if (RR.total == 0u) {
+			// no candidate at all (set_j is another, sparser or empty set): nq empty records, one int each
+			bool okz;
+			const uint64_t off = pool_alloc(a, ps, nq, lane, okz);
+			if ((uint32_t)lane < nq && okz) {
+				a.records[off + lane] = 0;
+				a.offs_by_orig[__float_as_uint(a.xyzi_i[cur_q.x + lane].w)] = off + lane;
+			}
+		}
+		else fast_cell_nc<ARITH, VARIABLE, SYM, SELF, FAT>(a, RR, lane, cur_q, ps, wave_hits);
+
+		if (!have_next) break;
+		key = key_next; p0 = p0_next;
+		first_next = first_next2;
 	}
 	if (lane == 0 && wave_hits) atomicAdd(a.hit_total, (unsigned long long)wave_hits);
 }
