@@ -7,7 +7,7 @@
 // of a 0.45 ms sort, the scattered 16-byte point stores 0.05 ms.
 //
 //   k_cs_hist<FIRST>     per-tile histogram of one digit               12 B (user xyz) or 16 B read per point
-//   k_cs_scan_bins       per digit value: exclusive scan over the tiles (one workgroup per digit value) + its total
+//   k_cs_strip_sums/scan exclusive scan of the tile histograms over the tiles (per digit value) + the totals
 //   k_cs_scatter<FIRST>  ranked, stable scatter of the points          12|16 B read, 16 B written per point
 //   k_cell_table         table[key] = (first, one past last) sorted position, list of occupied cells
 //
@@ -50,7 +50,8 @@ CellSortPlan cell_sort_plan(int key_bits)
 size_t cell_sort_temp_bytes(int n)
 {
 	const size_t hist_elems = ((size_t)1 << CS_MAX_BITS) * (size_t)cs_num_tiles(n > 0 ? n : 1);
-	return ((hist_elems * sizeof(uint32_t) + 255) / 256) * 256 + ((size_t)1 << CS_MAX_BITS) * sizeof(uint32_t) + 256;
+	const size_t nstrips = ((size_t)cs_num_tiles(n > 0 ? n : 1) + 31) / 32;
+	return ((hist_elems * sizeof(uint32_t) + 255) / 256) * 256 + ((size_t)1 << CS_MAX_BITS) * sizeof(uint32_t) * (1 + nstrips) + 256;
 }
 
 struct F3 { float x, y, z; };   // 12-byte AoS point of the user array (4-byte aligned)
@@ -93,37 +94,44 @@ __global__ void __launch_bounds__(CS_THREADS) k_cs_hist(const float* __restrict_
 		}
 	}
 	__syncthreads();
-	for (int b = threadIdx.x; b < RADIX; b += CS_THREADS) hist[(size_t)b * ntiles + blockIdx.x] = h[b];
+	for (int b = threadIdx.x; b < RADIX; b += CS_THREADS) hist[(size_t)blockIdx.x * RADIX + b] = h[b];   // row = tile: coalesced
 }
 
-// ---- one workgroup per digit value: exclusive scan of its tile counts in place, total -> totals[value] ------------
+// ---- scan of the tile histograms down the columns: hist[tile][value] -> exclusive prefix over the tiles, totals[value].
+//      The table is stored row = tile (the histogram and scatter kernels then read and write whole rows; written column-wise
+//      the 4-byte stores of the histogram kernel cost +25 us per pass).  Two small kernels over strips of SB_STRIP tiles:
+//      column sums of every strip, then every strip adds the sums of the strips before it and scans its own rows in place.
 static constexpr int SB_THREADS = 256;
-__global__ void __launch_bounds__(SB_THREADS) k_cs_scan_bins(uint32_t* __restrict__ hist, int ntiles, uint32_t* __restrict__ totals)
+static constexpr int SB_STRIP = 32;
+template <int BITS>
+__global__ void __launch_bounds__(SB_THREADS) k_cs_strip_sums(const uint32_t* __restrict__ hist, int ntiles, uint32_t* __restrict__ strip_sums)
 {
-	__shared__ uint32_t wsum[SB_THREADS / WAVE];
-	uint32_t* row = hist + (size_t)blockIdx.x * ntiles;
-	uint32_t carry = 0;
-	for (int base = 0; base < ntiles; base += SB_THREADS * 4) {
-		const int e = base + (int)threadIdx.x * 4;
-		uint32_t v[4];
+	constexpr int RADIX = 1 << BITS;
+	const int t0 = blockIdx.x * SB_STRIP, t1 = min(t0 + SB_STRIP, ntiles);
+	const int b = blockIdx.y * SB_THREADS + threadIdx.x;   // grid.y = RADIX / SB_THREADS
+	uint32_t acc = 0;
+	#pragma unroll 16
+	for (int t = t0; t < t1; t++) acc += hist[(size_t)t * RADIX + b];
+	strip_sums[(size_t)blockIdx.x * RADIX + b] = acc;
+}
+template <int BITS>
+__global__ void __launch_bounds__(SB_THREADS) k_cs_strip_scan(uint32_t* __restrict__ hist, int ntiles, const uint32_t* __restrict__ strip_sums,
+                                                              uint32_t* __restrict__ totals)
+{
+	constexpr int RADIX = 1 << BITS;
+	const int t0 = blockIdx.x * SB_STRIP, t1 = min(t0 + SB_STRIP, ntiles);
+	const int b = blockIdx.y * SB_THREADS + threadIdx.x;   // grid.y = RADIX / SB_THREADS
+	uint32_t base = 0;
+	#pragma unroll 16
+	for (int st = 0; st < (int)blockIdx.x; st++) base += strip_sums[(size_t)st * RADIX + b];
+	for (int t = t0; t < t1; t += 16) {
+		uint32_t v[16];
 		#pragma unroll
-		for (int k = 0; k < 4; k++) v[k] = (e + k < ntiles) ? row[e + k] : 0u;
-		const uint32_t t = v[0] + v[1] + v[2] + v[3];
-		uint32_t inc = t;
+		for (int k = 0; k < 16; k++) v[k] = (t + k < t1) ? hist[(size_t)(t + k) * RADIX + b] : 0u;
 		#pragma unroll
-		for (int o = 1; o < WAVE; o <<= 1) { const uint32_t u = __shfl_up(inc, o, WAVE); if (lane_id() >= o) inc += u; }
-		__syncthreads();   // wsum reuse
-		if (lane_id() == WAVE - 1) wsum[threadIdx.x / WAVE] = inc;
-		__syncthreads();
-		uint32_t woff = 0, chunk_total = 0;
-		#pragma unroll
-		for (int w = 0; w < SB_THREADS / WAVE; w++) { if (w < (int)(threadIdx.x / WAVE)) woff += wsum[w]; chunk_total += wsum[w]; }
-		uint32_t ex = carry + woff + inc - t;
-		#pragma unroll
-		for (int k = 0; k < 4; k++) { if (e + k < ntiles) row[e + k] = ex; ex += v[k]; }
-		carry += chunk_total;
+		for (int k = 0; k < 16; k++) { if (t + k < t1) hist[(size_t)(t + k) * RADIX + b] = base; base += v[k]; }
 	}
-	if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+	if (blockIdx.x == gridDim.x - 1) totals[b] = base;
 }
 
 // ---- ranked scatter of the points --------------------------------------------------------------------------------
@@ -191,7 +199,7 @@ k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, con
 		#pragma unroll
 		for (int k = 0; k < PER; k++) {
 			const int b = threadIdx.x * PER + k;
-			gbase[b] = ex + hist_scanned[(size_t)b * ntiles + tile];
+			gbase[b] = ex + hist_scanned[(size_t)tile * RADIX + b];
 			ex += tot[k];
 		}
 	}
@@ -243,6 +251,13 @@ static void cs_hist(bool first, const float* xyz, const float4* xyzi, int n, con
 	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_hist<BITS, false>), dim3(ntiles), dim3(CS_THREADS), 0, s, xyz, xyzi, n, g, shift, hist, ntiles);
 }
 template <int BITS>
+static void cs_scan(uint32_t* hist, int ntiles, uint32_t* strip_sums, uint32_t* totals, hipStream_t s)
+{
+	const int nstrips = (ntiles + SB_STRIP - 1) / SB_STRIP;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_strip_sums<BITS>), dim3(nstrips, (1u << BITS) / SB_THREADS), dim3(SB_THREADS), 0, s, hist, ntiles, strip_sums);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_strip_scan<BITS>), dim3(nstrips, (1u << BITS) / SB_THREADS), dim3(SB_THREADS), 0, s, hist, ntiles, strip_sums, totals);
+}
+template <int BITS>
 static void cs_scatter(bool first, bool variable, const float* xyz, const float* radii, const float4* xyzi_in, const float* r2_in, float4* xyzi_out,
                        float* r2_out, int n, const GridParams& g, int shift, const uint32_t* hs, const uint32_t* totals, int ntiles, hipStream_t s)
 {
@@ -270,12 +285,13 @@ int launch_cell_sort(const float* xyz, const float* radii, int n, GridParams g, 
 	const size_t hist_cap = ((size_t)1 << CS_MAX_BITS) * (size_t)ntiles;
 	uint32_t* hist = (uint32_t*)temp;
 	uint32_t* totals = (uint32_t*)((char*)temp + ((hist_cap * sizeof(uint32_t) + 255) / 256) * 256);
+	uint32_t* strip_sums = totals + ((size_t)1 << CS_MAX_BITS);
 	const bool variable = radii != nullptr;
 	int cur = 0, shift = 0;
 	for (int p = 0; p < plan.passes; p++) {
 		const int bits = plan.bits[p];
 		TNSX_CS_DISPATCH(bits, cs_hist<B>(p == 0, xyz, b.xyzi[cur], n, g, shift, hist, ntiles, s));
-		hipLaunchKernelGGL(k_cs_scan_bins, dim3(1u << bits), dim3(SB_THREADS), 0, s, hist, ntiles, totals);
+		TNSX_CS_DISPATCH(bits, cs_scan<B>(hist, ntiles, strip_sums, totals, s));
 		TNSX_CS_DISPATCH(bits, cs_scatter<B>(p == 0, variable, xyz, radii, b.xyzi[cur], b.r2[cur], b.xyzi[cur ^ 1], b.r2[cur ^ 1], n, g, shift, hist,
 		                                     totals, ntiles, s));
 		cur ^= 1;

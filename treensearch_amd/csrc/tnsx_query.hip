@@ -631,12 +631,15 @@ __device__ __forceinline__ void fast_cell_nc(const QueryArgs& a, const RunRef RR
 	}
 }
 
+// Occupancy of the first tier.  Left alone the compiler takes 85 VGPRs (5 waves per SIMD); capped at 80 it spills eight
+// dwords outside the query loop and runs 6 waves: -7 % (measured with tools/ab_libs.py; 3 / 4 / 5 / 6 waves: 2.11 / 1.92 /
+// 1.94 / 1.80 ms).  The second tier keeps its 3 waves (it needs ~135 VGPRs for 16 chunks).
 #ifndef TNSX_FAST_WAVES_PER_EU
-#define TNSX_FAST_WAVES_PER_EU 0   // 0 = let the compiler choose
+#define TNSX_FAST_WAVES_PER_EU 6
 #endif
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF, bool FAT>
-#if TNSX_FAST_WAVES_PER_EU
-__attribute__((amdgpu_waves_per_eu(TNSX_FAST_WAVES_PER_EU, TNSX_FAST_WAVES_PER_EU)))
+#if TNSX_FAST_WAVES_PER_EU > 0
+__attribute__((amdgpu_waves_per_eu(FAT ? 3 : TNSX_FAST_WAVES_PER_EU, FAT ? 3 : TNSX_FAST_WAVES_PER_EU)))
 #endif
 __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a)
 {
