@@ -9,14 +9,24 @@ import treensearch_amd.api as A
 from treensearch_amd import datagen as D
 ap = argparse.ArgumentParser(); ap.add_argument("libs", nargs="+"); ap.add_argument("--rounds", type=int, default=6); ap.add_argument("--steps", type=int, default=15)
 ap.add_argument("--points", type=int, default=10_000_000)
+ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2", help="c2 uniform fixed radius; c3 two sets 0->0,0->1; c4 dam break, per-point radii, symmetric")
 args = ap.parse_args()
 n = args.points
-pts = torch.from_numpy(D.uniform_cloud(n, 12345)).cuda()
+if args.workload == "c2":
+    sets = [(torch.from_numpy(D.uniform_cloud(n, 12345)).cuda(), None)]; radius = D.radius_for_neighbors(n); pairs = [(0, 0)]
+elif args.workload == "c3":
+    f, b, radius = D.two_set_cloud(int(0.8 * n), n - int(0.8 * n))
+    sets = [(torch.from_numpy(f).cuda(), None), (torch.from_numpy(b).cuda(), None)]; pairs = [(0, 0), (0, 1)]
+else:
+    p, rad, _ = D.dam_break_cloud(n)
+    sets = [(torch.from_numpy(p).cuda(), torch.from_numpy(rad).cuda())]; radius = None; pairs = [(0, 0)]
 engines = []
 for path in args.libs:
     A._lib = None; A.LIB_PATH = os.path.abspath(path)
     ns = A.TreeNSearch(stream=torch.cuda.current_stream().cuda_stream, collect_stage_times=True)
-    ns.set_search_radius(D.radius_for_neighbors(n)); ns.add_point_set(pts); ns.set_active_search(0, 0, True)
+    if radius is not None: ns.set_search_radius(radius)
+    for (p, r) in sets: ns.add_point_set(p, r)
+    for (i, j) in pairs: ns.set_active_search(i, j, True)
     for _ in range(3): ns.run()
     engines.append(ns)
 acc = [dict(fill=[], sort=[], total=[]) for _ in engines]

@@ -74,7 +74,7 @@ struct QueryArgs {
 	uint64_t pool_capacity;            // ints available in `records`
 	uint32_t pool_slab;                // ints a wave takes from the cursor per atomic
 	unsigned long long* hit_total;     // += number of neighbour indices emitted
-	uint32_t* tickets;                 // per-XCD ticket counters of the fast kernel: tickets[x * CTRL_STRIDE_U32] (zeroed before the launch)
+	uint32_t* tickets;                 // ticket counters of the fast kernel: tickets[(xcd * CTRL_SUBRANGES + piece) * CTRL_STRIDE_U32] (zeroed before the launch)
 	uint2* heavy;                      // worklist {first sorted position, key} of the cells the fast kernel skipped
 	uint32_t* n_heavy;                 // its length (zeroed before the launch)
 	uint32_t* tickets2; uint2* heavy2; uint32_t* n_heavy2;   // the same for the second tier (fat kernel -> general kernel)
@@ -83,8 +83,9 @@ struct QueryArgs {
 // atomics that hit the same cache line (measured: ~88 atomics/us per line, whatever the word), and the stride also spreads
 // the counters over different L2 channels whether these interleave at 256 B or at 4 KiB.
 static constexpr size_t CTRL_STRIDE_U32 = 1088;
-enum { CTRL_CURSOR = 0 /* u64 cursor, u64 hit_total */, CTRL_TICKETS = 1 /* 8 slots */, CTRL_NHEAVY = 9, CTRL_TICKETS2 = 10 /* 8 slots */,
-       CTRL_NHEAVY2 = 18, CTRL_SLOTS = 19 };
+static constexpr uint32_t CTRL_SUBRANGES = 8;   // ticket counters per XCD and tier (each hands out one contiguous piece of the XCD's cells)
+enum { CTRL_CURSOR = 0 /* u64 cursor, u64 hit_total */, CTRL_TICKETS = 1 /* 8 x CTRL_SUBRANGES slots */, CTRL_NHEAVY = CTRL_TICKETS + 8 * CTRL_SUBRANGES,
+       CTRL_TICKETS2 = CTRL_NHEAVY + 1 /* 8 x CTRL_SUBRANGES slots */, CTRL_NHEAVY2 = CTRL_TICKETS2 + 8 * CTRL_SUBRANGES, CTRL_SLOTS = CTRL_NHEAVY2 + 1 };
 static constexpr size_t CTRL_BYTES = CTRL_SLOTS * CTRL_STRIDE_U32 * sizeof(uint32_t);
 enum { QUERY_COUNT = 0, QUERY_FILL = 1, QUERY_POOL = 2 };
 struct QueryConfig {

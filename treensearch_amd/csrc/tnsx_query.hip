@@ -637,9 +637,12 @@ __device__ __forceinline__ void fast_cell_nc(const QueryArgs& a, const RunRef RR
 #ifndef TNSX_FAST_WAVES_PER_EU
 #define TNSX_FAST_WAVES_PER_EU 6
 #endif
+#ifndef TNSX_FAT_WAVES_PER_EU
+#define TNSX_FAT_WAVES_PER_EU 3
+#endif
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF, bool FAT>
 #if TNSX_FAST_WAVES_PER_EU > 0
-__attribute__((amdgpu_waves_per_eu(FAT ? 3 : TNSX_FAST_WAVES_PER_EU, FAT ? 3 : TNSX_FAST_WAVES_PER_EU)))
+__attribute__((amdgpu_waves_per_eu(FAT ? TNSX_FAT_WAVES_PER_EU : TNSX_FAST_WAVES_PER_EU, FAT ? TNSX_FAT_WAVES_PER_EU : TNSX_FAST_WAVES_PER_EU)))
 #endif
 __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a)
 {
@@ -656,23 +659,47 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 	const uint32_t lo = (uint32_t)(((uint64_t)n_occ * xcd) >> 3), hi = (uint32_t)(((uint64_t)n_occ * (xcd + 1u)) >> 3);
 	// more waves than cells (short worklists of the later tiers): the surplus leaves without touching the counter
 	if ((blockIdx.x >> 3) * Q_WAVES + threadIdx.x / WAVE >= hi - lo) return;
-	uint32_t* const my_tickets = tickets + xcd * CTRL_STRIDE_U32;
 	PoolState ps = { 0u, 0u, 0u, 0u };
 	uint32_t wave_hits = 0;
 
-	// One cell per ticket (measured: 1.79 ms against 1.99 ms with tickets of 8 cells -- the waves of an XCD then work inside a
-	// narrow window of the key-ordered cell list and share their 27-neighbourhoods in the L2), fetched through a three-deep
-	// software pipeline so that only the candidate loads of a cell are ever waited for:
+	// One cell per ticket (measured: 1.79 ms against 1.99 ms with tickets of 8 cells), fetched through a three-deep software
+	// pipeline so that only the candidate loads of a cell are ever waited for:
 	//   ticket (atomic) two cells ahead -> occupied-cell entry one cell ahead -> its 27 lookups issued before the current
 	//   cell is processed.
-	auto take = [&]() { uint32_t t = 0; if (lane == 0) t = atomicAdd(my_tickets, 1u); return t; };
+	// One counter can hand out ~88 tickets per microsecond (the L2 serialises the atomics of a cache line), which would cap a
+	// pass over millions of cheap cells.  Every XCD's share of the cell list is therefore cut into CTRL_SUBRANGES contiguous
+	// pieces with a counter each; a wave starts on piece (its index % CTRL_SUBRANGES) and moves on to the next piece when one
+	// is used up, until all are.
+	const uint32_t span = hi - lo;
+	uint32_t sub = readfirstlane_u32(((blockIdx.x >> 3) * Q_WAVES + threadIdx.x / WAVE) % CTRL_SUBRANGES), used_up = 0;
+	auto sub_begin = [&](uint32_t k) { return lo + (uint32_t)(((uint64_t)span * k) / CTRL_SUBRANGES); };
+	uint32_t cur_lo = sub_begin(sub), cur_hi = sub_begin(sub + 1u);
+	auto take = [&]() { uint32_t t = 0; if (lane == 0) t = atomicAdd(tickets + (xcd * CTRL_SUBRANGES + sub) * CTRL_STRIDE_U32, 1u); return t; };
+	// a returned ticket -> position in the cell list (>= hi: nothing is left anywhere on this XCD)
+	auto resolve = [&](uint32_t pending) -> uint32_t {
+		uint32_t t = readfirstlane_u32(pending);
+		while (cur_lo + t >= cur_hi) {
+			if (++used_up >= CTRL_SUBRANGES) return hi;
+			sub = (sub + 1u) % CTRL_SUBRANGES; cur_lo = sub_begin(sub); cur_hi = sub_begin(sub + 1u);
+			t = readfirstlane_u32(take());
+		}
+		return cur_lo + t;
+	};
 	auto entry = [&](uint32_t first) { return cell_list[first < hi ? first : lo]; };   // uniform address; clamped, never out of range
+	uint2 rej = make_uint2(0u, 0u);
+	uint32_t rej_n = 0;
+	auto flush_rejects = [&]() {
+		uint32_t hb = 0;
+		if (lane == 0) hb = atomicAdd(reject_count, rej_n);
+		hb = readfirstlane_u32(hb);
+		if ((uint32_t)lane < rej_n) reject_list[hb + (uint32_t)lane] = rej;
+	};
 	uint32_t tk_pending = take();
-	uint32_t first_cur = lo + readfirstlane_u32(tk_pending);
+	uint32_t first_cur = resolve(tk_pending);
 	if (first_cur >= hi) return;
 	tk_pending = take();
 	uint2 oc = entry(first_cur);
-	uint32_t first_next = lo + readfirstlane_u32(tk_pending);
+	uint32_t first_next = resolve(tk_pending);
 	tk_pending = take();
 	uint2 oc_next = entry(first_next);
 	uint32_t key = readfirstlane_u32(oc.y), p0 = readfirstlane_u32(oc.x);
@@ -682,7 +709,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 
 	for (;;) {
 		// ---- advance the pipeline: ticket of cell +2 has arrived, entry of cell +1 has arrived
-		const uint32_t first_next2 = lo + readfirstlane_u32(tk_pending);
+		const uint32_t first_next2 = resolve(tk_pending);
 		tk_pending = take();
 		const bool have_next = first_next < hi;
 		const uint32_t key_next = readfirstlane_u32(oc_next.y), p0_next = readfirstlane_u32(oc_next.x);
@@ -707,8 +734,10 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 
 		const uint32_t nq = cur_q.y - cur_q.x;
 		if (RR.total > MAX_SLOTS || nq > (uint32_t)WAVE || (SELF && (cur_q.y - RR.d_self) > 2u * WAVE)) {
-			// not for this tier: append the cell to the next tier's worklist
-			if (lane == 0) reject_list[atomicAdd(reject_count, 1u)] = make_uint2(p0, key);
+			// not for this tier: goes to the next tier's worklist.  Collected one entry per lane and appended 64 at a time: the
+			// worklist length is ONE counter, and e.g. a dense column of fluid sends most of its cells here.
+			if ((uint32_t)lane == rej_n) rej = make_uint2(p0, key);
+			if (++rej_n == (uint32_t)WAVE) { flush_rejects(); rej_n = 0; }
 		}
 		else if (RR.total == 0u) {
 			// no candidate at all (set_j is another, sparser or empty set): nq empty records, one int each
@@ -725,6 +754,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 		key = key_next; p0 = p0_next;
 		first_next = first_next2;
 	}
+	if (rej_n) flush_rejects();
 	if (lane == 0 && wave_hits) atomicAdd(a.hit_total, (unsigned long long)wave_hits);
 }
 
