@@ -167,6 +167,17 @@ tnsx_status tnsx_apply_zsort(tnsx_context* ctx, int set_i, void* data, size_t el
 /* ---- introspection ------------------------------------------------------------------------------- */
 tnsx_status tnsx_get_stats(const tnsx_context* ctx, tnsx_stats* out);
 
+/* ---- multi-GPU support (no counterpart in the single-process reference) ----------------------
+ * Ghost-halo selection for a slab decomposition along x: packs every point with x < left_cut into out_left and every
+ * point with x >= right_cut into out_right (either may be NULL = side not wanted), as rows of `5 + (radii != NULL)`
+ * floats: x, y, z, [r,] and the point's 64-bit global id bit-cast into the last two floats.  All pointers are device
+ * memory; rows are appended in no particular order.  counts_dev[0..1] receive the number of rows the selection HAS (they
+ * may exceed capacity_rows: then only capacity_rows rows were written and the caller repeats with larger buffers).
+ * Enqueued on the context's stream; returns without waiting. */
+tnsx_status tnsx_halo_pack(tnsx_context* ctx, const float* xyz, const float* radii, const long long* global_ids, int n_points,
+                           float left_cut, float right_cut, float* out_left, float* out_right, unsigned long long capacity_rows,
+                           unsigned int* counts_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -213,3 +213,37 @@ def test_cpp_dropin_scenarios(built_library, tmp_path):
     print(out.stdout[-3000:])
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "FAILED" not in out.stdout and "ALL PASSED" in out.stdout
+
+
+def test_halo_pack_kernel_matches_torch_selection():
+    """tnsx_halo_pack (multi-GPU ghost selection): same rows as the torch compare / nonzero / index_select chain, as sets;
+    too small buffers report the needed size instead of overflowing."""
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd.multi import SlabExchange
+    n = 300_000
+    g = torch.Generator().manual_seed(5)
+    pts = torch.rand((n, 3), generator=g).cuda()
+    pts[:, 0] += 3.0                                             # slab [3, 4)
+    radii = (torch.rand(n, generator=g) * 0.01 + 0.01).cuda()
+    gids = (torch.arange(n, dtype=torch.int64) * 7919 + (1 << 40)).cuda()   # ids that need all 64 bits
+    ns = T.TreeNSearch()
+    for r in (None, radii):
+        cols = 5 if r is None else 6
+        lcut, rcut = 3.0 + 0.02, 4.0 - 0.02
+        ex = SlabExchange(3.0, 4.0, 0.02, packer=ns)
+        sl, sr = ex._pack_device(pts, gids, r, True, True, cols - 1)
+        for got, mask in ((sl, pts[:, 0] < lcut), (sr, pts[:, 0] >= rcut)):
+            sel = torch.nonzero(mask).squeeze(1)
+            assert got.shape == (sel.numel(), cols)
+            got_ids = got[:, cols - 2:cols].contiguous().view(torch.int64).view(-1)
+            order = torch.argsort(got_ids)
+            assert torch.equal(got_ids[order], gids[sel])         # gids ascend with the index
+            assert torch.equal(got[order, 0:3], pts[sel])
+            if r is not None:
+                assert torch.equal(got[order, 3], r[sel])
+        # one side only, and a buffer that is too small at first (the exchange grows it and repeats)
+        ex2 = SlabExchange(3.0, 4.0, 0.25, packer=ns)
+        ex2._send_buf = [None, torch.empty((16, cols), dtype=torch.float32, device="cuda")]
+        l2, r2 = ex2._pack_device(pts, gids, r, False, True, cols - 1)
+        assert l2 is None and r2.shape[0] == int((pts[:, 0] >= 4.0 - 0.25).sum())

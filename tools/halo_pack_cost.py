@@ -29,3 +29,12 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): m = step()
 torch.cuda.synchronize()
 print(f"torch halo select+pack: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per step, {m} halo points")
+
+import treensearch_amd as T
+from treensearch_amd.multi import SlabExchange
+ex = SlabExchange(0.0, 1.0, halo, packer=T.TreeNSearch(stream=torch.cuda.current_stream().cuda_stream))
+for _ in range(3): ex._pack_device(pts, gids, None, True, True, 4)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(20): a, b = ex._pack_device(pts, gids, None, True, True, 4)
+torch.cuda.synchronize()
+print(f"tnsx_halo_pack kernel : {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per step, {a.shape[0] + b.shape[0]} halo points")

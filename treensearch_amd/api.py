@@ -71,7 +71,7 @@ ABI_SYMBOLS = [
     "tnsx_get_n_sets", "tnsx_get_n_points_in_set", "tnsx_get_total_n_points", "tnsx_is_search_active",
     "tnsx_does_set_exist", "tnsx_get_neighborlist_n_bytes",
     "tnsx_run", "tnsx_get_pair_view", "tnsx_mirror_pair_to_host", "tnsx_copy_pair",
-    "tnsx_prepare_zsort", "tnsx_get_zsort_order", "tnsx_apply_zsort", "tnsx_get_stats",
+    "tnsx_prepare_zsort", "tnsx_get_zsort_order", "tnsx_apply_zsort", "tnsx_get_stats", "tnsx_halo_pack",
 ]
 
 _lib = None
@@ -100,6 +100,7 @@ def load_library():
     L.tnsx_destroy.restype = None
     L.tnsx_last_error.argtypes = [vp]
     L.tnsx_last_error.restype = C.c_char_p
+    L.tnsx_halo_pack.argtypes = [vp, vp, vp, vp, ci, C.c_float, C.c_float, vp, vp, C.c_ulonglong, vp]
     L.tnsx_add_point_set.argtypes = [vp, vp, vp, ci, C.c_uint]
     L.tnsx_resize_point_set.argtypes = [vp, ci, vp, vp, ci, C.c_uint]
     L.tnsx_set_search_radius.argtypes = [vp, C.c_float]
@@ -309,6 +310,16 @@ class TreeNSearch:
         st = Stats()
         self._check(self._L.tnsx_get_stats(self._h, C.byref(st)))
         return st.as_dict()
+
+    # ------------------------------------------------------------------ multi-GPU support
+    def halo_pack(self, pts, gids, radii, left_cut, right_cut, out_left, out_right, counts) -> None:
+        """tnsx_halo_pack on device tensors (torch, CUDA): selects the points with x < left_cut / x >= right_cut and appends
+        them as rows [x, y, z, (r,) gid_lo, gid_hi] to out_left / out_right (None = side not wanted); counts (uint32[2] or
+        int32[2] tensor) receives the number of selected points per side.  Asynchronous on the engine's stream."""
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        cap = min(t.shape[0] for t in (out_left, out_right) if t is not None) if (out_left is not None or out_right is not None) else 0
+        self._check(self._L.tnsx_halo_pack(self._h, ptr(pts), ptr(radii), ptr(gids), int(pts.shape[0]), float(left_cut), float(right_cut),
+                                           ptr(out_left), ptr(out_right), int(cap), ptr(counts)))
 
     def print_state(self) -> None:
         for k, v in self.get_stats().items():

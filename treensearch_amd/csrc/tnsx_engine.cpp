@@ -920,6 +920,18 @@ tnsx_status tnsx_apply_zsort(tnsx_context* c, int set_i, void* data, size_t elem
 	return TNSX_OK;
 }
 
+tnsx_status tnsx_halo_pack(tnsx_context* c, const float* xyz, const float* radii, const long long* global_ids, int n_points, float left_cut,
+                           float right_cut, float* out_left, float* out_right, unsigned long long capacity_rows, unsigned int* counts_dev)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	if (n_points < 0 || !counts_dev || (n_points > 0 && (!xyz || !global_ids))) TNSX_FAIL(c, TNSX_ERR_INVALID, "tnsx_halo_pack: null pointer or negative size");
+	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
+	HIPCHK(c, hipMemsetAsync(counts_dev, 0, 2 * sizeof(unsigned int), c->stream));
+	tnsx::launch_halo_pack(xyz, radii, global_ids, n_points, left_cut, right_cut, out_left, out_right, capacity_rows, counts_dev, c->stream);
+	HIPCHK(c, hipGetLastError());
+	return TNSX_OK;
+}
+
 tnsx_status tnsx_get_stats(const tnsx_context* c, tnsx_stats* out)
 {
 	if (!c || !out) return TNSX_ERR_INVALID;

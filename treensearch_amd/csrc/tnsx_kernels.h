@@ -97,6 +97,10 @@ struct QueryConfig {
 };
 void launch_query(const QueryArgs& a, const QueryConfig& c, int n_compute_units, hipStream_t s);
 
+// ---- ghost-halo selection of a slab decomposition along x (tnsx_kernels.hip); counts[2] must be zeroed before
+void launch_halo_pack(const float* xyz, const float* radii, const long long* gids, int n, float left_cut, float right_cut, float* out_left,
+                      float* out_right, unsigned long long capacity_rows, unsigned int* counts, hipStream_t s);
+
 // ---- permutation of byte records: out[new] = in[perm[new]] ------------------------------------------
 void launch_permute_bytes(const void* in, void* out, const int* new_to_old, int n, size_t rec_bytes, hipStream_t s);
 

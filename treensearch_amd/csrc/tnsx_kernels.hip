@@ -391,4 +391,67 @@ void launch_permute_bytes(const void* in, void* out, const int* new_to_old, int 
 	}
 }
 
+// =====================================================================================================
+// ghost-halo selection (multi-GPU slabs): one pass over x, wave-aggregated append to the two send buffers
+// =====================================================================================================
+// One workgroup per tile of 4096 points and ONE atomic per workgroup and side (a single counter takes ~88 atomics per
+// microsecond; per-wave appends would cost 1.8 ms at 10 M points).
+static constexpr int HP_ITEMS = 16;
+template <bool WITH_R>
+__global__ void __launch_bounds__(256) k_halo_pack(const float* __restrict__ xyz, const float* __restrict__ radii, const long long* __restrict__ gids, int n,
+                                                   float left_cut, float right_cut, float* __restrict__ out_left, float* __restrict__ out_right,
+                                                   unsigned long long capacity, unsigned int* __restrict__ counts)
+{
+	constexpr int COLS = WITH_R ? 6 : 5;
+	__shared__ uint32_t wcnt[2][HP_ITEMS * 4];   // [side][round * 4 + wave] -> exclusive prefix inside the tile
+	__shared__ uint32_t bbase[2];
+	const int w = threadIdx.x / WAVE;
+	const size_t base = (size_t)blockIdx.x * (256 * HP_ITEMS);
+	uint32_t flags = 0;   // bit 2i: point i goes left, bit 2i+1: right
+	#pragma unroll
+	for (int i = 0; i < HP_ITEMS; i++) {
+		const size_t p = base + (size_t)i * 256 + threadIdx.x;
+		const float x = p < (size_t)n ? xyz[3 * p] : 0.0f;
+		const bool tl = out_left != nullptr && p < (size_t)n && x < left_cut;
+		const bool tr = out_right != nullptr && p < (size_t)n && x >= right_cut;
+		flags |= (tl ? 1u : 0u) << (2 * i) | (tr ? 2u : 0u) << (2 * i);
+		const uint64_t ml = __ballot(tl), mr = __ballot(tr);
+		if (lane_id() == 0) { wcnt[0][i * 4 + w] = (uint32_t)__popcll(ml); wcnt[1][i * 4 + w] = (uint32_t)__popcll(mr); }
+	}
+	__syncthreads();
+	if (threadIdx.x < 2) {
+		const int side = threadIdx.x;
+		uint32_t s = 0;
+		for (int q = 0; q < HP_ITEMS * 4; q++) { const uint32_t t = wcnt[side][q]; wcnt[side][q] = s; s += t; }
+		bbase[side] = s ? atomicAdd(counts + side, s) : 0u;
+	}
+	__syncthreads();
+	#pragma unroll
+	for (int i = 0; i < HP_ITEMS; i++) {
+		const size_t p = base + (size_t)i * 256 + threadIdx.x;
+		#pragma unroll
+		for (int side = 0; side < 2; side++) {
+			const bool take = (flags >> (2 * i + side)) & 1u;
+			const uint64_t m = __ballot(take);
+			const unsigned long long row = (unsigned long long)bbase[side] + wcnt[side][i * 4 + w] + mbcnt64(m);
+			if (take && row < capacity) {
+				float* o = (side == 0 ? out_left : out_right) + row * COLS;
+				o[0] = xyz[3 * p]; o[1] = xyz[3 * p + 1]; o[2] = xyz[3 * p + 2];
+				if (WITH_R) o[3] = radii[p];
+				const long long g = gids[p];
+				o[COLS - 2] = __uint_as_float((uint32_t)g);
+				o[COLS - 1] = __uint_as_float((uint32_t)((unsigned long long)g >> 32));
+			}
+		}
+	}
+}
+void launch_halo_pack(const float* xyz, const float* radii, const long long* gids, int n, float left_cut, float right_cut, float* out_left,
+                      float* out_right, unsigned long long capacity_rows, unsigned int* counts, hipStream_t s)
+{
+	if (n <= 0 || (!out_left && !out_right)) return;
+	const dim3 grid((n + 256 * HP_ITEMS - 1) / (256 * HP_ITEMS)), block(256);
+	if (radii) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_halo_pack<true>), grid, block, 0, s, xyz, radii, gids, n, left_cut, right_cut, out_left, out_right, capacity_rows, counts);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_halo_pack<false>), grid, block, 0, s, xyz, radii, gids, n, left_cut, right_cut, out_left, out_right, capacity_rows, counts);
+}
+
 }  // namespace tnsx

