@@ -171,12 +171,13 @@ tnsx_status tnsx_get_stats(const tnsx_context* ctx, tnsx_stats* out);
  * Ghost-halo selection for a slab decomposition along x: packs every point with x < left_cut into out_left and every
  * point with x >= right_cut into out_right (either may be NULL = side not wanted), as rows of `5 + (radii != NULL)`
  * floats: x, y, z, [r,] and the point's 64-bit global id bit-cast into the last two floats.  All pointers are device
- * memory; rows are appended in no particular order.  counts_dev[0..1] receive the number of rows the selection HAS (they
- * may exceed capacity_rows: then only capacity_rows rows were written and the caller repeats with larger buffers).
- * Enqueued on the context's stream; returns without waiting. */
+ * memory; rows are appended in no particular order.  counts_dev[0..1] (device scratch) and counts_host[0..1] receive the
+ * number of rows the selection HAS (they may exceed capacity_rows: then only capacity_rows rows were written and the
+ * caller repeats with larger buffers).  Runs on the context's stream; with counts_host != NULL the call waits for it, with
+ * NULL it only enqueues.  Like tnsx_run, it does not wait for work other streams still have in flight on its inputs. */
 tnsx_status tnsx_halo_pack(tnsx_context* ctx, const float* xyz, const float* radii, const long long* global_ids, int n_points,
                            float left_cut, float right_cut, float* out_left, float* out_right, unsigned long long capacity_rows,
-                           unsigned int* counts_dev);
+                           unsigned int* counts_dev, unsigned int* counts_host);
 
 #ifdef __cplusplus
 }

@@ -55,8 +55,15 @@ def _worker(rank, world, port, n_per_rank, radius, tmpdir):
         gids = torch.arange(rank * n_per_rank, (rank + 1) * n_per_rank, dtype=torch.int64)
         slab = SlabSearch(float(rank), float(rank + 1), float(radius), OracleEngine)
         t_pts = torch.from_numpy(pts)
-        for step in range(2):                              # second step exercises the resize path
+        rounds = []
+        for step in range(4):                              # step 0: two rounds (no capacity agreed yet); step 1: one round;
+            if step == 2:                                  # step 2: twice the halo => overflow => two rounds again; step 3: back to the
+                slab.ex.halo *= 2.0                        # original halo, one round (the capacity only grows)
+            if step == 3:
+                slab.ex.halo /= 2.0
             slab.step(t_pts, gids)
+            rounds.append(slab.ex.rounds_last)
+        assert rounds == [2, 1, 2, 1], rounds
         offs, nbr = slab.global_neighbors()
         np.save(os.path.join(tmpdir, f"offs_{rank}.npy"), offs)
         np.save(os.path.join(tmpdir, f"nbr_{rank}.npy"), nbr)

@@ -233,7 +233,7 @@ def test_halo_pack_kernel_matches_torch_selection():
         lcut, rcut = 3.0 + 0.02, 4.0 - 0.02
         ex = SlabExchange(3.0, 4.0, 0.02, packer=ns)
         sl, sr = ex._pack_device(pts, gids, r, True, True, cols - 1)
-        for got, mask in ((sl, pts[:, 0] < lcut), (sr, pts[:, 0] >= rcut)):
+        for got, mask in ((sl[1:], pts[:, 0] < lcut), (sr[1:], pts[:, 0] >= rcut)):   # row 0 is the message header
             sel = torch.nonzero(mask).squeeze(1)
             assert got.shape == (sel.numel(), cols)
             got_ids = got[:, cols - 2:cols].contiguous().view(torch.int64).view(-1)
@@ -246,4 +246,4 @@ def test_halo_pack_kernel_matches_torch_selection():
         ex2 = SlabExchange(3.0, 4.0, 0.25, packer=ns)
         ex2._send_buf = [None, torch.empty((16, cols), dtype=torch.float32, device="cuda")]
         l2, r2 = ex2._pack_device(pts, gids, r, False, True, cols - 1)
-        assert l2 is None and r2.shape[0] == int((pts[:, 0] >= 4.0 - 0.25).sum())
+        assert l2 is None and r2.shape[0] - 1 == int((pts[:, 0] >= 4.0 - 0.25).sum())

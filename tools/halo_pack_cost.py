@@ -37,4 +37,4 @@ for _ in range(3): ex._pack_device(pts, gids, None, True, True, 4)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): a, b = ex._pack_device(pts, gids, None, True, True, 4)
 torch.cuda.synchronize()
-print(f"tnsx_halo_pack kernel : {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per step, {a.shape[0] + b.shape[0]} halo points")
+print(f"tnsx_halo_pack kernel : {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per step, {a.shape[0] + b.shape[0] - 2} halo points")

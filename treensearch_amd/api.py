@@ -100,7 +100,7 @@ def load_library():
     L.tnsx_destroy.restype = None
     L.tnsx_last_error.argtypes = [vp]
     L.tnsx_last_error.restype = C.c_char_p
-    L.tnsx_halo_pack.argtypes = [vp, vp, vp, vp, ci, C.c_float, C.c_float, vp, vp, C.c_ulonglong, vp]
+    L.tnsx_halo_pack.argtypes = [vp, vp, vp, vp, ci, C.c_float, C.c_float, vp, vp, C.c_ulonglong, vp, C.POINTER(C.c_uint)]
     L.tnsx_add_point_set.argtypes = [vp, vp, vp, ci, C.c_uint]
     L.tnsx_resize_point_set.argtypes = [vp, ci, vp, vp, ci, C.c_uint]
     L.tnsx_set_search_radius.argtypes = [vp, C.c_float]
@@ -196,6 +196,7 @@ class TreeNSearch:
         self._keep = {}
         self._views = {}
         self._n_threads = -1
+        self._own_stream = not stream          # the engine then runs on a stream of its own (non-blocking)
 
     def __del__(self):
         try:
@@ -253,8 +254,17 @@ class TreeNSearch:
     def set_arithmetic(self, arith: int) -> None:
         self._check(self._L.tnsx_set_arithmetic(self._h, int(arith)))
 
+    def _wait_for_producers(self) -> None:
+        """Device inputs are read on the engine's stream.  When that is the engine's own stream, work that torch has queued on
+        ITS current stream (position updates, ghost copies, NCCL receives) is not ordered before it -- wait for it.  With a
+        caller-supplied stream everything is in stream order and nothing is waited for."""
+        if self._own_stream and any(_is_torch(k) and k.is_cuda for pair in self._keep.values() for k in pair if k is not None):
+            import torch
+            torch.cuda.current_stream().synchronize()
+
     def run(self) -> None:
         self._views = {}
+        self._wait_for_producers()
         self._check(self._L.tnsx_run(self._h))
 
     def run_scalar(self) -> None:
@@ -312,14 +322,20 @@ class TreeNSearch:
         return st.as_dict()
 
     # ------------------------------------------------------------------ multi-GPU support
-    def halo_pack(self, pts, gids, radii, left_cut, right_cut, out_left, out_right, counts) -> None:
+    def halo_pack(self, pts, gids, radii, left_cut, right_cut, out_left, out_right, counts):
         """tnsx_halo_pack on device tensors (torch, CUDA): selects the points with x < left_cut / x >= right_cut and appends
-        them as rows [x, y, z, (r,) gid_lo, gid_hi] to out_left / out_right (None = side not wanted); counts (uint32[2] or
-        int32[2] tensor) receives the number of selected points per side.  Asynchronous on the engine's stream."""
+        them as rows [x, y, z, (r,) gid_lo, gid_hi] to out_left / out_right (None = side not wanted).  counts is a 2-element
+        int32 scratch tensor on the device.  Returns (n_left, n_right), the number of selected points per side (may exceed
+        the buffers: then only the first rows were written); the call has completed when it returns."""
+        if self._own_stream:
+            import torch
+            torch.cuda.current_stream().synchronize()
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         cap = min(t.shape[0] for t in (out_left, out_right) if t is not None) if (out_left is not None or out_right is not None) else 0
+        host = (C.c_uint * 2)()
         self._check(self._L.tnsx_halo_pack(self._h, ptr(pts), ptr(radii), ptr(gids), int(pts.shape[0]), float(left_cut), float(right_cut),
-                                           ptr(out_left), ptr(out_right), int(cap), ptr(counts)))
+                                           ptr(out_left), ptr(out_right), int(cap), ptr(counts), host))
+        return int(host[0]), int(host[1])
 
     def print_state(self) -> None:
         for k, v in self.get_stats().items():
@@ -377,6 +393,7 @@ class TreeNSearch:
 
     # ------------------------------------------------------------------ zsort
     def prepare_zsort(self) -> None:
+        self._wait_for_producers()
         self._check(self._L.tnsx_prepare_zsort(self._h))
 
     def get_zsort_order(self, set_i: int) -> np.ndarray:
@@ -391,6 +408,9 @@ class TreeNSearch:
         if _is_torch(data):
             if not data.is_contiguous():
                 raise ValueError("tensor must be contiguous")
+            if data.is_cuda and self._own_stream:
+                import torch
+                torch.cuda.current_stream().synchronize()
             self._check(self._L.tnsx_apply_zsort(self._h, int(set_i), data.data_ptr(), data.element_size(), int(stride),
                                                  1 if data.is_cuda else 0))
         else:

@@ -921,7 +921,8 @@ tnsx_status tnsx_apply_zsort(tnsx_context* c, int set_i, void* data, size_t elem
 }
 
 tnsx_status tnsx_halo_pack(tnsx_context* c, const float* xyz, const float* radii, const long long* global_ids, int n_points, float left_cut,
-                           float right_cut, float* out_left, float* out_right, unsigned long long capacity_rows, unsigned int* counts_dev)
+                           float right_cut, float* out_left, float* out_right, unsigned long long capacity_rows, unsigned int* counts_dev,
+                           unsigned int* counts_host)
 {
 	if (!c) return TNSX_ERR_INVALID;
 	if (n_points < 0 || !counts_dev || (n_points > 0 && (!xyz || !global_ids))) TNSX_FAIL(c, TNSX_ERR_INVALID, "tnsx_halo_pack: null pointer or negative size");
@@ -929,6 +930,13 @@ tnsx_status tnsx_halo_pack(tnsx_context* c, const float* xyz, const float* radii
 	HIPCHK(c, hipMemsetAsync(counts_dev, 0, 2 * sizeof(unsigned int), c->stream));
 	tnsx::launch_halo_pack(xyz, radii, global_ids, n_points, left_cut, right_cut, out_left, out_right, capacity_rows, counts_dev, c->stream);
 	HIPCHK(c, hipGetLastError());
+	if (counts_host) {
+		HIPCHK(c, c->h_small.reserve(64));
+		HIPCHK(c, hipMemcpyAsync(c->h_small.p, counts_dev, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		counts_host[0] = c->h_small.as<unsigned int>()[0];
+		counts_host[1] = c->h_small.as<unsigned int>()[1];
+	}
 	return TNSX_OK;
 }
 

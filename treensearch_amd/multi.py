@@ -40,46 +40,63 @@ class SlabExchange:
         self.packer = packer if hasattr(packer, "halo_pack") else None
         self._send_buf = [None, None]
         self._counts = None
+        self._caps = {}          # peer -> (rows I may send, rows it may send) agreed for the one-round exchange
+        self.rounds_last = 0
+
+    @staticmethod
+    def _capacity(count: int) -> int:
+        return count + count // 4 + 256
 
     def _pack_device(self, pts, gids, radii, has_l, has_r, cols):
-        """Both sides in one kernel launch; buffers are reused from step to step and grown when the selection does not fit."""
+        """Both sides in one kernel launch.  The rows land behind one header row of buffers that are reused from step to step
+        (grown when the selection, or the capacity agreed with the peer, does not fit), so the message of the one-round
+        exchange is a plain prefix of the buffer."""
         dev = pts.device
         if self._counts is None or self._counts.device != dev:
             self._counts = torch.zeros(2, dtype=torch.int32, device=dev)
         n = int(pts.shape[0])
+        peers = (self.rank - 1, self.rank + 1)
         while True:
             for side, want in enumerate((has_l, has_r)):
-                if want and (self._send_buf[side] is None or self._send_buf[side].shape[1] != cols + 1 or self._send_buf[side].device != dev):
-                    self._send_buf[side] = torch.empty((max(n // 32, 1024), cols + 1), dtype=torch.float32, device=dev)
-            bl = self._send_buf[0] if has_l else None
-            br = self._send_buf[1] if has_r else None
-            self.packer.halo_pack(pts, gids, radii, self.lo + self.halo, self.hi - self.halo, bl, br, self._counts)
-            cl, cr = (int(v) for v in self._counts.tolist())          # one small D2H: the message sizes are needed on the host anyway
+                need = max(n // 32, 1024, self._caps.get(peers[side], (0, 0))[0]) + 1
+                b = self._send_buf[side]
+                if want and (b is None or b.shape[1] != cols + 1 or b.device != dev or b.shape[0] < need):
+                    self._send_buf[side] = torch.empty((need, cols + 1), dtype=torch.float32, device=dev)
+            bl = self._send_buf[0][1:] if has_l else None
+            br = self._send_buf[1][1:] if has_r else None
+            cl, cr = self.packer.halo_pack(pts, gids, radii, self.lo + self.halo, self.hi - self.halo, bl, br, self._counts)
             grown = False
             for side, (want, c) in enumerate(((has_l, cl), (has_r, cr))):
-                if want and c > self._send_buf[side].shape[0]:
+                if want and c + 1 > self._send_buf[side].shape[0]:
                     self._send_buf[side] = torch.empty((c + c // 8 + 1024, cols + 1), dtype=torch.float32, device=dev)
                     grown = True
             if not grown:
-                return (bl[:cl] if has_l else None), (br[:cr] if has_r else None)
+                return (self._send_buf[0][:cl + 1] if has_l else None), (self._send_buf[1][:cr + 1] if has_r else None)
 
     def exchange(self, pts: torch.Tensor, gids: torch.Tensor, radii: Optional[torch.Tensor] = None):
         """pts (n,3) float32, gids (n,) int64 global ids, radii (n,) float32 or None.
-        -> (ghost_pts (m,3), ghost_gids (m,), ghost_radii (m,) or None)"""
+        -> (ghost_pts (m,3), ghost_gids (m,), ghost_radii (m,) or None)
+
+        Wire format per neighbour and step: ONE message of `capacity + 1` rows of W floats -- row 0 carries the row count
+        (int32 bits), rows 1..count the points [x, y, z, (r,) gid_lo, gid_hi].  `capacity` is what both sides derived from
+        the previous step's count (grow-only, +25 %); the very first step, and a step whose selection outgrows the capacity,
+        add a second round with the exact size.  Both directions of a link apply the same rule to the same numbers, so
+        sender and receiver always agree on the message size."""
         dev = pts.device
         has_l, has_r = self.rank > 0, self.rank < self.world - 1
         cols = 4 if radii is None else 5
-        # payload rows: x, y, z, [r], and the 64-bit global id bit-cast into two float32 columns
-        def pack(mask):
+        W = cols + 1
+
+        def pack(mask):   # torch path (CPU tensors / no engine): header row + payload rows
             sel = torch.nonzero(mask, as_tuple=False).squeeze(1)
-            out = torch.empty((sel.numel(), cols + 1), dtype=torch.float32, device=dev)
-            out[:, 0:3] = pts.index_select(0, sel)
+            out = torch.empty((sel.numel() + 1, W), dtype=torch.float32, device=dev)
+            out[1:, 0:3] = pts.index_select(0, sel)
             if radii is not None:
-                out[:, 3] = radii.index_select(0, sel)
-            out[:, cols - 1:cols + 1] = gids.index_select(0, sel).view(-1, 1).view(torch.float32).view(-1, 2)
+                out[1:, 3] = radii.index_select(0, sel)
+            out[1:, cols - 1:cols + 1] = gids.index_select(0, sel).view(-1, 1).view(torch.float32).view(-1, 2)
             return out
 
-        send = {}
+        send = {}   # peer -> (count + 1, W) tensor, row 0 = header (possibly a prefix of a larger buffer)
         if self.packer is not None and pts.is_cuda and (has_l or has_r):
             sl, sr = self._pack_device(pts, gids, radii, has_l, has_r, cols)
             if has_l:
@@ -92,32 +109,47 @@ class SlabExchange:
             if has_r:
                 send[self.rank + 1] = pack(pts[:, 0] >= (self.hi - self.halo))
         peers = sorted(send.keys())
-        # 1) counts
-        cnt_out = {p: torch.tensor([send[p].shape[0]], dtype=torch.int64, device=dev) for p in peers}
-        cnt_in = {p: torch.zeros(1, dtype=torch.int64, device=dev) for p in peers}
-        ops = []
+        n_out = {p: int(send[p].shape[0]) - 1 for p in peers}
         for p in peers:
-            ops.append(dist.P2POp(dist.isend, cnt_out[p], p, self.group))
-            ops.append(dist.P2POp(dist.irecv, cnt_in[p], p, self.group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        # 2) payload
-        recv = {p: torch.empty((int(cnt_in[p].item()), cols + 1), dtype=torch.float32, device=dev) for p in peers}
-        ops = []
+            send[p].view(torch.int32)[0, 0] = n_out[p]
+
+        def round_trip(out_msgs, in_msgs):
+            ops = []
+            for p in peers:
+                if p in out_msgs:
+                    ops.append(dist.P2POp(dist.isend, out_msgs[p], p, self.group))
+                    self.bytes_sent += out_msgs[p].numel() * 4
+                if p in in_msgs:
+                    ops.append(dist.P2POp(dist.irecv, in_msgs[p], p, self.group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+
+        # ---- round 1: header + as many rows as the agreed capacity holds (capacity 0 before the first exchange)
+        out1, in1 = {}, {}
         for p in peers:
-            if send[p].numel():
-                ops.append(dist.P2POp(dist.isend, send[p], p, self.group))
-                self.bytes_sent += send[p].numel() * 4
-            if recv[p].numel():
-                ops.append(dist.P2POp(dist.irecv, recv[p], p, self.group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        if peers:
-            g = torch.cat([recv[p] for p in peers], dim=0)
-        else:
-            g = torch.empty((0, cols + 1), dtype=torch.float32, device=dev)
+            cs, cr = self._caps.get(p, (0, 0))
+            k = min(n_out[p], cs)
+            if send[p].shape[0] >= cs + 1:
+                out1[p] = send[p][:cs + 1]                     # a prefix of the (larger) pack buffer: no copy
+            else:
+                out1[p] = torch.empty((cs + 1, W), dtype=torch.float32, device=dev)
+                out1[p][:k + 1] = send[p][:k + 1]
+            in1[p] = torch.empty((cr + 1, W), dtype=torch.float32, device=dev)
+        round_trip(out1, in1)
+        n_in = {p: int(in1[p].view(torch.int32)[0, 0].item()) for p in peers}
+        # ---- round 2 (first step / overflow only): the full payload, now that both sides know the count
+        out2 = {p: send[p][1:] for p in peers if n_out[p] > self._caps.get(p, (0, 0))[0]}
+        in2 = {p: torch.empty((n_in[p], W), dtype=torch.float32, device=dev) for p in peers if n_in[p] > self._caps.get(p, (0, 0))[1]}
+        if out2 or in2:
+            round_trip(out2, in2)
+        recv = []
+        for p in peers:
+            cs, cr = self._caps.get(p, (0, 0))
+            recv.append(in2[p] if p in in2 else in1[p][1:1 + n_in[p]])
+            self._caps[p] = (max(cs, self._capacity(n_out[p])) if n_out[p] > cs else cs, max(cr, self._capacity(n_in[p])) if n_in[p] > cr else cr)
+        self.rounds_last = 2 if (out2 or in2) else (1 if peers else 0)
+        g = torch.cat(recv, dim=0) if recv else torch.empty((0, W), dtype=torch.float32, device=dev)
         ghost_pts = g[:, 0:3].contiguous()
         ghost_r = g[:, 3].contiguous() if radii is not None else None
         # (clone, not contiguous(): an EMPTY slice counts as contiguous and keeps its odd storage offset, which int64 cannot view)
