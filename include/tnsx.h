@@ -68,10 +68,11 @@ typedef struct tnsx_options {
 	int mirror_to_host;       /* 1: tnsx_run also mirrors every active pair's lists into pinned host memory
 	                             (what get_neighborlist needs for CPU consumers); 0: lists stay in HBM */
 	int collect_stage_times;  /* 1: record hipEvents around every stage (tnsx_get_stats) */
-	int exact_layout;         /* 0 (default): once a pair has run, its lists are built in ONE pass into a record pool
-	                             (per-wave slabs from a device cursor; records exact and contiguous, order of records in
-	                             memory unspecified, pool has unused gaps).  1: always count -> scan -> fill, records laid
-	                             out in spatially sorted point order without gaps (deterministic, ~1.6x more query work) */
+	int exact_layout;         /* 0 (default): the lists of a pair are built in ONE pass into a record pool sized from the
+	                             previous run (per-wave slabs from a device cursor; records exact and contiguous, order of
+	                             records in memory unspecified, pool has unused gaps; the first run of a pair adds a dry,
+	                             count-only pass).  1: always count -> scan -> fill, records laid out in spatially sorted
+	                             point order without gaps (deterministic, ~2x more query work) */
 	uint64_t max_dense_cells; /* upper bound of the dense cell table (8 bytes per cell and point set); 0 = default = maximum (2^30) */
 	int reserved[7];
 } tnsx_options;

@@ -81,23 +81,27 @@ def test_coarsened_grid_still_exact(oracle):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# single-pass pool mode: from the second run() on, every pair is built in one pass into a record pool
+# single-pass pool mode (default): every pair is built in one pass into a record pool that is sized from the previous run;
+# the first run of a pair makes a dry (count-only) pass first.  exact_layout=1 selects count -> scan -> fill instead.
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("case", SMALL, ids=[c.name for c in SMALL])
 @pytest.mark.parametrize("mode", [0, 1], ids=["strict", "contracted"])
 def test_pool_mode_matches_golden(case, mode, oracle):
+    ns_exact = P.make_engine(case, mode, exact_layout=True)
+    ns_exact.run()                # count -> scan -> fill (general kernel)
+    assert ns_exact.get_stats()["n_pool_pairs"] == 0
+    exact = {pr: ns_exact.neighbor_csr(*pr) for pr in case.active}
+    P.assert_matches_golden(exact, load_golden(case.name), mode, oracle, case.name + " (exact layout)")
     ns = P.make_engine(case, mode)
-    ns.run()                      # exact two-pass layout, sizes the pools
-    first = {pr: ns.neighbor_csr(*pr) for pr in case.active}
-    ns.run()                      # pool mode
-    st = ns.get_stats()
     n_nonempty = sum(1 for (i, j) in case.active if len(case.points[i]) > 0)
-    assert st["n_pool_pairs"] == n_nonempty and st["pool_retries"] == 0
-    res = {pr: ns.neighbor_csr(*pr) for pr in case.active}
-    for pr in case.active:
-        P.assert_same_csr(res[pr], first[pr], f"{case.name} {pr} pool-vs-exact")
-    P.assert_matches_golden(res, load_golden(case.name), mode, oracle, case.name + " (pool)")
-    assert st["n_neighbors"] == sum(int(first[pr][0][-1]) for pr in case.active)
+    for step in range(2):         # step 0: dry pass + sized pass, step 1: one pass
+        ns.run()
+        st = ns.get_stats()
+        assert st["n_pool_pairs"] == n_nonempty and st["pool_retries"] == 0
+        res = {pr: ns.neighbor_csr(*pr) for pr in case.active}
+        for pr in case.active:
+            P.assert_same_csr(res[pr], exact[pr], f"{case.name} {pr} pool (run {step}) vs exact layout")
+        assert st["n_neighbors"] == sum(int(exact[pr][0][-1]) for pr in case.active)
 
 
 def test_pool_overflow_is_detected_and_repaired(oracle):

@@ -46,7 +46,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
-        extra = os.environ.get("TNSX_EXTRA_FLAGS", "").split()     # experiments, e.g. -DTNSX_F4_LAYOUT=1
+        extra = os.environ.get("TNSX_EXTRA_FLAGS", "").split()     # experiments, e.g. -DTNSX_FAST_WAVES_PER_EU=5
         cmd = [hipcc()] + FLAGS + extra + ["-I" + os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

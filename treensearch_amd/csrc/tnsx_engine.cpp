@@ -101,6 +101,7 @@ struct PairResult {
 	uint64_t n_neighbors = 0;
 	uint64_t need_hint = 0;      // neighbours + points of the previous run: sizes the pool of the next one
 	uint32_t pool_slab = 16384;
+	bool dry = false;            // this pass only counts (first run of a pair: nothing is known about its size yet)
 	DevBuf counts, offs_sorted, offs_orig, records, heavy, heavy2;
 	PinnedBuf h_offs, h_records;
 	bool mirrored = false;
@@ -595,8 +596,8 @@ tnsx_status tnsx_run(tnsx_context* c)
 	}
 
 	// ---- per active pair: the query.
-	//      pool mode (default once a pair has run before): ONE pass, records bump-allocated from a device cursor;
-	//      exact mode (first run of a pair, overflow, or opt.exact_layout): count -> scan -> fill, CSR in sorted order.
+	//      pool mode (default): ONE pass, records bump-allocated from a device cursor (first run of a pair: a dry pass first);
+	//      exact mode (opt.exact_layout): count -> scan -> fill, gap-free CSR in sorted order.
 	struct Job { int i, j; bool pool; };
 	std::vector<Job> jobs;
 	for (int i = 0; i < n_sets; i++) for (int j = 0; j < n_sets; j++) if (c->active[i][j]) jobs.push_back({ i, j, false });
@@ -629,7 +630,7 @@ tnsx_status tnsx_run(tnsx_context* c)
 		a.n_heavy2 = ctrl_slot(k, tnsx::CTRL_NHEAVY2);
 		a.heavy = pr.heavy.as<uint2>();
 		a.heavy2 = pr.heavy2.as<uint2>();
-		a.pool_capacity = c->debug_nostore ? 0 : pr.records.cap / sizeof(int);
+		a.pool_capacity = (c->debug_nostore || pr.dry) ? 0 : pr.records.cap / sizeof(int);
 		a.pool_slab = pr.pool_slab;
 		return a;
 	};
@@ -653,20 +654,28 @@ tnsx_status tnsx_run(tnsx_context* c)
 		return TNSX_OK;
 	};
 
+	// slab size and record storage of a pool pass that is expected to need `need` ints (0: dry pass)
+	auto size_pool = [&](PairResult& pr, uint64_t need) -> tnsx_status {
+		const uint64_t expect = need + need / 8 + 1024;
+		uint64_t slab = expect / ((uint64_t)query_waves * 8);
+		slab = std::min<uint64_t>(16384, std::max<uint64_t>(256, slab));
+		pr.pool_slab = (uint32_t)slab;
+		HIPCHK(c, pr.records.reserve(need == 0 ? 1024 : (expect + (uint64_t)query_waves * slab * 2) * sizeof(int)));
+		return TNSX_OK;
+	};
 	for (size_t k = 0; k < jobs.size(); k++) {
 		Job& jb = jobs[k];
 		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
 		const int n_i = c->sets[jb.i].n;
 		pr.n_i = n_i;
 		HIPCHK(c, pr.offs_orig.reserve((size_t)std::max(n_i, 1) * sizeof(uint64_t)));
-		jb.pool = !c->opt.exact_layout && pr.need_hint > 0 && n_i > 0;
+		jb.pool = !c->opt.exact_layout && n_i > 0;
 		if (jb.pool) {
-			// capacity: last run's exact need + 12 % + room for every wave's partly used slab
-			const uint64_t expect = pr.need_hint + pr.need_hint / 8 + 1024;
-			uint64_t slab = expect / ((uint64_t)query_waves * 8);
-			slab = std::min<uint64_t>(16384, std::max<uint64_t>(256, slab));
-			pr.pool_slab = (uint32_t)slab;
-			HIPCHK(c, pr.records.reserve((expect + (uint64_t)query_waves * slab * 2) * sizeof(int)));
+			// capacity: last run's exact need + 12 % + room for every wave's partly used slab.  A pair that runs for the first time
+			// makes a DRY pass first (same kernels, capacity 0: everything is counted, nothing is written), which the overflow
+			// handling below turns into a real pass of the right size.
+			pr.dry = pr.need_hint == 0;
+			{ const tnsx_status r = size_pool(pr, pr.need_hint); if (r != TNSX_OK) return r; }
 			// worklists of the cells the fast / fat kernels pass on (at most one entry per occupied cell)
 			const size_t max_cells = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_i, n_cells));
 			HIPCHK(c, pr.heavy.reserve(max_cells * sizeof(uint2)));
@@ -699,14 +708,23 @@ tnsx_status tnsx_run(tnsx_context* c)
 		uint64_t n_neighbors = 0;
 		if (jb.pool) {
 			// pool overflow: the cursor says how much was needed; grow and redo this pair's pass
-			for (int attempt = 0; !c->debug_nostore && h_ctrl[2 * k] > pr.records.cap / sizeof(int); attempt++) {
-				if (attempt >= 4) TNSX_FAIL(c, TNSX_ERR_HIP, "neighbour pool kept overflowing (needed %llu ints)", (unsigned long long)h_ctrl[2 * k]);
-				const uint64_t need = h_ctrl[2 * k];
-				HIPCHK(c, pr.records.reserve((need + need / 8 + (uint64_t)query_waves * pr.pool_slab * 2) * sizeof(int)));
+			for (int attempt = 0; !c->debug_nostore && (pr.dry || h_ctrl[2 * k] > pr.records.cap / sizeof(int)); attempt++) {
+				if (attempt >= 5) TNSX_FAIL(c, TNSX_ERR_HIP, "neighbour pool kept overflowing (needed %llu ints)", (unsigned long long)h_ctrl[2 * k]);
+				if (pr.dry) {
+					// the dry pass counted every neighbour: size the real pass exactly
+					pr.dry = false;
+					const tnsx_status r = size_pool(pr, h_ctrl[2 * k + 1] + (uint64_t)pr.n_i);
+					if (r != TNSX_OK) return r;
+				}
+				else {
+					const uint64_t need = h_ctrl[2 * k];
+					if (std::getenv("TNSX_DEBUG_POOL")) fprintf(stderr, "[tnsx] pool overflow pair %zu: cursor %llu hits %llu cap %zu slab %u n_i %d\n", k, (unsigned long long)need, (unsigned long long)h_ctrl[2 * k + 1], pr.records.cap / sizeof(int), pr.pool_slab, pr.n_i);
+					HIPCHK(c, pr.records.reserve((need + need / 8 + (uint64_t)query_waves * pr.pool_slab * 2) * sizeof(int)));
+					S.pool_retries++;
+				}
 				const tnsx_status r = launch_pool(k);
 				if (r != TNSX_OK) return r;
 				HIPCHK(c, hipStreamSynchronize(st));
-				S.pool_retries++;
 			}
 			pr.n_records = h_ctrl[2 * k];
 			n_neighbors = h_ctrl[2 * k + 1];

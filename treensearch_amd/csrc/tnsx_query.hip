@@ -28,9 +28,6 @@ namespace tnsx {
 // =====================================================================================================
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-#ifndef TNSX_F4_LAYOUT
-#define TNSX_F4_LAYOUT 0   // candidate register layout, see process_batch
-#endif
 
 static constexpr int Q_THREADS = 256;
 static constexpr int Q_WAVES = Q_THREADS / WAVE;
@@ -49,21 +46,6 @@ __device__ __forceinline__ v2f dist_sq2(float qx, float qy, float qz, v2f cx, v2
 	}
 	else {
 		return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));   // CONTRACTED
-	}
-}
-
-// squared distance of one query to one candidate kept in its float4 (x,y handled as one packed pair)
-template <int ARITH>
-__device__ __forceinline__ float dist_sq1(float qx, float qy, float qz, const float4& c)
-{
-	const v2f dxy = (v2f){ qx, qy } - (v2f){ c.x, c.y };
-	const float dz = __fsub_rn(qz, c.z);
-	if (ARITH == 0) {
-		const v2f sq = dxy * dxy;
-		return __fadd_rn(__fadd_rn(sq.x, sq.y), __fmul_rn(dz, dz));                                 // STRICT
-	}
-	else {
-		return __fmaf_rn(dz, dz, __fmaf_rn(dxy.x, dxy.x, __fmul_rn(dxy.y, dxy.y)));                   // CONTRACTED
 	}
 }
 
@@ -209,29 +191,7 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 	//      Branch-free on purpose: a load inside `if (slot < total)` gets its own exec region and its own
 	//      s_waitcnt, which serialises the round trips.  Out-of-range slots read a clamped (valid) address instead and
 	//      are overwritten with padding afterwards.
-#if TNSX_F4_LAYOUT
-	// layout A: every chunk stays in the float4 it was loaded into (x,y packed per candidate); no repacking, fewer registers
-	float4 c4[NC];
-	float cr2[NC];
-	#pragma unroll
-	for (int k = 0; k < NC; k++) {
-		const uint32_t slot = wb + (uint32_t)(k * WAVE + lane);
-		const uint32_t src = slot < R.total ? slot_to_src(slot, R) : R.d0;   // R.d0 = first candidate of the cell
-		c4[k] = a.xyzi_j[src];
-		cr2[k] = SYM ? a.r2_j[src] : 0.f;
-	}
-	#pragma unroll
-	for (int k = 0; k < NC; k++) {
-		const uint32_t slot = wb + (uint32_t)(k * WAVE + lane);
-		if (!EXACT_NC || k == NC - 1) {      // with an exact chunk count only the last chunk can be partial
-			const bool valid = slot < R.total;
-			c4[k].x = valid ? c4[k].x : FLT_MAX; c4[k].y = valid ? c4[k].y : FLT_MAX; c4[k].z = valid ? c4[k].z : FLT_MAX;
-			c4[k].w = valid ? c4[k].w : __uint_as_float(0xffffffffu);
-			if (SYM) cr2[k] = valid ? cr2[k] : -1.0f;
-		}
-	}
-#else
-	// layout B: chunks paired as (x_k, x_k+1) so that one packed instruction serves two chunks
+	// chunks paired as (x_k, x_k+1) so that one packed instruction serves two chunks
 	v2f cx[NP], cy[NP], cz[NP];
 	uint32_t cid[2 * NP];
 	float cr2[2 * NP];
@@ -261,7 +221,6 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 		cid[k] = __float_as_uint(c.w);
 		cr2[k] = r2c;
 	}
-#endif
 	// ---- every query of the cell against them
 	for (uint32_t t = 0; t < nq; t++) {
 		const float qx = readlane_f32(qv.x, (int)t), qy = readlane_f32(qv.y, (int)t), qz = readlane_f32(qv.z, (int)t);
@@ -269,15 +228,6 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 		const uint32_t qi = readlane_u32(__float_as_uint(qv.w), (int)t);
 		// hit masks of all chunks first: every compare writes its lane mask to an SGPR pair, the rest is scalar work
 		uint64_t m[NC];
-#if TNSX_F4_LAYOUT
-		#pragma unroll
-		for (int k = 0; k < NC; k++) {
-			const float d2 = dist_sq1<ARITH>(qx, qy, qz, c4[k]);
-			m[k] = __builtin_amdgcn_ballot_w64(d2 <= r2);
-			if (SYM) m[k] |= __builtin_amdgcn_ballot_w64(d2 <= cr2[k]);
-			if (SELF == 1) m[k] &= __builtin_amdgcn_ballot_w64(__float_as_uint(c4[k].w) != qi);
-		}
-#else
 		#pragma unroll
 		for (int h = 0; h < NP; h++) {
 			const v2f d2 = dist_sq2<ARITH>(qx, qy, qz, cx[h], cy[h], cz[h]);
@@ -293,7 +243,6 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 				}
 			}
 		}
-#endif
 		if (SELF == 2) {
 			// the query is always a hit of itself (d2 == 0); its slot is its sorted position minus the start of the centre run
 			const uint32_t ss = (qb + t) - RR.d_self - wb;
@@ -321,11 +270,7 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 				uint32_t pos = 0;
 				#pragma unroll
 				for (int k = 0; k < NC; k++) {
-#if TNSX_F4_LAYOUT
-					emit_chunk(dst, pos, m[k], __float_as_uint(c4[k].w));
-#else
 					emit_chunk(dst, pos, m[k], cid[k]);
-#endif
 					pos += (uint32_t)__popcll(m[k]);
 				}
 			}
@@ -430,9 +375,11 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 			else {
 				// ---- rare: several candidate batches in pool mode.  Count sweep, allocate the records of all nq queries
 				//      at once, fill sweep.
+				//      (the hits are tallied by the count sweep, so that a pass that cannot write -- pool overflow, dry pass -- still
+				//      reports how many neighbours there are)
 				uint32_t unused_hits = 0;
 				for (uint32_t wb = 0; wb < RR.total; wb += Q_SLOTS) {
-					process_batch_nc<ARITH, VARIABLE, SYM, SELF, MODE_COUNT, false>(a, RR, wb, Q_SLOTS, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, unused_hits);
+					process_batch_nc<ARITH, VARIABLE, SYM, SELF, MODE_COUNT, false>(a, RR, wb, Q_SLOTS, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits);
 				}
 				const uint32_t len = (uint32_t)lane < nq ? run_cnt + 1u : 0u;
 				uint32_t inc = len;
@@ -445,7 +392,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 				run_cnt = 0;
 				if (okm) {
 					for (uint32_t wb = 0; wb < RR.total; wb += Q_SLOTS) {
-						process_batch_nc<ARITH, VARIABLE, SYM, SELF, MODE_FILL, false>(a, RR, wb, Q_SLOTS, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits);
+						process_batch_nc<ARITH, VARIABLE, SYM, SELF, MODE_FILL, false>(a, RR, wb, Q_SLOTS, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, unused_hits);
 					}
 				}
 			}

@@ -149,7 +149,10 @@ class SlabExchange:
             recv.append(in2[p] if p in in2 else in1[p][1:1 + n_in[p]])
             self._caps[p] = (max(cs, self._capacity(n_out[p])) if n_out[p] > cs else cs, max(cr, self._capacity(n_in[p])) if n_in[p] > cr else cr)
         self.rounds_last = 2 if (out2 or in2) else (1 if peers else 0)
-        g = torch.cat(recv, dim=0) if recv else torch.empty((0, W), dtype=torch.float32, device=dev)
+        if not recv:
+            return (torch.empty((0, 3), dtype=torch.float32, device=dev), torch.empty(0, dtype=torch.int64, device=dev),
+                    None if radii is None else torch.empty(0, dtype=torch.float32, device=dev))
+        g = torch.cat(recv, dim=0) if len(recv) > 1 else recv[0]
         ghost_pts = g[:, 0:3].contiguous()
         ghost_r = g[:, 3].contiguous() if radii is not None else None
         # (clone, not contiguous(): an EMPTY slice counts as contiguous and keeps its odd storage offset, which int64 cannot view)
