@@ -174,6 +174,53 @@ __device__ __forceinline__ void emit_chunk(const int* rec, uint32_t pos, uint64_
 		: "memory");
 }
 
+// Up to four chunks in ONE asm statement: exec goes from mask to mask and is restored once at the end (5 scalar moves for
+// four chunks instead of 8), and the compiler cannot put instructions -- or its hazard s_nops -- between the pieces.
+// Chunk k appends the set lanes of m_k to rec[1 + p_k ...].
+#define TNSX_EMIT_PIECE(K)                                                  \
+	"s_mov_b64 exec, %[m" #K "]\n\t"                                       \
+	"v_mbcnt_lo_u32_b32 %[t], %[l" #K "], 0\n\t"                            \
+	"v_mbcnt_hi_u32_b32 %[t], %[h" #K "], %[t]\n\t"                         \
+	"v_add_lshl_u32 %[t], %[t], %[p" #K "], 2\n\t"                          \
+	"global_store_dword %[t], %[v" #K "], %[base] offset:4\n\t"
+#define TNSX_EMIT_IN(K, M, P, V) [m##K] "s"(M), [l##K] "s"((uint32_t)(M)), [h##K] "s"((uint32_t)((M) >> 32)), [p##K] "s"(P), [v##K] "v"(V)
+template <int N>
+__device__ __forceinline__ void emit_chunks(const int* rec, const uint64_t* m, const uint32_t* p, const uint32_t* v)
+{
+	uint32_t tmp;
+	if (N == 1) {
+		asm volatile(TNSX_EMIT_PIECE(0) "s_mov_b64 exec, -1" : [t] "=&v"(tmp) : TNSX_EMIT_IN(0, m[0], p[0], v[0]), [base] "s"(rec) : "memory");
+	}
+	else if (N == 2) {
+		asm volatile(TNSX_EMIT_PIECE(0) TNSX_EMIT_PIECE(1) "s_mov_b64 exec, -1"
+		             : [t] "=&v"(tmp) : TNSX_EMIT_IN(0, m[0], p[0], v[0]), TNSX_EMIT_IN(1, m[1], p[1], v[1]), [base] "s"(rec) : "memory");
+	}
+	else if (N == 3) {
+		asm volatile(TNSX_EMIT_PIECE(0) TNSX_EMIT_PIECE(1) TNSX_EMIT_PIECE(2) "s_mov_b64 exec, -1"
+		             : [t] "=&v"(tmp)
+		             : TNSX_EMIT_IN(0, m[0], p[0], v[0]), TNSX_EMIT_IN(1, m[1], p[1], v[1]), TNSX_EMIT_IN(2, m[2], p[2], v[2]), [base] "s"(rec) : "memory");
+	}
+	else {
+		asm volatile(TNSX_EMIT_PIECE(0) TNSX_EMIT_PIECE(1) TNSX_EMIT_PIECE(2) TNSX_EMIT_PIECE(3) "s_mov_b64 exec, -1"
+		             : [t] "=&v"(tmp)
+		             : TNSX_EMIT_IN(0, m[0], p[0], v[0]), TNSX_EMIT_IN(1, m[1], p[1], v[1]), TNSX_EMIT_IN(2, m[2], p[2], v[2]),
+		               TNSX_EMIT_IN(3, m[3], p[3], v[3]), [base] "s"(rec) : "memory");
+	}
+}
+// all NC chunks of one query, four per asm statement
+template <int NC>
+__device__ __forceinline__ void emit_all(const int* rec, const uint64_t (&m)[NC], const uint32_t (&p)[NC], const uint32_t* v)
+{
+	#pragma unroll
+	for (int g = 0; g < NC; g += 4) {
+		constexpr int dummy = 0; (void)dummy;
+		if (NC - g >= 4) emit_chunks<4>(rec, m + g, p + g, v + g);
+		else if (NC - g == 3) emit_chunks<3>(rec, m + g, p + g, v + g);
+		else if (NC - g == 2) emit_chunks<2>(rec, m + g, p + g, v + g);
+		else emit_chunks<1>(rec, m + g, p + g, v + g);
+	}
+}
+
 // One batch of <= NC*64 candidates (register resident) against the nq query points held one per lane in qv.
 //   MODE_COUNT: run_cnt (lane t) += hits of query t
 //   MODE_FILL : record of query t starts at my_off (lane t); indices appended at my_off + 1 + run_cnt
@@ -248,7 +295,7 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 			const uint32_t ss = (qb + t) - RR.d_self - wb;
 			const uint64_t bit = 1ull << (ss & 63u);
 			m[0] &= ~(ss < 64u ? bit : 0ull);
-			if (NC > 1) m[1] &= ~((ss >= 64u && ss < 128u) ? bit : 0ull);
+			if (NC > 1) m[NC > 1 ? 1 : 0] &= ~((ss >= 64u && ss < 128u) ? bit : 0ull);
 		}
 		uint32_t cnt = 0;
 		#pragma unroll
@@ -475,15 +522,30 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 		cr2[k] = r2c;
 	}
 
-	// ---- allocator state in plain scalars: byte pointer of the next record, ints left in the slab, slab-inside-pool flag
+	// ---- allocator state in plain scalars.  Records of this cell go to records[base + pos0 ...]: `base` (64-bit) changes only
+	//      when a new slab is taken, everything per query is 32-bit: pos0 (ints used since `base`), left (ints left in the slab).
 	uint32_t left = readfirstlane_u32(ps.left);
-	bool ok = readfirstlane_u32(ps.ok) != 0u;        // (explicitly uniform: otherwise `if (ok)` becomes an exec-masked region)
-	const int* rec = a.records + (((uint64_t)readfirstlane_u32(ps.cur_hi) << 32) | readfirstlane_u32(ps.cur_lo));
+	uint32_t ok = readfirstlane_u32(ps.ok);          // (an explicitly uniform integer: as a bool it ends up in a VGPR / an exec-masked region)
+	uint64_t base = ((uint64_t)readfirstlane_u32(ps.cur_hi) << 32) | readfirstlane_u32(ps.cur_lo);
+	const int* rec = a.records + base;
+	uint32_t pos0 = 0;
+
+	// lane t keeps (count, pos0) of query t (v_writelane); the count words and the offsets by original index are written for
+	// all queries together -- at the end of the cell, or before `base` changes
+	uint32_t v_cnt = 0, v_pos = 0;
+	uint32_t flushed = 0;                            // queries [0, flushed) have been written
+	auto flush = [&](uint32_t upto) {
+		if ((uint32_t)lane >= flushed && (uint32_t)lane < upto && ok != 0u) {
+			const uint64_t off = base + v_pos;
+			a.records[off] = (int)v_cnt;
+			a.offs_by_orig[qidx] = off;
+		}
+		flushed = upto;
+	};
 
 	// ---- the query loop.  (Fetching the query point with a scalar load one iteration ahead instead of v_readlane was
 	//      tried and dropped: the compiler is free to copy the destination SGPRs before the asynchronous load has landed.)
-	uint32_t run_cnt = 0, hits = 0;
-	const int* my_rec = nullptr;                     // lane t: start of the record of query t (nullptr: not written)
+	uint32_t hits = 0;
 	for (uint32_t t = 0; t < nq; t++) {
 		const float qx = readlane_f32(qv.x, (int)t), qy = readlane_f32(qv.y, (int)t), qz = readlane_f32(qv.z, (int)t);
 		const float r2q = VARIABLE ? readlane_f32(qr2, (int)t) : a.r2_fixed;
@@ -505,45 +567,41 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 			const uint32_t ss = (cur_q.x + t) - RR.d_self;
 			const uint64_t bit = 1ull << (ss & 63u);
 			m[0] &= ~(ss < 64u ? bit : 0ull);
-			if (NC > 1) m[1] &= ~(ss >= 64u ? bit : 0ull);
+			if (NC > 1) m[NC > 1 ? 1 : 0] &= ~(ss >= 64u ? bit : 0ull);
 		}
-		uint32_t cnt = 0;
+		uint32_t p[NC];                                  // chunk k goes to rec[1 + p[k] ...]
+		uint32_t run = pos0;
 		#pragma unroll
-		for (int k = 0; k < NC; k++) cnt += (uint32_t)__popcll(m[k]);
-		const uint32_t len = cnt + 1u;
+		for (int k = 0; k < NC; k++) { p[k] = run; run += (uint32_t)__popcll(m[k]); }
+		const uint32_t cnt = run - pos0, len = cnt + 1u;
 		if (len > left) {
-			// rare: new slab (one atomic on the global cursor)
+			// rare: new slab (one atomic on the global cursor).  The queries so far refer to the old base: write them out first.
+			flush(t);
 			const uint32_t sz = len > a.pool_slab ? len : a.pool_slab;
 			const unsigned long long old = pool_take_slab(a.pool_cursor, sz);
-			const uint64_t base = ((uint64_t)readfirstlane_u32((uint32_t)(old >> 32)) << 32) | readfirstlane_u32((uint32_t)old);
+			base = ((uint64_t)readfirstlane_u32((uint32_t)(old >> 32)) << 32) | readfirstlane_u32((uint32_t)old);
 			rec = a.records + base;
 			left = sz;
-			ok = readfirstlane_u32(base + sz <= a.pool_capacity ? 1u : 0u) != 0u;
-		}
-		if (ok) {
-			uint32_t pos = 0;
+			ok = readfirstlane_u32(base + sz <= a.pool_capacity ? 1u : 0u);
 			#pragma unroll
-			for (int k = 0; k < NC; k++) {
-				emit_chunk(rec, pos, m[k], cid[k]);
-				pos += (uint32_t)__popcll(m[k]);
-			}
+			for (int k = 0; k < NC; k++) p[k] -= pos0;
+			pos0 = 0;
 		}
-		if ((uint32_t)lane == t) { run_cnt = cnt; my_rec = ok ? rec : nullptr; }
-		rec += len;
+		if (ok != 0u) emit_all<NC>(rec, m, p, cid);
+		// (lane select in m0: a VALU instruction of gfx9 may read only one SGPR besides it.  m0 is a reserved register that the
+		//  compiler loads right before each of its own uses -- none in this kernel -- so it is not, and cannot be, listed as clobbered)
+		asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(v_cnt), "+v"(v_pos) : "s"(cnt), "s"(pos0), "s"(t));
+		pos0 += len;
 		left -= len;
 		hits += cnt;
 	}
+	flush(nq);
 	wave_hits += hits;
 	{
-		const uint64_t cur = (uint64_t)(rec - a.records);
+		const uint64_t cur = base + pos0;
 		ps.cur_lo = (uint32_t)cur; ps.cur_hi = (uint32_t)(cur >> 32);
 		ps.left = left;
-		ps.ok = ok ? 1u : 0u;
-	}
-	if ((uint32_t)lane < nq && my_rec != nullptr) {
-		const uint64_t my_off = (uint64_t)(my_rec - a.records);
-		a.records[my_off] = (int)run_cnt;
-		a.offs_by_orig[qidx] = my_off;
+		ps.ok = ok;
 	}
 }
 
