@@ -174,50 +174,64 @@ __device__ __forceinline__ void emit_chunk(const int* rec, uint32_t pos, uint64_
 		: "memory");
 }
 
-// Up to four chunks in ONE asm statement: exec goes from mask to mask and is restored once at the end (5 scalar moves for
-// four chunks instead of 8), and the compiler cannot put instructions -- or its hazard s_nops -- between the pieces.
-// Chunk k appends the set lanes of m_k to rec[1 + p_k ...].
-#define TNSX_EMIT_PIECE(K)                                                  \
-	"s_mov_b64 exec, %[m" #K "]\n\t"                                       \
-	"v_mbcnt_lo_u32_b32 %[t], %[l" #K "], 0\n\t"                            \
-	"v_mbcnt_hi_u32_b32 %[t], %[h" #K "], %[t]\n\t"                         \
-	"v_add_lshl_u32 %[t], %[t], %[p" #K "], 2\n\t"                          \
-	"global_store_dword %[t], %[v" #K "], %[base] offset:4\n\t"
+// Emission of the fast kernels.  Up to four chunks in ONE asm statement: exec goes from mask to mask and is restored once at
+// the end (5 scalar moves for four chunks instead of 8), and the compiler cannot put instructions -- or its hazard s_nops --
+// between the pieces.  The store is a BUFFER store with index addressing: the record storage is described by a V# with
+// stride 4, so the hardware computes base + soffset + index * 4 and the lane's prefix count (v_mbcnt) is the index as it is:
+// two VALU instructions per chunk instead of three (no shift/add), in a kernel that is bound by VALU issue.
+// Chunk k appends the set lanes of m_k at byte offset pb_k (+4: the count word) of the record.
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i record_rsrc(const int* base)
+{
+	// gfx9 buffer resource: base address [47:0], stride [61:48] = 4 bytes, num_records = 2^32 - 1 (never out of range),
+	// word 3 = DATA_FORMAT_32 (0x00020000, as used by composable_kernel for gfx9)
+	const uint64_t b = (uint64_t)base;
+	v4i r;
+	r.x = (int)(uint32_t)b;
+	r.y = (int)(((uint32_t)(b >> 32) & 0xffffu) | (4u << 16));
+	r.z = -1;
+	r.w = 0x00020000;
+	return r;
+}
+#define TNSX_EMIT_PIECE(K)                                                                   \
+	"s_mov_b64 exec, %[m" #K "]\n\t"                                                        \
+	"v_mbcnt_lo_u32_b32 %[t], %[l" #K "], 0\n\t"                                             \
+	"v_mbcnt_hi_u32_b32 %[t], %[h" #K "], %[t]\n\t"                                          \
+	"buffer_store_dword %[v" #K "], %[t], %[rsrc], %[p" #K "] idxen offset:4\n\t"
 #define TNSX_EMIT_IN(K, M, P, V) [m##K] "s"(M), [l##K] "s"((uint32_t)(M)), [h##K] "s"((uint32_t)((M) >> 32)), [p##K] "s"(P), [v##K] "v"(V)
 template <int N>
-__device__ __forceinline__ void emit_chunks(const int* rec, const uint64_t* m, const uint32_t* p, const uint32_t* v)
+__device__ __forceinline__ void emit_chunks(v4i rsrc, const uint64_t* m, const uint32_t* pb, const uint32_t* v)
 {
 	uint32_t tmp;
 	if (N == 1) {
-		asm volatile(TNSX_EMIT_PIECE(0) "s_mov_b64 exec, -1" : [t] "=&v"(tmp) : TNSX_EMIT_IN(0, m[0], p[0], v[0]), [base] "s"(rec) : "memory");
+		asm volatile(TNSX_EMIT_PIECE(0) "s_mov_b64 exec, -1" : [t] "=&v"(tmp) : TNSX_EMIT_IN(0, m[0], pb[0], v[0]), [rsrc] "s"(rsrc) : "memory");
 	}
 	else if (N == 2) {
 		asm volatile(TNSX_EMIT_PIECE(0) TNSX_EMIT_PIECE(1) "s_mov_b64 exec, -1"
-		             : [t] "=&v"(tmp) : TNSX_EMIT_IN(0, m[0], p[0], v[0]), TNSX_EMIT_IN(1, m[1], p[1], v[1]), [base] "s"(rec) : "memory");
+		             : [t] "=&v"(tmp) : TNSX_EMIT_IN(0, m[0], pb[0], v[0]), TNSX_EMIT_IN(1, m[1], pb[1], v[1]), [rsrc] "s"(rsrc) : "memory");
 	}
 	else if (N == 3) {
 		asm volatile(TNSX_EMIT_PIECE(0) TNSX_EMIT_PIECE(1) TNSX_EMIT_PIECE(2) "s_mov_b64 exec, -1"
 		             : [t] "=&v"(tmp)
-		             : TNSX_EMIT_IN(0, m[0], p[0], v[0]), TNSX_EMIT_IN(1, m[1], p[1], v[1]), TNSX_EMIT_IN(2, m[2], p[2], v[2]), [base] "s"(rec) : "memory");
+		             : TNSX_EMIT_IN(0, m[0], pb[0], v[0]), TNSX_EMIT_IN(1, m[1], pb[1], v[1]), TNSX_EMIT_IN(2, m[2], pb[2], v[2]), [rsrc] "s"(rsrc) : "memory");
 	}
 	else {
 		asm volatile(TNSX_EMIT_PIECE(0) TNSX_EMIT_PIECE(1) TNSX_EMIT_PIECE(2) TNSX_EMIT_PIECE(3) "s_mov_b64 exec, -1"
 		             : [t] "=&v"(tmp)
-		             : TNSX_EMIT_IN(0, m[0], p[0], v[0]), TNSX_EMIT_IN(1, m[1], p[1], v[1]), TNSX_EMIT_IN(2, m[2], p[2], v[2]),
-		               TNSX_EMIT_IN(3, m[3], p[3], v[3]), [base] "s"(rec) : "memory");
+		             : TNSX_EMIT_IN(0, m[0], pb[0], v[0]), TNSX_EMIT_IN(1, m[1], pb[1], v[1]), TNSX_EMIT_IN(2, m[2], pb[2], v[2]),
+		               TNSX_EMIT_IN(3, m[3], pb[3], v[3]), [rsrc] "s"(rsrc) : "memory");
 	}
 }
 // all NC chunks of one query, four per asm statement
 template <int NC>
-__device__ __forceinline__ void emit_all(const int* rec, const uint64_t (&m)[NC], const uint32_t (&p)[NC], const uint32_t* v)
+__device__ __forceinline__ void emit_all(v4i rsrc, const uint64_t (&m)[NC], const uint32_t (&pb)[NC], const uint32_t* v)
 {
 	#pragma unroll
 	for (int g = 0; g < NC; g += 4) {
-		constexpr int dummy = 0; (void)dummy;
-		if (NC - g >= 4) emit_chunks<4>(rec, m + g, p + g, v + g);
-		else if (NC - g == 3) emit_chunks<3>(rec, m + g, p + g, v + g);
-		else if (NC - g == 2) emit_chunks<2>(rec, m + g, p + g, v + g);
-		else emit_chunks<1>(rec, m + g, p + g, v + g);
+		if (NC - g >= 4) emit_chunks<4>(rsrc, m + g, pb + g, v + g);
+		else if (NC - g == 3) emit_chunks<3>(rsrc, m + g, pb + g, v + g);
+		else if (NC - g == 2) emit_chunks<2>(rsrc, m + g, pb + g, v + g);
+		else emit_chunks<1>(rsrc, m + g, pb + g, v + g);
 	}
 }
 
@@ -522,12 +536,13 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 		cr2[k] = r2c;
 	}
 
-	// ---- allocator state in plain scalars.  Records of this cell go to records[base + pos0 ...]: `base` (64-bit) changes only
-	//      when a new slab is taken, everything per query is 32-bit: pos0 (ints used since `base`), left (ints left in the slab).
+	// ---- allocator state in plain scalars.  Records of this cell go to records[base ...] + pos0 bytes: `base` (64-bit, and the
+	//      buffer resource made from it) changes only when a new slab is taken, everything per query is 32-bit: pos0 (BYTES used
+	//      since `base`), left (ints left in the slab).
 	uint32_t left = readfirstlane_u32(ps.left);
 	uint32_t ok = readfirstlane_u32(ps.ok);          // (an explicitly uniform integer: as a bool it ends up in a VGPR / an exec-masked region)
 	uint64_t base = ((uint64_t)readfirstlane_u32(ps.cur_hi) << 32) | readfirstlane_u32(ps.cur_lo);
-	const int* rec = a.records + base;
+	v4i rsrc = record_rsrc(a.records + base);
 	uint32_t pos0 = 0;
 
 	// lane t keeps (count, pos0) of query t (v_writelane); the count words and the offsets by original index are written for
@@ -536,7 +551,7 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 	uint32_t flushed = 0;                            // queries [0, flushed) have been written
 	auto flush = [&](uint32_t upto) {
 		if ((uint32_t)lane >= flushed && (uint32_t)lane < upto && ok != 0u) {
-			const uint64_t off = base + v_pos;
+			const uint64_t off = base + (v_pos >> 2);
 			a.records[off] = (int)v_cnt;
 			a.offs_by_orig[qidx] = off;
 		}
@@ -546,6 +561,11 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 	// ---- the query loop.  (Fetching the query point with a scalar load one iteration ahead instead of v_readlane was
 	//      tried and dropped: the compiler is free to copy the destination SGPRs before the asynchronous load has landed.)
 	uint32_t hits = 0;
+	// slot of query 0 = its sorted position minus the start of the centre run (< 128: in chunk 0 or 1); one bit of a 128-bit
+	// mask that is shifted along with t -- cheaper than building the bit from the slot number for every query
+	const uint32_t ss0 = cur_q.x - RR.d_self;
+	uint64_t self0 = (SELF && ss0 < 64u) ? 1ull << (ss0 & 63u) : 0ull;
+	uint64_t self1 = (SELF && ss0 >= 64u) ? 1ull << (ss0 & 63u) : 0ull;
 	for (uint32_t t = 0; t < nq; t++) {
 		const float qx = readlane_f32(qv.x, (int)t), qy = readlane_f32(qv.y, (int)t), qz = readlane_f32(qv.z, (int)t);
 		const float r2q = VARIABLE ? readlane_f32(qr2, (int)t) : a.r2_fixed;
@@ -563,42 +583,42 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 			}
 		}
 		if (SELF) {
-			// the query is always a hit of itself (d2 == 0); its slot is its sorted position minus the start of the centre run
-			const uint32_t ss = (cur_q.x + t) - RR.d_self;
-			const uint64_t bit = 1ull << (ss & 63u);
-			m[0] &= ~(ss < 64u ? bit : 0ull);
-			if (NC > 1) m[NC > 1 ? 1 : 0] &= ~(ss >= 64u ? bit : 0ull);
+			// the query is always a hit of itself (d2 == 0): clear its own slot, then move the bit on to the next query's slot
+			m[0] &= ~self0;
+			if (NC > 1) m[NC > 1 ? 1 : 0] &= ~self1;
+			self1 = (self1 << 1) | (self0 >> 63);
+			self0 <<= 1;
 		}
-		uint32_t p[NC];                                  // chunk k goes to rec[1 + p[k] ...]
+		uint32_t p[NC];                                  // chunk k goes to byte 4 + p[k] ... of the storage at `base`
 		uint32_t run = pos0;
 		#pragma unroll
-		for (int k = 0; k < NC; k++) { p[k] = run; run += (uint32_t)__popcll(m[k]); }
-		const uint32_t cnt = run - pos0, len = cnt + 1u;
+		for (int k = 0; k < NC; k++) { p[k] = run; run += 4u * (uint32_t)__popcll(m[k]); }
+		const uint32_t cnt = (run - pos0) >> 2, len = cnt + 1u;
 		if (len > left) {
 			// rare: new slab (one atomic on the global cursor).  The queries so far refer to the old base: write them out first.
 			flush(t);
 			const uint32_t sz = len > a.pool_slab ? len : a.pool_slab;
 			const unsigned long long old = pool_take_slab(a.pool_cursor, sz);
 			base = ((uint64_t)readfirstlane_u32((uint32_t)(old >> 32)) << 32) | readfirstlane_u32((uint32_t)old);
-			rec = a.records + base;
+			rsrc = record_rsrc(a.records + base);
 			left = sz;
 			ok = readfirstlane_u32(base + sz <= a.pool_capacity ? 1u : 0u);
 			#pragma unroll
 			for (int k = 0; k < NC; k++) p[k] -= pos0;
 			pos0 = 0;
 		}
-		if (ok != 0u) emit_all<NC>(rec, m, p, cid);
+		if (ok != 0u) emit_all<NC>(rsrc, m, p, cid);
 		// (lane select in m0: a VALU instruction of gfx9 may read only one SGPR besides it.  m0 is a reserved register that the
 		//  compiler loads right before each of its own uses -- none in this kernel -- so it is not, and cannot be, listed as clobbered)
 		asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(v_cnt), "+v"(v_pos) : "s"(cnt), "s"(pos0), "s"(t));
-		pos0 += len;
+		pos0 += 4u * len;
 		left -= len;
 		hits += cnt;
 	}
 	flush(nq);
 	wave_hits += hits;
 	{
-		const uint64_t cur = base + pos0;
+		const uint64_t cur = base + (pos0 >> 2);
 		ps.cur_lo = (uint32_t)cur; ps.cur_hi = (uint32_t)(cur >> 32);
 		ps.left = left;
 		ps.ok = ok;
