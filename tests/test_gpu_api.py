@@ -251,3 +251,28 @@ def test_halo_pack_kernel_matches_torch_selection():
         ex2._send_buf = [None, torch.empty((16, cols), dtype=torch.float32, device="cuda")]
         l2, r2 = ex2._pack_device(pts, gids, r, False, True, cols - 1)
         assert l2 is None and r2.shape[0] - 1 == int((pts[:, 0] >= 4.0 - 0.25).sum())
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 1023, 100003])
+@pytest.mark.parametrize("on_device", [False, True])
+def test_grid_follows_the_tight_bounds(n, on_device):
+    """Binning clamps coordinates, so a wrong bounding box would not change a single neighbour list -- only the speed.  The grid
+    geometry is therefore checked on its own: per-axis cell counts = floor(extent / h) + 1 over the exact min / max of the
+    points (extreme points placed at the ends of the array and in odd positions, sizes around the 4-point vector width)."""
+    import torch
+    import treensearch_amd as T
+    rng = np.random.default_rng(n)
+    pts = (rng.random((n, 3), dtype=np.float32) * np.array([0.7, 0.2, 1.3], np.float32) + np.array([-3.0, 5.0, 0.1], np.float32)).astype(np.float32)
+    pts[n - 1] += np.float32(0.4)          # maxima at the very end
+    pts[(n - 1) // 2, 1] -= np.float32(0.3)
+    pts = np.ascontiguousarray(pts)
+    ns = T.TreeNSearch()
+    ns.set_search_radius(0.013)
+    ns.add_point_set(torch.from_numpy(pts).cuda() if on_device else pts)
+    ns.set_active_search(0, 0, True)
+    ns.run()
+    st = ns.get_stats()
+    h = float(st["grid_cell_size"])
+    lo, hi = pts.min(axis=0).astype(np.float64), pts.max(axis=0).astype(np.float64)
+    expect = [int(np.floor((hi[d] - lo[d]) / h)) + 1 for d in range(3)]
+    assert list(st["grid_dims"]) == expect

@@ -66,15 +66,31 @@ __device__ void block_reduce_write8(float (&v)[8], float* out)
 		out[k] = r;
 	}
 }
+// VEC: the xyz array is 16-byte aligned and is read as float4 -- three of them hold four points: [x y z x | y z x y | z x y z]
+template <bool VEC>
 __global__ void __launch_bounds__(BOUNDS_THREADS) k_bounds_partial(const float* __restrict__ xyz, const float* __restrict__ radii, int n,
                                                                    float* __restrict__ partials)
 {
 	float v[8] = { FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX, FLT_MAX, -FLT_MAX };
-	for (int i = blockIdx.x * BOUNDS_THREADS + threadIdx.x; i < n; i += gridDim.x * BOUNDS_THREADS) {
-		const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+	auto take = [&](float x, float y, float z) {
 		v[0] = fminf(v[0], x); v[1] = fminf(v[1], y); v[2] = fminf(v[2], z);
 		v[3] = fmaxf(v[3], x); v[4] = fmaxf(v[4], y); v[5] = fmaxf(v[5], z);
-		if (radii) { const float r = radii[i]; v[6] = fminf(v[6], r); v[7] = fmaxf(v[7], r); }
+	};
+	const int stride = gridDim.x * BOUNDS_THREADS, t0 = blockIdx.x * BOUNDS_THREADS + threadIdx.x;
+	int first_scalar = 0;
+	if (VEC) {
+		const int n4 = n / 4;   // groups of four points = three float4
+		const float4* q = reinterpret_cast<const float4*>(xyz);
+		#pragma unroll 2
+		for (int gi = t0; gi < n4; gi += stride) {
+			const float4 a = q[3 * (size_t)gi], b = q[3 * (size_t)gi + 1], c = q[3 * (size_t)gi + 2];
+			take(a.x, a.y, a.z); take(a.w, b.x, b.y); take(b.z, b.w, c.x); take(c.y, c.z, c.w);
+		}
+		first_scalar = n4 * 4;
+	}
+	for (int i = first_scalar + t0; i < n; i += stride) take(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]);
+	if (radii) {
+		for (int i = t0; i < n; i += stride) { const float r = radii[i]; v[6] = fminf(v[6], r); v[7] = fmaxf(v[7], r); }
 	}
 	block_reduce_write8(v, partials + 8 * (size_t)blockIdx.x);
 }
@@ -89,7 +105,8 @@ __global__ void __launch_bounds__(BOUNDS_THREADS) k_bounds_final(const float* __
 }
 void launch_bounds_partial(const float* xyz, const float* radii, int n, float* partials, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_bounds_partial, dim3(bounds_num_blocks(n)), dim3(BOUNDS_THREADS), 0, s, xyz, radii, n, partials);
+	if (((uintptr_t)xyz & 15u) == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bounds_partial<true>), dim3(bounds_num_blocks(n)), dim3(BOUNDS_THREADS), 0, s, xyz, radii, n, partials);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bounds_partial<false>), dim3(bounds_num_blocks(n)), dim3(BOUNDS_THREADS), 0, s, xyz, radii, n, partials);
 }
 void launch_bounds_final(const float* partials, int n_partials, float* out8, hipStream_t s)
 {
