@@ -12,6 +12,7 @@
 //   k_cell_table         table[key] = (first, one past last) sorted position, list of occupied cells
 //
 // Digits are up to 11 bits wide, so the 20-bit keys of a 10 M-point cloud need TWO passes: every point is moved twice.
+// prepare_zsort uses the same kernels with the Morton code of the reference grid as the key (sort_key<true>).
 // Stable: wave w of a workgroup owns CS_ITEMS*64 consecutive elements and walks them in rounds of 64, so (wave, round, lane)
 // order is index order; the point order inside a cell is therefore the input order -- reproducible from run to run.
 #include "tnsx_kernels.h"
@@ -72,9 +73,18 @@ __device__ __forceinline__ uint32_t cell_key(float x, float y, float z, const Gr
 	const int iz = bin_coord(z, g.oz, g.inv_h, g.nz);
 	return (uint32_t)((iz * g.ny + iy) * g.nx + ix);
 }
+// the two sort keys: MORTON = false the cell key of the search grid, MORTON = true the Morton code of the cell on the reference's
+// grid (prepare_zsort; up to 63 bits)
+template <bool MORTON>
+__device__ __forceinline__ uint64_t sort_key(float x, float y, float z, const GridParams& g)
+{
+	if (!MORTON) return cell_key(x, y, z, g);
+	const uint64_t ux = (uint64_t)bin_coord(x, g.ox, g.inv_h, g.nx), uy = (uint64_t)bin_coord(y, g.oy, g.inv_h, g.ny), uz = (uint64_t)bin_coord(z, g.oz, g.inv_h, g.nz);
+	return spread3(ux) | (spread3(uy) << 1) | (spread3(uz) << 2);
+}
 
 // ---- per-tile histogram of one digit -----------------------------------------------------------------------------
-template <int BITS, bool FIRST>
+template <int BITS, bool FIRST, bool MORTON>
 __global__ void __launch_bounds__(CS_THREADS) k_cs_hist(const float* __restrict__ xyz, const float4* __restrict__ xyzi, int n, GridParams g, int shift,
                                                         uint32_t* __restrict__ hist, int ntiles)
 {
@@ -87,10 +97,10 @@ __global__ void __launch_bounds__(CS_THREADS) k_cs_hist(const float* __restrict_
 	for (int i = 0; i < CS_ITEMS; i++) {
 		const size_t e = base + (size_t)i * CS_THREADS + threadIdx.x;
 		if (e < (size_t)n) {
-			uint32_t key;
-			if (FIRST) { const F3 q = reinterpret_cast<const F3*>(xyz)[e]; key = cell_key(q.x, q.y, q.z, g); }
-			else { const float4 q = xyzi[e]; key = cell_key(q.x, q.y, q.z, g); }
-			atomicAdd(&h[(key >> shift) & (RADIX - 1)], 1u);
+			uint64_t key;
+			if (FIRST) { const F3 q = reinterpret_cast<const F3*>(xyz)[e]; key = sort_key<MORTON>(q.x, q.y, q.z, g); }
+			else { const float4 q = xyzi[e]; key = sort_key<MORTON>(q.x, q.y, q.z, g); }
+			atomicAdd(&h[(uint32_t)(key >> shift) & (RADIX - 1)], 1u);
 		}
 	}
 	__syncthreads();
@@ -137,7 +147,7 @@ __global__ void __launch_bounds__(SB_THREADS) k_cs_strip_scan(uint32_t* __restri
 // ---- ranked scatter of the points --------------------------------------------------------------------------------
 // FIRST: the point comes from the user's arrays (xyz AoS, radii) and gets its original index attached; r2 = r*r in fp32
 // (TreeNSearch.cpp:2352).  Otherwise it comes from the previous pass.
-template <int BITS, bool FIRST, bool VARIABLE>
+template <int BITS, bool FIRST, bool VARIABLE, bool MORTON>
 __global__ void __launch_bounds__(CS_THREADS) __attribute__((amdgpu_waves_per_eu(BITS <= 10 ? 4 : 3, 4)))
 k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, const float4* __restrict__ xyzi_in, const float* __restrict__ r2_in,
              float4* __restrict__ xyzi_out, float* __restrict__ r2_out, int n, GridParams g, int shift, const uint32_t* __restrict__ hist_scanned,
@@ -208,7 +218,7 @@ k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, con
 	#pragma unroll
 	for (int i = 0; i < CS_ITEMS; i++) {
 		const bool valid = (uint32_t)(i * WAVE + lane) < rem;
-		const uint32_t d = (cell_key(px[i], py[i], pz[i], g) >> shift) & (RADIX - 1);
+		const uint32_t d = (uint32_t)(sort_key<MORTON>(px[i], py[i], pz[i], g) >> shift) & (RADIX - 1);
 		uint64_t peers = __ballot(valid);
 		#pragma unroll
 		for (int b = 0; b < BITS; b++) {
@@ -244,11 +254,11 @@ k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, con
 	}
 }
 
-template <int BITS>
+template <int BITS, bool MORTON>
 static void cs_hist(bool first, const float* xyz, const float4* xyzi, int n, const GridParams& g, int shift, uint32_t* hist, int ntiles, hipStream_t s)
 {
-	if (first) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_hist<BITS, true>), dim3(ntiles), dim3(CS_THREADS), 0, s, xyz, xyzi, n, g, shift, hist, ntiles);
-	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_hist<BITS, false>), dim3(ntiles), dim3(CS_THREADS), 0, s, xyz, xyzi, n, g, shift, hist, ntiles);
+	if (first) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_hist<BITS, true, MORTON>), dim3(ntiles), dim3(CS_THREADS), 0, s, xyz, xyzi, n, g, shift, hist, ntiles);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_hist<BITS, false, MORTON>), dim3(ntiles), dim3(CS_THREADS), 0, s, xyz, xyzi, n, g, shift, hist, ntiles);
 }
 template <int BITS>
 static void cs_scan(uint32_t* hist, int ntiles, uint32_t* strip_sums, uint32_t* totals, hipStream_t s)
@@ -257,15 +267,16 @@ static void cs_scan(uint32_t* hist, int ntiles, uint32_t* strip_sums, uint32_t* 
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_strip_sums<BITS>), dim3(nstrips, (1u << BITS) / SB_THREADS), dim3(SB_THREADS), 0, s, hist, ntiles, strip_sums);
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_strip_scan<BITS>), dim3(nstrips, (1u << BITS) / SB_THREADS), dim3(SB_THREADS), 0, s, hist, ntiles, strip_sums, totals);
 }
-template <int BITS>
+template <int BITS, bool MORTON>
 static void cs_scatter(bool first, bool variable, const float* xyz, const float* radii, const float4* xyzi_in, const float* r2_in, float4* xyzi_out,
                        float* r2_out, int n, const GridParams& g, int shift, const uint32_t* hs, const uint32_t* totals, int ntiles, hipStream_t s)
 {
 #define TNSX_CS_GO(F, V)                                                                                                                       \
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_scatter<BITS, F, V>), dim3(cs_grid(ntiles)), dim3(CS_THREADS), 0, s, xyz, radii, xyzi_in, r2_in, xyzi_out, \
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_scatter<BITS, F, V, MORTON>), dim3(cs_grid(ntiles)), dim3(CS_THREADS), 0, s, xyz, radii, xyzi_in, r2_in, xyzi_out, \
 	                   r2_out, n, g, shift, hs, totals, ntiles)
-	if (first) { if (variable) TNSX_CS_GO(true, true); else TNSX_CS_GO(true, false); }
-	else       { if (variable) TNSX_CS_GO(false, true); else TNSX_CS_GO(false, false); }
+	if (MORTON) { if (first) TNSX_CS_GO(true, false); else TNSX_CS_GO(false, false); }   // the z-order carries no radii
+	else if (first) { if (variable) TNSX_CS_GO(true, true); else TNSX_CS_GO(true, false); }
+	else            { if (variable) TNSX_CS_GO(false, true); else TNSX_CS_GO(false, false); }
 #undef TNSX_CS_GO
 }
 
@@ -277,7 +288,8 @@ static void cs_scatter(bool first, bool variable, const float* xyz, const float*
 	default: { constexpr int B = 11; call; } break;   \
 	}
 
-int launch_cell_sort(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, hipStream_t s)
+template <bool MORTON>
+static int point_sort(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, hipStream_t s)
 {
 	const CellSortPlan plan = cell_sort_plan(key_bits);
 	if (n <= 0) return plan.passes & 1;
@@ -290,14 +302,30 @@ int launch_cell_sort(const float* xyz, const float* radii, int n, GridParams g, 
 	int cur = 0, shift = 0;
 	for (int p = 0; p < plan.passes; p++) {
 		const int bits = plan.bits[p];
-		TNSX_CS_DISPATCH(bits, cs_hist<B>(p == 0, xyz, b.xyzi[cur], n, g, shift, hist, ntiles, s));
+		TNSX_CS_DISPATCH(bits, (cs_hist<B, MORTON>(p == 0, xyz, b.xyzi[cur], n, g, shift, hist, ntiles, s)));
 		TNSX_CS_DISPATCH(bits, cs_scan<B>(hist, ntiles, strip_sums, totals, s));
-		TNSX_CS_DISPATCH(bits, cs_scatter<B>(p == 0, variable, xyz, radii, b.xyzi[cur], b.r2[cur], b.xyzi[cur ^ 1], b.r2[cur ^ 1], n, g, shift, hist,
-		                                     totals, ntiles, s));
+		TNSX_CS_DISPATCH(bits, (cs_scatter<B, MORTON>(p == 0, variable, xyz, radii, b.xyzi[cur], b.r2[cur], b.xyzi[cur ^ 1], b.r2[cur ^ 1], n, g, shift, hist,
+		                                              totals, ntiles, s)));
 		cur ^= 1;
 		shift += bits;
 	}
 	return cur;
+}
+int launch_cell_sort(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, hipStream_t s)
+{
+	return point_sort<false>(xyz, radii, n, g, key_bits, b, temp, s);
+}
+
+__global__ void __launch_bounds__(256) k_extract_order(const float4* __restrict__ xyzi, int n, int* __restrict__ order)
+{
+	const int p = blockIdx.x * 256 + threadIdx.x;
+	if (p < n) order[p] = (int)__float_as_uint(xyzi[p].w);
+}
+int launch_morton_sort(const float* xyz, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, int* order_out, hipStream_t s)
+{
+	const int res = point_sort<true>(xyz, nullptr, n, g, key_bits, b, temp, s);
+	if (n > 0) hipLaunchKernelGGL(k_extract_order, dim3((n + 255) / 256), dim3(256), 0, s, b.xyzi[res], n, order_out);
+	return res;
 }
 
 // =====================================================================================================

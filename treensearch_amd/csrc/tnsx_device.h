@@ -24,4 +24,15 @@ __device__ __forceinline__ void wave_lds_fence()
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// spreads the low 21 bits of v to every third bit (libmorton's 3-D encoding: x -> bit 0, y -> bit 1, z -> bit 2)
+__device__ __forceinline__ uint64_t spread3(uint64_t v)
+{
+	v &= 0x1fffffull;
+	v = (v | (v << 32)) & 0x1f00000000ffffull;
+	v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+	v = (v | (v << 8)) & 0x100f00f00f00f00full;
+	v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+	v = (v | (v << 2)) & 0x1249249249249249ull;
+	return v;
+}
 }  // namespace tnsx

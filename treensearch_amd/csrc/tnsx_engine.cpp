@@ -80,7 +80,6 @@ struct PointSet {
 	const float* d_radii = nullptr;
 	// search structures
 	DevBuf xyzi[2], r2[2];             // ping-pong of the cell sort; [sorted_buf] holds the sorted points of this run
-	DevBuf idx[2];                     // zsort scratch
 	DevBuf table, occ;
 	int sorted_buf = 0;
 	// The cell table is never memset per run (it may be gigabytes for a sparse domain): the entries a run sets are exactly the
@@ -89,7 +88,8 @@ struct PointSet {
 	int table_state = 0;
 	uint32_t table_dirty = 0;
 	// zsort
-	std::vector<int> zsort_host;
+	std::vector<int> zsort_host;    // filled on demand (zsort_host_order)
+	int zsort_n = 0;
 	DevBuf zsort_dev;
 	bool zsort_ready = false;
 };
@@ -136,7 +136,6 @@ struct tnsx_context {
 	// scratch
 	DevBuf bounds_partials, bounds_out, sort_temp, scan_temp, n_occ, permute_tmp, pool_ctrl;
 	PinnedBuf h_small;
-	DevBuf mkeys[2];   // 64-bit morton keys for zsort
 	tnsx_stats stats{};
 	std::vector<hipEvent_t> events;
 	std::mutex mirror_mutex;
@@ -876,27 +875,41 @@ tnsx_status tnsx_prepare_zsort(tnsx_context* c)
 	const int bits_per_axis = std::max(1, ceil_log2_u64((uint64_t)n_pow2));
 	const int key_bits = 3 * bits_per_axis;
 
+	tnsx::GridParams mg{};
+	mg.ox = c->world[0]; mg.oy = c->world[1]; mg.oz = c->world[2];
+	mg.inv_h = c->cell_size_inv;
+	mg.nx = mg.ny = mg.nz = n_pow2;
 	for (PointSet& s : c->sets) {
-		s.zsort_host.assign((size_t)s.n, 0);
+		s.zsort_n = s.n;
+		s.zsort_host.clear();          // fetched from the device when somebody asks for it (get_zsort_order, host-side apply_zsort)
 		s.zsort_ready = true;
 		if (s.n == 0) continue;
-		HIPCHK(c, c->mkeys[0].reserve((size_t)s.n * sizeof(uint64_t)));
-		HIPCHK(c, c->mkeys[1].reserve((size_t)s.n * sizeof(uint64_t)));
-		for (int k = 0; k < 2; k++) HIPCHK(c, s.idx[k].reserve((size_t)s.n * sizeof(uint32_t)));
-		HIPCHK(c, c->sort_temp.reserve(tnsx::radix_temp_bytes(s.n)));
+		for (int k = 0; k < 2; k++) HIPCHK(c, s.xyzi[k].reserve((size_t)s.n * sizeof(float4)));
+		HIPCHK(c, c->sort_temp.reserve(tnsx::cell_sort_temp_bytes(s.n)));
 		HIPCHK(c, s.zsort_dev.reserve((size_t)s.n * sizeof(int)));
-		// Morton key of the point's cell on the reference grid (cell-level order, stable => deterministic)
-		tnsx::launch_morton_keys(s.d_xyz, s.n, c->world[0], c->world[1], c->world[2], c->cell_size_inv, n_pow2 - 1, c->mkeys[0].as<uint64_t>(),
-		                         s.idx[0].as<uint32_t>(), st);
-		uint64_t* kk[2] = { c->mkeys[0].as<uint64_t>(), c->mkeys[1].as<uint64_t>() };
-		uint32_t* vv[2] = { s.idx[0].as<uint32_t>(), s.idx[1].as<uint32_t>() };
-		const int res = tnsx::radix_sort_pairs_u64(kk, vv, s.n, key_bits, c->sort_temp.p, st);
-		HIPCHK(c, hipMemcpyAsync(s.zsort_dev.p, vv[res], (size_t)s.n * sizeof(int), hipMemcpyDeviceToDevice, st));
-		HIPCHK(c, hipMemcpyAsync(s.zsort_host.data(), vv[res], (size_t)s.n * sizeof(int), hipMemcpyDeviceToHost, st));
-		HIPCHK(c, hipStreamSynchronize(st));
+		// Morton key of the point's cell on the reference grid (cell-level order, stable => deterministic): the same
+		// point-moving radix sort as the search structure, the order is the index column of the sorted points
+		tnsx::CellSortBuffers cb;
+		for (int k = 0; k < 2; k++) { cb.xyzi[k] = s.xyzi[k].as<float4>(); cb.r2[k] = nullptr; }
+		(void)tnsx::launch_morton_sort(s.d_xyz, s.n, mg, key_bits, cb, c->sort_temp.p, s.zsort_dev.as<int>(), st);
+		HIPCHK(c, hipGetLastError());
 	}
-	// idx[] of the search structures was reused as scratch: results of the previous run() stay valid (they do not
-	// depend on it), but the next run() rebuilds everything anyway.
+	HIPCHK(c, hipStreamSynchronize(st));
+	// xyzi[] of the search structures was reused as scratch: results of the previous run() stay valid (they do not
+	// depend on it), and the next run() rebuilds everything anyway.
+	return TNSX_OK;
+}
+
+// host copy of the z-order of one set, made on first use
+static tnsx_status zsort_host_order(tnsx_context* c, PointSet& s)
+{
+	if (s.zsort_host.size() == (size_t)s.zsort_n) return TNSX_OK;
+	s.zsort_host.assign((size_t)s.zsort_n, 0);
+	if (s.zsort_n > 0) {
+		if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
+		HIPCHK(c, hipMemcpyAsync(s.zsort_host.data(), s.zsort_dev.p, (size_t)s.zsort_n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+	}
 	return TNSX_OK;
 }
 
@@ -906,9 +919,9 @@ tnsx_status tnsx_get_zsort_order(tnsx_context* c, int set_i, const int** host, c
 	if (!set_ok(c, set_i)) TNSX_FAIL(c, TNSX_ERR_INVALID, "tns::TreeNSearch::apply_zsort error: set to z_sort does not exit.");
 	PointSet& s = c->sets[set_i];
 	if (!s.zsort_ready) TNSX_FAIL(c, TNSX_ERR_STATE, "tns::TreeNSearch::apply_zsort error: no zsort order ready for set_i (%d).", set_i);
-	if (host) *host = s.zsort_host.data();
+	if (host) { const tnsx_status r = zsort_host_order(c, s); if (r != TNSX_OK) return r; *host = s.zsort_host.data(); }
 	if (dev) *dev = s.zsort_dev.as<int>();
-	if (n) *n = (int)s.zsort_host.size();
+	if (n) *n = s.zsort_n;
 	return TNSX_OK;
 }
 
@@ -918,7 +931,7 @@ tnsx_status tnsx_apply_zsort(tnsx_context* c, int set_i, void* data, size_t elem
 	if (!set_ok(c, set_i)) TNSX_FAIL(c, TNSX_ERR_INVALID, "tns::TreeNSearch::apply_zsort error: set to z_sort does not exit.");
 	PointSet& s = c->sets[set_i];
 	if (!s.zsort_ready) TNSX_FAIL(c, TNSX_ERR_STATE, "tns::TreeNSearch::apply_zsort error: no zsort order ready for set_i (%d).", set_i);
-	const int n = (int)s.zsort_host.size();
+	const int n = s.zsort_n;
 	if (n == 0 || stride <= 0 || elem_bytes == 0) return TNSX_OK;
 	if (!data) TNSX_FAIL(c, TNSX_ERR_INVALID, "apply_zsort: null data pointer");
 	const size_t rec = elem_bytes * (size_t)stride;
@@ -933,6 +946,7 @@ tnsx_status tnsx_apply_zsort(tnsx_context* c, int set_i, void* data, size_t elem
 		// user memory on the host: plain gather through a swap buffer, as TreeNSearch.h:456-480 does
 		std::vector<unsigned char> swap((const unsigned char*)data, (const unsigned char*)data + rec * (size_t)n);
 		unsigned char* dst = (unsigned char*)data;
+		{ const tnsx_status r = zsort_host_order(c, s); if (r != TNSX_OK) return r; }
 		const int* map = s.zsort_host.data();
 		for (int i = 0; i < n; i++) std::memcpy(dst + rec * (size_t)i, swap.data() + rec * (size_t)map[i], rec);
 	}

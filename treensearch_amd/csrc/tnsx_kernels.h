@@ -23,19 +23,8 @@ int  bounds_num_blocks(int n);
 void launch_bounds_partial(const float* xyz, const float* radii, int n, float* partials /*[nb*8]*/, hipStream_t s);
 void launch_bounds_final(const float* partials, int n_partials, float* out8, hipStream_t s);
 
-// ---- keys ---------------------------------------------------------------------------------------
-// Morton keys of the reference grid (TreeNSearch.cpp:713-715 quantisation, libmorton bit order)
-void launch_morton_keys(const float* xyz, int n, float bx, float by, float bz, float cell_size_inv, int max_coord,
-                        uint64_t* keys, uint32_t* idx, hipStream_t s);
-
-// ---- LSD radix sort of (key, value) pairs; stable ------------------------------------------------
-size_t radix_temp_bytes(int n);
-// sorts `key_bits` low bits.  Buffers ping-pong between [0] and [1]; returns the index holding the result.
-int radix_sort_pairs_u64(uint64_t* keys[2], uint32_t* vals[2], int n, int key_bits, void* temp, hipStream_t s);
-
 // ---- exclusive scans ----------------------------------------------------------------------------
 size_t scan_temp_bytes(size_t n);
-void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* temp, hipStream_t s);          // out[n]
 void exclusive_scan_u32_to_u64(const uint32_t* in, uint64_t* out, size_t n, void* temp, hipStream_t s);   // out[n+1], out[n]=total
 
 // ---- build of the search structure of one point set (tnsx_build.hip) ---------------------------------------
@@ -48,6 +37,10 @@ CellSortPlan cell_sort_plan(int key_bits);
 struct CellSortBuffers { float4* xyzi[2]; float* r2[2]; };
 size_t cell_sort_temp_bytes(int n);
 int launch_cell_sort(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, hipStream_t s);
+// The same sort on the Morton code of the point's cell on the REFERENCE grid (TreeNSearch.cpp:713-715 quantisation, libmorton bit
+// order; prepare_zsort): g.ox/oy/oz = world bottom, g.inv_h = 1 / cell size, g.nx = cells per axis (a power of two), 3 * log2(nx)
+// key bits.  order_out[p] = original index of the p-th point in z-order.
+int launch_morton_sort(const float* xyz, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, int* order_out, hipStream_t s);
 // Cell table: table[key] = (first sorted position, one past last); occ = {first sorted position, key} of every occupied cell
 // (order of blocks of 4096 points is arbitrary), *n_occ = their number (must be zeroed before)
 void launch_cell_table(const float4* xyzi_sorted, int n, GridParams g, uint2* table, uint2* occ, uint32_t* n_occ, hipStream_t s);

@@ -124,35 +124,6 @@ __device__ __forceinline__ int cell_coord(float p, float o, float inv_h, int n)
 	c = c < 0 ? 0 : c;
 	return c > n - 1 ? n - 1 : c;
 }
-__device__ __forceinline__ uint64_t spread3(uint64_t v)
-{
-	v &= 0x1fffffull;
-	v = (v | (v << 32)) & 0x1f00000000ffffull;
-	v = (v | (v << 16)) & 0x1f0000ff0000ffull;
-	v = (v | (v << 8)) & 0x100f00f00f00f00full;
-	v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
-	v = (v | (v << 2)) & 0x1249249249249249ull;
-	return v;
-}
-__global__ void __launch_bounds__(256) k_morton_keys(const float* __restrict__ xyz, int n, float bx, float by, float bz, float inv, int max_coord,
-                                                    uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
-{
-	const int i = blockIdx.x * 256 + threadIdx.x;
-	if (i >= n) return;
-	// (uint)((p - bottom) * cell_size_inv), TreeNSearch.cpp:713-715 / :2694-2696; x -> bit 0, y -> bit 1, z -> bit 2 (libmorton)
-	const uint32_t ux = (uint32_t)cell_coord(xyz[3 * (size_t)i], bx, inv, max_coord + 1);
-	const uint32_t uy = (uint32_t)cell_coord(xyz[3 * (size_t)i + 1], by, inv, max_coord + 1);
-	const uint32_t uz = (uint32_t)cell_coord(xyz[3 * (size_t)i + 2], bz, inv, max_coord + 1);
-	keys[i] = spread3(ux) | (spread3(uy) << 1) | (spread3(uz) << 2);
-	idx[i] = (uint32_t)i;
-}
-void launch_morton_keys(const float* xyz, int n, float bx, float by, float bz, float cell_size_inv, int max_coord, uint64_t* keys,
-                        uint32_t* idx, hipStream_t s)
-{
-	if (n <= 0) return;
-	hipLaunchKernelGGL(k_morton_keys, dim3((n + 255) / 256), dim3(256), 0, s, xyz, n, bx, by, bz, cell_size_inv, max_coord, keys, idx);
-}
-
 // =====================================================================================================
 // exclusive scan (reduce -> spine -> apply), tiles of 4096 elements, 16-byte vector loads
 // =====================================================================================================
@@ -258,125 +229,7 @@ static void scan_impl(const uint32_t* in, TOut* out, size_t n, void* temp, hipSt
 	hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, sums, nb);
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<TOut>), dim3(nb), dim3(SCAN_THREADS), 0, s, in, out, n, sums, nb, write_total);
 }
-void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* temp, hipStream_t s) { scan_impl<uint32_t>(in, out, n, temp, s, 0); }
 void exclusive_scan_u32_to_u64(const uint32_t* in, uint64_t* out, size_t n, void* temp, hipStream_t s) { scan_impl<uint64_t>(in, out, n, temp, s, 1); }
-
-// =====================================================================================================
-// LSD radix sort of (key, value) pairs, 8-bit digits, stable (used by prepare_zsort; the search structure has its own
-// sort in tnsx_build.hip).  Per pass: per-block digit histogram -> scan -> ranked scatter.
-// A block owns a tile of 4096 consecutive elements; wave w owns the 1024-element sub-tile w and walks it
-// in 16 rounds of 64 consecutive elements, so (wave, round, lane) order == index order == stable order.
-// =====================================================================================================
-static constexpr int RS_BITS = 8;
-static constexpr int RS_RADIX = 1 << RS_BITS;
-static constexpr int RS_THREADS = 256;
-static constexpr int RS_ITEMS = 16;
-static constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
-
-static int rs_num_blocks(int n) { return (n + RS_TILE - 1) / RS_TILE; }
-size_t radix_temp_bytes(int n)
-{
-	const size_t hist = (size_t)RS_RADIX * rs_num_blocks(n) * sizeof(uint32_t);
-	return ((hist + 255) / 256) * 256 * 2 + scan_temp_bytes((size_t)RS_RADIX * rs_num_blocks(n)) + 256;
-}
-
-template <typename KeyT>
-__global__ void __launch_bounds__(RS_THREADS) k_radix_hist(const KeyT* __restrict__ keys, int n, int shift, uint32_t* __restrict__ hist, int nblocks)
-{
-	__shared__ uint32_t h[RS_RADIX];
-	h[threadIdx.x] = 0;
-	__syncthreads();
-	const size_t base = (size_t)blockIdx.x * RS_TILE;
-	#pragma unroll
-	for (int i = 0; i < RS_ITEMS; i++) {
-		const size_t e = base + (size_t)i * RS_THREADS + threadIdx.x;
-		if (e < (size_t)n) atomicAdd(&h[(uint32_t)(keys[e] >> shift) & (RS_RADIX - 1)], 1u);
-	}
-	__syncthreads();
-	hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
-}
-
-template <typename KeyT>
-__global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                             KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n, int shift,
-                                                             const uint32_t* __restrict__ hist_scanned, int nblocks)
-{
-	__shared__ uint32_t wcount[RS_THREADS / WAVE][RS_RADIX];
-	__shared__ uint32_t gbase[RS_RADIX];
-	const int w = threadIdx.x / WAVE, lane = lane_id();
-	#pragma unroll
-	for (int ww = 0; ww < RS_THREADS / WAVE; ww++) wcount[ww][threadIdx.x] = 0;
-	gbase[threadIdx.x] = hist_scanned[(size_t)threadIdx.x * nblocks + blockIdx.x];
-	__syncthreads();
-
-	KeyT key[RS_ITEMS];
-	uint32_t val[RS_ITEMS];
-	uint32_t rank[RS_ITEMS];
-	const size_t wbase = (size_t)blockIdx.x * RS_TILE + (size_t)w * (RS_ITEMS * WAVE);
-	#pragma unroll
-	for (int i = 0; i < RS_ITEMS; i++) {
-		const size_t e = wbase + (size_t)i * WAVE + lane;
-		const bool valid = e < (size_t)n;
-		key[i] = valid ? keys_in[e] : (KeyT)0;
-		val[i] = valid ? vals_in[e] : 0u;
-		const uint32_t d = (uint32_t)(key[i] >> shift) & (RS_RADIX - 1);
-		uint64_t peers = __ballot(valid);
-		#pragma unroll
-		for (int b = 0; b < RS_BITS; b++) {
-			const bool bit = (d >> b) & 1u;
-			const uint64_t m = __ballot(valid && bit);
-			peers &= bit ? m : ~m;
-		}
-		const uint32_t r = mbcnt64(peers);                 // peers in lower lanes
-		const uint32_t c = (uint32_t)__popcll(peers);
-		uint32_t prev = 0;
-		if (valid) prev = wcount[w][d];
-		wave_lds_fence();
-		if (valid && r == 0) wcount[w][d] = prev + c;
-		wave_lds_fence();
-		rank[i] = prev + r;
-	}
-	__syncthreads();
-	{
-		const int d = threadIdx.x;
-		uint32_t s = 0;
-		#pragma unroll
-		for (int ww = 0; ww < RS_THREADS / WAVE; ww++) { const uint32_t t = wcount[ww][d]; wcount[ww][d] = s; s += t; }
-	}
-	__syncthreads();
-	#pragma unroll
-	for (int i = 0; i < RS_ITEMS; i++) {
-		const size_t e = wbase + (size_t)i * WAVE + lane;
-		if (e < (size_t)n) {
-			const uint32_t d = (uint32_t)(key[i] >> shift) & (RS_RADIX - 1);
-			const uint32_t pos = gbase[d] + wcount[w][d] + rank[i];
-			keys_out[pos] = key[i];
-			vals_out[pos] = val[i];
-		}
-	}
-}
-
-template <typename KeyT>
-static int radix_sort_impl(KeyT* keys[2], uint32_t* vals[2], int n, int key_bits, void* temp, hipStream_t s)
-{
-	if (n <= 1 || key_bits <= 0) return 0;
-	const int nblocks = rs_num_blocks(n);
-	const size_t hist_elems = (size_t)RS_RADIX * nblocks;
-	const size_t hist_bytes = ((hist_elems * sizeof(uint32_t) + 255) / 256) * 256;
-	uint32_t* hist = (uint32_t*)temp;
-	uint32_t* hist_scanned = (uint32_t*)((char*)temp + hist_bytes);
-	void* scan_temp = (char*)temp + 2 * hist_bytes;
-	int cur = 0;
-	for (int shift = 0; shift < key_bits; shift += RS_BITS) {
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<KeyT>), dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], n, shift, hist, nblocks);
-		exclusive_scan_u32(hist, hist_scanned, hist_elems, scan_temp, s);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<KeyT>), dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
-		                   vals[cur ^ 1], n, shift, hist_scanned, nblocks);
-		cur ^= 1;
-	}
-	return cur;
-}
-int radix_sort_pairs_u64(uint64_t* keys[2], uint32_t* vals[2], int n, int key_bits, void* temp, hipStream_t s) { return radix_sort_impl<uint64_t>(keys, vals, n, key_bits, temp, s); }
 
 // =====================================================================================================
 // permutation of fixed-size byte records (device-side apply_zsort, TreeNSearch.h:465-480)
