@@ -73,6 +73,19 @@ class SlabExchange:
             if not grown:
                 return (self._send_buf[0][:cl + 1] if has_l else None), (self._send_buf[1][:cr + 1] if has_r else None)
 
+    def _message(self, peer, msg, rows):
+        """The first `rows` rows of the buffer behind `msg` when it is that large (device path: the pack buffer itself, rows past
+        the count are unspecified), else a copy padded to `rows`."""
+        side = 0 if peer < self.rank else 1
+        buf = self._send_buf[side]
+        if buf is not None and buf.data_ptr() == msg.data_ptr() and buf.shape[0] >= rows:
+            return buf[:rows]
+        if msg.shape[0] >= rows:
+            return msg[:rows]
+        out = torch.empty((rows, msg.shape[1]), dtype=msg.dtype, device=msg.device)
+        out[:msg.shape[0]] = msg
+        return out
+
     def exchange(self, pts: torch.Tensor, gids: torch.Tensor, radii: Optional[torch.Tensor] = None):
         """pts (n,3) float32, gids (n,) int64 global ids, radii (n,) float32 or None.
         -> (ghost_pts (m,3), ghost_gids (m,), ghost_radii (m,) or None)
@@ -129,12 +142,7 @@ class SlabExchange:
         out1, in1 = {}, {}
         for p in peers:
             cs, cr = self._caps.get(p, (0, 0))
-            k = min(n_out[p], cs)
-            if send[p].shape[0] >= cs + 1:
-                out1[p] = send[p][:cs + 1]                     # a prefix of the (larger) pack buffer: no copy
-            else:
-                out1[p] = torch.empty((cs + 1, W), dtype=torch.float32, device=dev)
-                out1[p][:k + 1] = send[p][:k + 1]
+            out1[p] = self._message(p, send[p], cs + 1)
             in1[p] = torch.empty((cr + 1, W), dtype=torch.float32, device=dev)
         round_trip(out1, in1)
         n_in = {p: int(in1[p].view(torch.int32)[0, 0].item()) for p in peers}
