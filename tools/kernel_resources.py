@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Prints VGPR/SGPR/scratch/LDS/occupancy per kernel of treensearch_amd/csrc/tnsx_kernels.hip (gfx950)."""
+"""Prints VGPR/SGPR/scratch/LDS/occupancy per kernel of one source file of treensearch_amd/csrc (gfx950).
+env: TNSX_SRC = file name (default tnsx_kernels.hip), TNSX_EXTRA_FLAGS = extra compiler flags (as for treensearch_amd.build)."""
 import re, subprocess, sys, os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-x", "hip", "-I" + root + "/include",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"] + os.environ.get("TNSX_EXTRA_FLAGS", "").split() + ["-x", "hip", "-I" + root + "/include",
        "-c", root + "/treensearch_amd/csrc/" + (os.environ.get("TNSX_SRC", "tnsx_kernels.hip")), "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = {}
