@@ -201,3 +201,46 @@ def test_sparse_domain_and_lazy_table_clear(oracle):
         ns.run()
         P.assert_same_csr(ns.neighbor_csr(0, 0), oracle.pair_search(pts, pts, radius=r, same_set=True), f"sparse step {step + 1}")
         assert ns.get_stats()["n_pool_pairs"] == 1
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# size-independent properties at full size (no oracle, no fixture): they hold for ANY correct neighbour search
+# ------------------------------------------------------------------------------------------------------------------
+def _pair_moments(offs, idx):
+    """Two order-independent 64-bit moments of the directed pair set {(i, j)}: sum a_i * b_j and sum b_i * a_j (wrapping)."""
+    n = len(offs) - 1
+    rng = np.random.default_rng(99)
+    a = rng.integers(1, 1 << 62, n, dtype=np.uint64)
+    b = rng.integers(1, 1 << 62, n, dtype=np.uint64)
+    counts = np.diff(offs).astype(np.int64)
+    with np.errstate(over="ignore"):
+        sb = np.add.reduceat(b[idx], offs[:-1][counts > 0]) if len(idx) else np.zeros(0, np.uint64)   # sum of b_j over the list of i
+        sa = np.add.reduceat(a[idx], offs[:-1][counts > 0]) if len(idx) else np.zeros(0, np.uint64)
+        nz = counts > 0
+        return np.sum(a[nz] * sb, dtype=np.uint64), np.sum(b[nz] * sa, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("n", [1_000_000, 4_000_000])   # (the 10 M cloud is checked against the reference itself above)
+def test_full_size_properties_symmetry_idempotence_self_exclusion(n):
+    """Fixed radius, one set: (i, j) is a pair <=> (j, i) is (the fp32 predicate is symmetric under negation of the
+    difference vector); no point is its own neighbour; list entries are distinct; a second run() returns the same sets."""
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    pts = torch.from_numpy(D.uniform_cloud(n, 2024)).cuda()
+    ns = T.TreeNSearch()
+    ns.set_search_radius(D.radius_for_neighbors(n))
+    ns.add_point_set(pts)
+    ns.set_active_search(0, 0, True)
+    ns.run()
+    offs, idx = ns.neighbor_csr(0, 0)                       # lists ascending
+    assert offs[-1] == len(idx) and len(offs) == n + 1
+    m_ij, m_ji = _pair_moments(offs, idx)
+    assert m_ij == m_ji, "pair set is not symmetric"
+    owner = np.repeat(np.arange(n, dtype=idx.dtype), np.diff(offs))
+    assert not np.any(idx == owner), "a point lists itself"
+    inner = np.ones(len(idx), bool); inner[offs[1:-1][offs[1:-1] < len(idx)]] = False
+    assert np.all(np.diff(idx.astype(np.int64))[inner[1:]] > 0), "duplicate or unsorted entries inside a list"
+    ns.run()
+    offs2, idx2 = ns.neighbor_csr(0, 0)
+    assert np.array_equal(offs, offs2) and np.array_equal(idx, idx2), "second run differs"
