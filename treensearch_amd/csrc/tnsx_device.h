@@ -35,4 +35,36 @@ __device__ __forceinline__ uint64_t spread3(uint64_t v)
 	v = (v | (v << 2)) & 0x1249249249249249ull;
 	return v;
 }
+// Wave-wide bounding box: min of (x0,y0,z0) and max of (x1,y1,z1) over the 64 lanes, returned wave-uniform.  Six values are
+// reduced together, one DPP step at a time, so that the five instructions between a write and its DPP read cover the two
+// wait states gfx9 needs there (the compiler does not look into inline asm).  v_min/v_max ignore NaN operands.
+__device__ __forceinline__ void wave_bbox(float& x0, float& y0, float& z0, float& x1, float& y1, float& z1)
+{
+#define TNSX_DPP_STEP(pre, ctl)                                                                                          \
+	asm volatile(pre "v_min_f32_dpp %0, %0, %0 " ctl "\n\tv_min_f32_dpp %1, %1, %1 " ctl "\n\tv_min_f32_dpp %2, %2, %2 " ctl "\n\t" \
+	                 "v_max_f32_dpp %3, %3, %3 " ctl "\n\tv_max_f32_dpp %4, %4, %4 " ctl "\n\tv_max_f32_dpp %5, %5, %5 " ctl          \
+	             : "+v"(x0), "+v"(y0), "+v"(z0), "+v"(x1), "+v"(y1), "+v"(z1))
+	TNSX_DPP_STEP("s_nop 1\n\t", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+	TNSX_DPP_STEP("", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+	TNSX_DPP_STEP("", "row_half_mirror row_mask:0xf bank_mask:0xf");
+	TNSX_DPP_STEP("", "row_mirror row_mask:0xf bank_mask:0xf");
+	TNSX_DPP_STEP("", "row_bcast:15 row_mask:0xa bank_mask:0xf");
+	TNSX_DPP_STEP("", "row_bcast:31 row_mask:0xc bank_mask:0xf");
+#undef TNSX_DPP_STEP
+	asm volatile("s_nop 1" ::: );
+	x0 = readlane_f32(x0, 63); y0 = readlane_f32(y0, 63); z0 = readlane_f32(z0, 63);
+	x1 = readlane_f32(x1, 63); y1 = readlane_f32(y1, 63); z1 = readlane_f32(z1, 63);
+}
+// wave-wide maximum of one value (same scheme; s_nop between the dependent DPP steps)
+__device__ __forceinline__ float wave_max_dpp(float v)
+{
+	asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+	             : "+v"(v));
+	return readlane_f32(v, 63);
+}
 }  // namespace tnsx

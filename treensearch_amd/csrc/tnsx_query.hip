@@ -28,6 +28,10 @@ namespace tnsx {
 // =====================================================================================================
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+#ifndef TNSX_CULL
+#define TNSX_CULL 1   // first tier: cells with 513..1024 candidates are culled against the bounding box of their query points (fast_cell_culled)
+#endif
+
 
 static constexpr int Q_THREADS = 256;
 static constexpr int Q_WAVES = Q_THREADS / WAVE;
@@ -490,52 +494,17 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 //     and a pointer bump per query;
 //   * no 64-bit compares or offset/pointer conversions inside the loop; the per-lane record pointer is turned into an
 //     offset once per cell.
+// The query loop of one simple cell: NC register-resident candidate chunks (packed pairs) against the nq query points held one
+// per lane in qv / qr2.  Tests, record allocation, emission.
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int NC>
-__device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits)
+__device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits,
+                                                const v2f (&cx)[(NC + 1) / 2], const v2f (&cy)[(NC + 1) / 2], const v2f (&cz)[(NC + 1) / 2],
+                                                const uint32_t (&cid)[2 * ((NC + 1) / 2)], const float (&cr2)[2 * ((NC + 1) / 2)], const float4 qv,
+                                                const float qr2)
 {
 	constexpr int NP = (NC + 1) / 2;
 	const uint32_t nq = cur_q.y - cur_q.x;
-	const Runs R = extract_runs(RR.run_start, RR.run_len);
-	// ---- candidates -> registers (branch-free, see process_batch)
-	v2f cx[NP], cy[NP], cz[NP];
-	uint32_t cid[2 * NP];
-	float cr2[2 * NP];
-	float4 craw[2 * NP];
-	float r2raw[2 * NP];
-	#pragma unroll
-	for (int k = 0; k < 2 * NP; k++) {
-		if (k < NC) {
-			const uint32_t slot = (uint32_t)(k * WAVE + lane);
-			const uint32_t src = (k < NC - 1 || slot < R.total) ? slot_to_src(slot, R) : R.d0;
-			craw[k] = a.xyzi_j[src];
-			if (SYM) r2raw[k] = a.r2_j[src];
-		}
-	}
-	// the cell's query points, one per lane (clamped, branch-free load)
-	const uint32_t qsrc = cur_q.x + ((uint32_t)lane < nq ? (uint32_t)lane : 0u);
-	const float4 qv = a.xyzi_i[qsrc];
-	float qr2 = a.r2_fixed;
-	if (VARIABLE) qr2 = a.r2_i[qsrc];
 	const uint32_t qidx = __float_as_uint(qv.w);
-	#pragma unroll
-	for (int k = 0; k < 2 * NP; k++) {
-		float4 c = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, __uint_as_float(0xffffffffu));
-		float r2c = -1.0f;
-		if (k < NC) {
-			c = craw[k];
-			if (SYM) r2c = r2raw[k];
-			if (k == NC - 1) {   // the chunk count is exact: only the last chunk can be partial
-				const bool valid = (uint32_t)(k * WAVE + lane) < R.total;
-				c.x = valid ? c.x : FLT_MAX; c.y = valid ? c.y : FLT_MAX; c.z = valid ? c.z : FLT_MAX;
-				c.w = valid ? c.w : __uint_as_float(0xffffffffu);
-				if (SYM) r2c = valid ? r2c : -1.0f;
-			}
-		}
-		cx[k >> 1][k & 1] = c.x; cy[k >> 1][k & 1] = c.y; cz[k >> 1][k & 1] = c.z;
-		cid[k] = __float_as_uint(c.w);
-		cr2[k] = r2c;
-	}
-
 	// ---- allocator state in plain scalars.  Records of this cell go to records[base ...] + pos0 bytes: `base` (64-bit, and the
 	//      buffer resource made from it) changes only when a new slab is taken, everything per query is 32-bit: pos0 (BYTES used
 	//      since `base`), left (ints left in the slab).
@@ -625,6 +594,186 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 	}
 }
 
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int NC>
+__device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits)
+{
+	constexpr int NP = (NC + 1) / 2;
+	const uint32_t nq = cur_q.y - cur_q.x;
+	const Runs R = extract_runs(RR.run_start, RR.run_len);
+	// ---- candidates -> registers (branch-free, see process_batch)
+	v2f cx[NP], cy[NP], cz[NP];
+	uint32_t cid[2 * NP];
+	float cr2[2 * NP];
+	float4 craw[2 * NP];
+	float r2raw[2 * NP];
+	#pragma unroll
+	for (int k = 0; k < 2 * NP; k++) {
+		if (k < NC) {
+			const uint32_t slot = (uint32_t)(k * WAVE + lane);
+			const uint32_t src = (k < NC - 1 || slot < R.total) ? slot_to_src(slot, R) : R.d0;
+			craw[k] = a.xyzi_j[src];
+			if (SYM) r2raw[k] = a.r2_j[src];
+		}
+	}
+	// the cell's query points, one per lane (clamped, branch-free load)
+	const uint32_t qsrc = cur_q.x + ((uint32_t)lane < nq ? (uint32_t)lane : 0u);
+	const float4 qv = a.xyzi_i[qsrc];
+	float qr2 = a.r2_fixed;
+	if (VARIABLE) qr2 = a.r2_i[qsrc];
+	#pragma unroll
+	for (int k = 0; k < 2 * NP; k++) {
+		float4 c = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, __uint_as_float(0xffffffffu));
+		float r2c = -1.0f;
+		if (k < NC) {
+			c = craw[k];
+			if (SYM) r2c = r2raw[k];
+			if (k == NC - 1) {   // the chunk count is exact: only the last chunk can be partial
+				const bool valid = (uint32_t)(k * WAVE + lane) < R.total;
+				c.x = valid ? c.x : FLT_MAX; c.y = valid ? c.y : FLT_MAX; c.z = valid ? c.z : FLT_MAX;
+				c.w = valid ? c.w : __uint_as_float(0xffffffffu);
+				if (SYM) r2c = valid ? r2c : -1.0f;
+			}
+		}
+		cx[k >> 1][k & 1] = c.x; cy[k >> 1][k & 1] = c.y; cz[k >> 1][k & 1] = c.z;
+		cid[k] = __float_as_uint(c.w);
+		cr2[k] = r2c;
+	}
+
+	fast_query_loop<ARITH, VARIABLE, SYM, SELF, NC>(a, RR, lane, cur_q, ps, wave_hits, cx, cy, cz, cid, cr2, qv, qr2);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Bounding-box cull (first tier, cells with 513..1024 candidates: dense fluid, or a cell edge r_max well above most radii).
+// Every candidate is tested once against the bounding box of the cell's query points -- a lower bound of the squared distance
+// in the predicate's own arithmetic.  About a third of the candidates goes, and what is left nearly always fits the eight
+// chunks of the query loop, so these cells stay in the first tier (80 VGPRs, 6 waves per SIMD) instead of the 16-chunk second
+// tier (3 waves).  The candidates are looked at eight chunks at a time, so no more registers are needed than the loop has; only
+// the SLOT NUMBERS of the survivors are staged (2 bytes each in LDS) and the survivors are loaded a second time, from the L2.
+// More than 512 survivors: nothing has been written, the cell goes to the second tier.
+// (For cells that fit the loop anyway the cull was measured to pay nothing: 6.4 -> 4.3 chunks per query, but the staging
+// per cell costs what the shorter loop saves.)
+//
+// Exactness: every fp32 op of the predicate is monotone.  With b = max(fl(lo - c), fl(c - hi), 0) per axis, |fl(q - c)| >= b for
+// every query coordinate q in [lo, hi]; squares, sums and fmas preserve that order, so d2(q, c) >= d2lb(c) for all queries of the
+// cell, and d2lb > (largest radius^2 that can accept the pair) means that the predicate itself rejects the pair.
+// The centre row (slots < R.p1: it holds the cell's own points) is kept as it is, so that the self-exclusion slot stays valid.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int ARITH, bool SYM>
+__device__ __forceinline__ uint32_t cull_round(const QueryArgs& a, const Runs R, int lane, uint32_t base, uint32_t kept, float lox, float loy, float loz,
+                                               float hix, float hiy, float hiz, float r2q_max, uint16_t* __restrict__ lds_slots)
+{
+	const uint32_t nc = (R.total - base + WAVE - 1) / WAVE;   // chunks of this round that hold candidates (the rest is skipped)
+	float4 craw[Q_MAXPAIRS * 2];
+	float r2raw[Q_MAXPAIRS * 2];
+	#pragma unroll
+	for (int k = 0; k < Q_MAXPAIRS * 2; k++) {
+		if ((uint32_t)k < nc) {
+			const uint32_t slot = base + (uint32_t)(k * WAVE + lane);
+			const uint32_t src = slot < R.total ? slot_to_src(slot, R) : R.d0;
+			craw[k] = a.xyzi_j[src];
+			if (SYM) r2raw[k] = a.r2_j[src];
+		}
+	}
+	#pragma unroll
+	for (int k = 0; k < Q_MAXPAIRS * 2; k++) {
+		if ((uint32_t)k < nc) {
+			const uint32_t slot = base + (uint32_t)(k * WAVE + lane);
+			const float4 c = craw[k];
+			const float bx = fmaxf(fmaxf(__fsub_rn(lox, c.x), __fsub_rn(c.x, hix)), 0.0f);
+			const float by = fmaxf(fmaxf(__fsub_rn(loy, c.y), __fsub_rn(c.y, hiy)), 0.0f);
+			const float bz = fmaxf(fmaxf(__fsub_rn(loz, c.z), __fsub_rn(c.z, hiz)), 0.0f);
+			float d2lb;
+			if (ARITH == 0) d2lb = __fadd_rn(__fadd_rn(__fmul_rn(bx, bx), __fmul_rn(by, by)), __fmul_rn(bz, bz));
+			else d2lb = __fmaf_rn(bz, bz, __fmaf_rn(bx, bx, __fmul_rn(by, by)));
+			const float lim = SYM ? fmaxf(r2q_max, r2raw[k]) : r2q_max;
+			const bool keep = slot < R.total && (slot < R.p1 || d2lb <= lim);
+			const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+			const uint32_t pos = kept + mbcnt64(m);
+			if (keep && pos < (uint32_t)Q_SLOTS) lds_slots[pos] = (uint16_t)slot;
+			kept += (uint32_t)__popcll(m);
+		}
+	}
+	return kept;
+}
+
+// the query loop on the `kept` surviving candidates whose slot numbers are in lds_slots
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int NC>
+__device__ __forceinline__ void fast_cell_from_slots(const QueryArgs& a, const RunRef RR, const Runs R, int lane, const uint2 cur_q, PoolState& ps,
+                                                     uint32_t& wave_hits, const uint16_t* __restrict__ lds_slots, uint32_t kept, const float4 qv, const float qr2)
+{
+	constexpr int NP = (NC + 1) / 2;
+	v2f cx[NP], cy[NP], cz[NP];
+	uint32_t cid[2 * NP];
+	float cr2[2 * NP];
+	float4 craw[2 * NP];
+	float r2raw[2 * NP];
+	#pragma unroll
+	for (int k = 0; k < 2 * NP; k++) {
+		if (k < NC) {
+			const uint32_t i = (uint32_t)(k * WAVE + lane);
+			const uint32_t slot = lds_slots[i];                     // (slots past `kept` hold stale numbers: clamped below)
+			const uint32_t src = (k < NC - 1 || i < kept) ? slot_to_src(slot < R.total ? slot : 0u, R) : R.d0;
+			craw[k] = a.xyzi_j[src];
+			if (SYM) r2raw[k] = a.r2_j[src];
+		}
+	}
+	#pragma unroll
+	for (int k = 0; k < 2 * NP; k++) {
+		float4 c = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, __uint_as_float(0xffffffffu));
+		float r2c = -1.0f;
+		if (k < NC) {
+			c = craw[k];
+			if (SYM) r2c = r2raw[k];
+			if (k == NC - 1) {   // the chunk count is exact: only the last chunk can be partial
+				const bool valid = (uint32_t)(k * WAVE + lane) < kept;
+				c.x = valid ? c.x : FLT_MAX; c.y = valid ? c.y : FLT_MAX; c.z = valid ? c.z : FLT_MAX;
+				c.w = valid ? c.w : __uint_as_float(0xffffffffu);
+				if (SYM) r2c = valid ? r2c : -1.0f;
+			}
+		}
+		cx[k >> 1][k & 1] = c.x; cy[k >> 1][k & 1] = c.y; cz[k >> 1][k & 1] = c.z;
+		cid[k] = __float_as_uint(c.w);
+		cr2[k] = r2c;
+	}
+	fast_query_loop<ARITH, VARIABLE, SYM, SELF, NC>(a, RR, lane, cur_q, ps, wave_hits, cx, cy, cz, cid, cr2, qv, qr2);
+}
+
+// -> false: more than Q_SLOTS candidates survive; nothing has been written
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF>
+__device__ __forceinline__ bool fast_cell_culled(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits,
+                                                 uint16_t* __restrict__ lds_slots)
+{
+	const uint32_t nq = cur_q.y - cur_q.x;
+	const Runs R = extract_runs(RR.run_start, RR.run_len);
+	// the cell's query points, one per lane (clamped, branch-free load: the lanes beyond nq repeat the first point)
+	const uint32_t qsrc = cur_q.x + ((uint32_t)lane < nq ? (uint32_t)lane : 0u);
+	const float4 qv = a.xyzi_i[qsrc];
+	float qr2 = a.r2_fixed;
+	if (VARIABLE) qr2 = a.r2_i[qsrc];
+	float lox = qv.x, loy = qv.y, loz = qv.z, hix = qv.x, hiy = qv.y, hiz = qv.z;
+	wave_bbox(lox, loy, loz, hix, hiy, hiz);
+	const float r2q_max = VARIABLE ? wave_max_dpp(qr2) : a.r2_fixed;
+
+	uint32_t kept = 0;
+	for (uint32_t base = 0; base < R.total; base += (uint32_t)Q_SLOTS)
+		kept = readfirstlane_u32(cull_round<ARITH, SYM>(a, R, lane, base, kept, lox, loy, loz, hix, hiy, hiz, r2q_max, lds_slots));
+	if (kept > (uint32_t)Q_SLOTS) return false;
+	wave_lds_fence();
+	switch ((kept + WAVE - 1) / WAVE) {
+	case 0:
+	case 1: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 1>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2); break;
+	case 2: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 2>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2); break;
+	case 3: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 3>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2); break;
+	case 4: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 4>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2); break;
+	case 5: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 5>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2); break;
+	case 6: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 6>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2); break;
+	case 7: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 7>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2); break;
+	default: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 8>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2); break;
+	}
+	wave_lds_fence();   // the next culled cell of this wave overwrites the staging buffer
+	return true;
+}
+
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF, bool FAT>
 __device__ __forceinline__ void fast_cell_nc(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits)
 {
@@ -642,7 +791,7 @@ __device__ __forceinline__ void fast_cell_nc(const QueryArgs& a, const RunRef RR
 		}
 	}
 	else {
-		// 513..1024 candidates (dense cells, or h = r_max much larger than most radii): same single pass, more registers
+		// 513..1024 candidates of which more than 512 survive the first tier's cull: same single pass, more registers
 		switch (nc) {
 		case 9: fast_cell<ARITH, VARIABLE, SYM, SELF, 9>(a, RR, lane, cur_q, ps, wave_hits); break;
 		case 10: fast_cell<ARITH, VARIABLE, SYM, SELF, 10>(a, RR, lane, cur_q, ps, wave_hits); break;
@@ -673,11 +822,13 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 {
 	// FAT = false: cells from the occupied-cell list, 1..8 chunks; the rest -> a.heavy.
 	// FAT = true : cells from a.heavy, 9..16 chunks; the rest -> a.heavy2 (general kernel).
-	constexpr uint32_t MAX_SLOTS = FAT ? 2u * Q_SLOTS : (uint32_t)Q_SLOTS;
 	const uint2* __restrict__ cell_list = FAT ? a.heavy : a.occ_i;
 	uint2* __restrict__ reject_list = FAT ? a.heavy2 : a.heavy;
 	uint32_t* reject_count = FAT ? a.n_heavy2 : a.n_heavy;
 	uint32_t* tickets = FAT ? a.tickets2 : a.tickets;
+	// staging buffer of the bounding-box cull (slot numbers of the survivors), one slice per wave
+	__shared__ uint16_t s_slots[(!FAT && TNSX_CULL) ? Q_WAVES * Q_SLOTS : 2];
+	uint16_t* const my_slots = s_slots + ((!FAT && TNSX_CULL) ? (threadIdx.x / WAVE) * Q_SLOTS : 0);
 	const int lane = lane_id();
 	const uint32_t n_occ = FAT ? *a.n_heavy : *a.n_occ_i;
 	const uint32_t xcd = blockIdx.x & 7u;
@@ -758,12 +909,19 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 		qrange = a.table_i[have_next ? key_next : key];
 
 		const uint32_t nq = cur_q.y - cur_q.x;
-		if (RR.total > MAX_SLOTS || nq > (uint32_t)WAVE || (SELF && (cur_q.y - RR.d_self) > 2u * WAVE)) {
+		bool pass_on = RR.total > 2u * (uint32_t)Q_SLOTS || nq > (uint32_t)WAVE || (SELF && (cur_q.y - RR.d_self) > 2u * WAVE);
+		if (!pass_on && !FAT && RR.total > (uint32_t)Q_SLOTS) {
+			// more candidates than the loop holds: cull them against the bounding box of the query points; the cell is done
+			// here if at most 512 survive
+			pass_on = !(TNSX_CULL && fast_cell_culled<ARITH, VARIABLE, SYM, SELF>(a, RR, lane, cur_q, ps, wave_hits, my_slots));
+		}
+		if (pass_on) {
 			// not for this tier: goes to the next tier's worklist.  Collected one entry per lane and appended 64 at a time: the
 			// worklist length is ONE counter, and e.g. a dense column of fluid sends most of its cells here.
 			if ((uint32_t)lane == rej_n) rej = make_uint2(p0, key);
 			if (++rej_n == (uint32_t)WAVE) { flush_rejects(); rej_n = 0; }
 		}
+		else if (!FAT && RR.total > (uint32_t)Q_SLOTS) { /* done by the culled path above */ }
 		else if (RR.total == 0u) {
 			// no candidate at all (set_j is another, sparser or empty set): nq empty records, one int each
 			bool okz;
