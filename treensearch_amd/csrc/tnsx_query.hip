@@ -28,6 +28,10 @@ namespace tnsx {
 // =====================================================================================================
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+#ifndef TNSX_CULL_FROM
+#define TNSX_CULL_FROM 448   // cells with more candidates than this are culled first (measured: 512 / 448 / 384 -> C2 1.775 / 1.766 / 2.003 ms,
+                             // C3 2.54 / 2.44 / 2.61 ms, C4 at 20 M 5.77 / 5.68 / 5.58 ms)
+#endif
 #ifndef TNSX_CULL
 #define TNSX_CULL 1   // first tier: cells with 513..1024 candidates are culled against the bounding box of their query points (fast_cell_culled)
 #endif
@@ -910,7 +914,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 
 		const uint32_t nq = cur_q.y - cur_q.x;
 		bool pass_on = RR.total > 2u * (uint32_t)Q_SLOTS || nq > (uint32_t)WAVE || (SELF && (cur_q.y - RR.d_self) > 2u * WAVE);
-		if (!pass_on && !FAT && RR.total > (uint32_t)Q_SLOTS) {
+		if (!pass_on && !FAT && RR.total > (uint32_t)TNSX_CULL_FROM) {
 			// more candidates than the loop holds: cull them against the bounding box of the query points; the cell is done
 			// here if at most 512 survive
 			pass_on = !(TNSX_CULL && fast_cell_culled<ARITH, VARIABLE, SYM, SELF>(a, RR, lane, cur_q, ps, wave_hits, my_slots));
@@ -921,7 +925,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 			if ((uint32_t)lane == rej_n) rej = make_uint2(p0, key);
 			if (++rej_n == (uint32_t)WAVE) { flush_rejects(); rej_n = 0; }
 		}
-		else if (!FAT && RR.total > (uint32_t)Q_SLOTS) { /* done by the culled path above */ }
+		else if (!FAT && RR.total > (uint32_t)TNSX_CULL_FROM) { /* done by the culled path above */ }
 		else if (RR.total == 0u) {
 			// no candidate at all (set_j is another, sparser or empty set): nq empty records, one int each
 			bool okz;
