@@ -145,8 +145,10 @@ __global__ void __launch_bounds__(SB_THREADS) k_cs_strip_scan(uint32_t* __restri
 }
 
 // ---- ranked scatter of the points --------------------------------------------------------------------------------
-// FIRST: the point comes from the user's arrays (xyz AoS, radii) and gets its original index attached; r2 = r*r in fp32
-// (TreeNSearch.cpp:2352).  Otherwise it comes from the previous pass.
+// FIRST: the point comes from the user's array (xyz AoS) and gets its original index attached; otherwise it comes from the
+// previous pass.  VARIABLE (last pass only): r2 = r*r in fp32 (TreeNSearch.cpp:2352) is written next to the point, the radius
+// picked up by original index -- carrying it through every pass costs a scattered 4-byte store per point and pass, the expensive
+// kind (measured at 20 M points, two passes: sort 0.77 ms carried, 0.68 ms gathered).
 template <int BITS, bool FIRST, bool VARIABLE, bool MORTON>
 __global__ void __launch_bounds__(CS_THREADS) __attribute__((amdgpu_waves_per_eu(BITS <= 10 ? 4 : 3, 4)))
 k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, const float4* __restrict__ xyzi_in, const float* __restrict__ r2_in,
@@ -178,13 +180,17 @@ k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, con
 		if (FIRST) {
 			const F3 q = (reinterpret_cast<const F3*>(xyz) + lbase)[lc];
 			px[i] = q.x; py[i] = q.y; pz[i] = q.z; pw[i] = __uint_as_float((uint32_t)wbase + li);
-			if (VARIABLE) { const float r = (radii + lbase)[lc]; rr[i] = __fmul_rn(r, r); }
+			if (VARIABLE) { const float r = (radii + lbase)[lc]; rr[i] = __fmul_rn(r, r); }   // single pass: index = position
 		}
 		else {
 			const float4 q = (xyzi_in + lbase)[lc];
 			px[i] = q.x; py[i] = q.y; pz[i] = q.z; pw[i] = q.w;
-			if (VARIABLE) rr[i] = (r2_in + lbase)[lc];
 		}
+	}
+	if (VARIABLE && !FIRST) {
+		// gather by original index (the radii array of a 50 M-point set is 200 MB: it stays in the 256 MB Infinity Cache)
+		#pragma unroll
+		for (int i = 0; i < CS_ITEMS; i++) { const float r = radii[__float_as_uint(pw[i])]; rr[i] = __fmul_rn(r, r); }
 	}
 
 	// global base of every digit value for this tile = (exclusive scan of the totals) + (scanned tile count).  Thread t owns the
@@ -304,7 +310,7 @@ static int point_sort(const float* xyz, const float* radii, int n, GridParams g,
 		const int bits = plan.bits[p];
 		TNSX_CS_DISPATCH(bits, (cs_hist<B, MORTON>(p == 0, xyz, b.xyzi[cur], n, g, shift, hist, ntiles, s)));
 		TNSX_CS_DISPATCH(bits, cs_scan<B>(hist, ntiles, strip_sums, totals, s));
-		TNSX_CS_DISPATCH(bits, (cs_scatter<B, MORTON>(p == 0, variable, xyz, radii, b.xyzi[cur], b.r2[cur], b.xyzi[cur ^ 1], b.r2[cur ^ 1], n, g, shift, hist,
+		TNSX_CS_DISPATCH(bits, (cs_scatter<B, MORTON>(p == 0, variable && p == plan.passes - 1, xyz, radii, b.xyzi[cur], b.r2[cur], b.xyzi[cur ^ 1], b.r2[cur ^ 1], n, g, shift, hist,
 		                                              totals, ntiles, s)));
 		cur ^= 1;
 		shift += bits;
