@@ -650,7 +650,7 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 // Bounding-box cull (first tier, cells with 513..1024 candidates: dense fluid, or a cell edge r_max well above most radii).
 // Every candidate is tested once against the bounding box of the cell's query points -- a lower bound of the squared distance
 // in the predicate's own arithmetic.  About a third of the candidates goes, and what is left nearly always fits the eight
-// chunks of the query loop, so these cells stay in the first tier (80 VGPRs, 6 waves per SIMD) instead of the 16-chunk second
+// chunks of the query loop, so these cells stay in the first tier (5 waves per SIMD) instead of the 16-chunk second
 // tier (3 waves).  The candidates are looked at eight chunks at a time, so no more registers are needed than the loop has; only
 // the SLOT NUMBERS of the survivors are staged (2 bytes each in LDS) and the survivors are loaded a second time, from the L2.
 // More than 512 survivors: nothing has been written, the cell goes to the second tier.
@@ -809,11 +809,12 @@ __device__ __forceinline__ void fast_cell_nc(const QueryArgs& a, const RunRef RR
 	}
 }
 
-// Occupancy of the first tier.  Left alone the compiler takes 85 VGPRs (5 waves per SIMD); capped at 80 it spills eight
-// dwords outside the query loop and runs 6 waves: -7 % (measured with tools/ab_libs.py; 3 / 4 / 5 / 6 waves: 2.11 / 1.92 /
-// 1.94 / 1.80 ms).  The second tier keeps its 3 waves (it needs ~135 VGPRs for 16 chunks).
+// Occupancy of the first tier, pinned: left alone the compiler's register budget changes with every edit of the kernel (85 VGPRs /
+// 5 waves at one point, a slower schedule than either pinned variant).  5 waves per SIMD (<= 96 VGPRs, no spills) against 6 (80
+// VGPRs, a few spilled dwords), measured with tools/ab_libs.py on the final kernel: C2 equal or -4 %, C3 -4 %, C4 -4 %.
+// The second tier keeps its 3 waves (it needs ~135 VGPRs for 16 chunks).
 #ifndef TNSX_FAST_WAVES_PER_EU
-#define TNSX_FAST_WAVES_PER_EU 6
+#define TNSX_FAST_WAVES_PER_EU 5
 #endif
 #ifndef TNSX_FAT_WAVES_PER_EU
 #define TNSX_FAT_WAVES_PER_EU 3
