@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TNSX_VERSION 100
+#define TNSX_VERSION 200
 
 typedef struct tnsx_context tnsx_context;
 
@@ -169,16 +169,36 @@ tnsx_status tnsx_apply_zsort(tnsx_context* ctx, int set_i, void* data, size_t el
 tnsx_status tnsx_get_stats(const tnsx_context* ctx, tnsx_stats* out);
 
 /* ---- multi-GPU support (no counterpart in the single-process reference) ----------------------
- * Ghost-halo selection for a slab decomposition along x: packs every point with x < left_cut into out_left and every
- * point with x >= right_cut into out_right (either may be NULL = side not wanted), as rows of `5 + (radii != NULL)`
- * floats: x, y, z, [r,] and the point's 64-bit global id bit-cast into the last two floats.  All pointers are device
- * memory; rows are appended in no particular order.  counts_dev[0..1] (device scratch) and counts_host[0..1] receive the
- * number of rows the selection HAS (they may exceed capacity_rows: then only capacity_rows rows were written and the
- * caller repeats with larger buffers).  Runs on the context's stream; with counts_host != NULL the call waits for it, with
- * NULL it only enqueues.  Like tnsx_run, it does not wait for work other streams still have in flight on its inputs. */
+ * The slab layer (treensearch_amd/multi.py: one process per GPU, slabs along x, one halo exchange per step over RCCL) is built
+ * from these four device-side pieces; all pointers are device memory and everything runs on the context's stream. */
+
+/* Ghost-halo selection: packs every point with x < left_cut into out_left and every point with x >= right_cut into out_right
+ * (either may be NULL = side not wanted), as rows of `5 + (radii != NULL)` floats: x, y, z, [r,] and the point's 64-bit global
+ * id bit-cast into the last two floats.  Rows are appended in no particular order.  counts_dev[0..1] (device scratch) and
+ * counts_host[0..1] receive the number of rows the selection HAS per side (they may exceed that side's capacity: then only
+ * capacity rows were written and the caller repeats with a larger buffer).  With counts_host != NULL the call waits for the
+ * stream, with NULL it only enqueues.  Like tnsx_run, it does not wait for work other streams still have in flight on its inputs. */
 tnsx_status tnsx_halo_pack(tnsx_context* ctx, const float* xyz, const float* radii, const long long* global_ids, int n_points,
-                           float left_cut, float right_cut, float* out_left, float* out_right, unsigned long long capacity_rows,
-                           unsigned int* counts_dev, unsigned int* counts_host);
+                           float left_cut, float right_cut, float* out_left, float* out_right, unsigned long long capacity_left,
+                           unsigned long long capacity_right, unsigned int* counts_dev, unsigned int* counts_host);
+/* Balanced slab cuts: hist_dev[clamp(trunc((x - x0) * inv_dx), 0, n_bins - 1)] += 1 for every point (the caller zeroes hist_dev,
+ * all-reduces it over the ranks and cuts at the quantiles).  Enqueues only. */
+tnsx_status tnsx_x_histogram(tnsx_context* ctx, const float* xyz, int n_points, float x0, float inv_dx, int n_bins,
+                             unsigned int* hist_dev);
+/* Candidates-only tail: from the next tnsx_run on, only the first n_query points of set_i get neighbour lists; the others are
+ * still found as neighbours (the ghost points a slab appends to its owned points).  n_query < 0: all points (default).  The views
+ * of pairs (set_i -> *) then hold n_points = min(n, n_query) records; offsets of the remaining points are unspecified. */
+tnsx_status tnsx_set_query_count(tnsx_context* ctx, int set_i, int n_query);
+/* User ids: from the next tnsx_run on, the lists of every pair (* -> set_i) hold ids_dev[j] instead of the index j (the global ids
+ * of [owned | ghosts] of a slab, so that nothing is left to translate).  ids_dev: device array with one int per point of the set,
+ * re-read at every run like the coordinates; NULL switches back to indices.  Ids of one set must be distinct when the set is
+ * searched in itself.  Costs one 4-byte gather and one 4-byte store per point in the last pass of the cell sort. */
+tnsx_status tnsx_set_point_ids(tnsx_context* ctx, int set_i, const int* ids_dev);
+/* waits for everything the context has enqueued on its stream (tnsx_halo_pack / tnsx_x_histogram with no host result) */
+tnsx_status tnsx_synchronize(tnsx_context* ctx);
+/* Rewrites every neighbour index j of pair (set_i -> set_j) as id_map_dev[j], in place in HBM (local -> global ids of
+ * [owned | ghosts]); id_map_dev must have one entry per point of set_j.  Waits for completion. */
+tnsx_status tnsx_translate_neighbors(tnsx_context* ctx, int set_i, int set_j, const int* id_map_dev);
 
 #ifdef __cplusplus
 }

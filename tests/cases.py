@@ -23,6 +23,8 @@ class Case:
     active: List[Tuple[int, int]]            # (set_i searches in set_j)
     symmetric: bool = True
     bruteforce_ok: bool = True               # small enough for the O(N^2) reference oracle
+    tns_ok: bool = True                      # inside the regime where the reference's octree itself is valid (SURVEY.md 8c:
+                                             # ceil(r_max / cell) <= 2); False: the truth is BruteforceNSearch alone
     full_lists: int = 0                      # number of leading full lists kept in the fixture
     note: str = ""
     size_class: str = "small"                # small: CPU tests; medium/large: GPU / golden digests only
@@ -85,14 +87,19 @@ def dam_break(n: int, symmetric: bool = True, size_class="small") -> Case:
 
 def variable_two_sets_random(n0: int, n1: int, ratio: float = 2.5, symmetric: bool = True) -> Case:
     """Random coordinates + truly per-point radii on two sets, all four searches active
-    (not covered by the reference's own tests; pinned by BruteforceNSearch)."""
+    (not covered by the reference's own tests; pinned by BruteforceNSearch).  ratio = r_max / r_min; above 3 the reference's
+    octree is outside its valid regime (uint16 pivot underflow) and BruteforceNSearch alone is the truth --
+    this engine must be exact for any ratio."""
     p0 = D.uniform_cloud(n0, 777)
     p1 = D.uniform_cloud(n1, 778) * np.float32(0.9) + np.float32(0.05)
-    rbase = D.radius_for_neighbors(n0 + n1, 30.0)
+    # ~30 neighbours at the smallest radius for the ratio of the first fixtures; wider ratios start smaller so that the lists at
+    # the largest radius stay a few hundred entries long
+    rbase = D.radius_for_neighbors(n0 + n1, 30.0 * min(1.0, (2.5 / ratio) ** 3 * 4.0))
     r0 = (rbase * (1.0 + (ratio - 1.0) * D.uniform01(779, 0, n0))).astype(np.float32)
     r1 = (rbase * (1.0 + (ratio - 1.0) * D.uniform01(780, 0, n1))).astype(np.float32)
-    return Case(f"random_var_{'sym' if symmetric else 'asym'}_{n0}_{n1}", [p0, p1], [r0, r1], None,
-                [(0, 0), (0, 1), (1, 0), (1, 1)], symmetric=symmetric, full_lists=64)
+    name = f"random_var_{'sym' if symmetric else 'asym'}_{n0}_{n1}" + ("" if ratio == 2.5 else f"_ratio{ratio:g}")
+    return Case(name, [p0, p1], [r0, r1], None, [(0, 0), (0, 1), (1, 0), (1, 1)], symmetric=symmetric, full_lists=64 if ratio <= 3.0 else 8,
+                tns_ok=ratio <= 3.0)
 
 
 # ---------------------------------------------------------------- edge cases
@@ -138,6 +145,7 @@ def small_cases() -> List[Case]:
         two_set_asymmetric(80000, 20000),
         dam_break(100000, True), dam_break(100000, False),
         variable_two_sets_random(30000, 10000, 2.5, True), variable_two_sets_random(30000, 10000, 2.5, False),
+        variable_two_sets_random(12000, 6000, 5.0, True), variable_two_sets_random(12000, 6000, 10.0, False),
         edge_duplicates(), edge_empty_and_tiny(), edge_boundary_distance(), edge_far_outlier(),
     ]
 
@@ -146,6 +154,7 @@ def large_cases() -> List[Case]:
     """Digest-only fixtures (generated once from the real reference): scaled / full BASELINE configs."""
     return [
         uniform_fixed(1000000, size_class="medium"),
+        uniform_fixed(2000000, size_class="medium"),          # the scaled instance of configs[4] (slab tests)
         two_set_asymmetric(800000, 200000, size_class="medium"),
         dam_break(1000000, True, size_class="medium"),
         uniform_fixed(10000000, size_class="large"),

@@ -1,0 +1,57 @@
+"""Test infrastructure of the slab tests: a TreeNSearch-shaped stand-in backed by the CPU oracle (the product has no CPU search
+path, so the gloo tests of treensearch_amd/multi.py inject this as their per-rank search backend) and the single-process truth
+the unions of the slabs are compared with."""
+import numpy as np
+
+
+def _np(t):
+    return None if t is None else (t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t))
+
+
+class OracleEngine:
+    """The subset of treensearch_amd.TreeNSearch that SlabSearch uses, on oracle/tns_oracle.c."""
+
+    def __init__(self):
+        from oracle import oracle as O
+        self.orc = O.Oracle()
+        self.sets, self.active, self.radius, self.symmetric, self.res = [], {}, None, True, {}
+        self.query_count, self.ids = {}, {}
+
+    def set_search_radius(self, r): self.radius = np.float32(r)
+    def set_symmetric_search(self, on): self.symmetric = bool(on)
+    def add_point_set(self, pts, radii=None): self.sets.append((pts, radii)); return len(self.sets) - 1
+    def resize_point_set(self, s, pts, radii=None): self.sets[s] = (pts, radii)
+    def set_active_search(self, i, j, on=True): self.active[(i, j)] = bool(on)
+    def set_query_count(self, s, n): self.query_count[s] = int(n)
+    def set_point_ids(self, s, ids): self.ids[s] = ids
+
+    def run(self):
+        self.res = {}
+        for (i, j), on in self.active.items():
+            if not on:
+                continue
+            a, ra = _np(self.sets[i][0]).reshape(-1, 3), _np(self.sets[i][1])
+            b, rb = _np(self.sets[j][0]).reshape(-1, 3), _np(self.sets[j][1])
+            if ra is not None:
+                offs, idx = self.orc.pair_search(a, b, ra=ra, rb=rb, symmetric=self.symmetric, same_set=(i == j))
+            else:
+                offs, idx = self.orc.pair_search(a, b, radius=self.radius, same_set=(i == j))
+            nq = self.query_count.get(i, -1)
+            if nq >= 0:                               # candidates-only tail: no lists for the points behind nq
+                offs = offs[:nq + 1]
+                idx = idx[:offs[-1]]
+            ids = self.ids.get(j)
+            if ids is not None:                       # user ids instead of indices
+                idx = _np(ids).astype(np.int64)[idx]
+            self.res[(i, j)] = (offs, idx)
+
+    def neighbor_csr(self, i, j): return self.res[(i, j)]
+
+
+def reference_lists(orc, sets, i, j, radius, symmetric=True):
+    """(offsets, indices ascending) of pair (i -> j) on the WHOLE cloud; sets = [(points, radii or None)]"""
+    a, ra = sets[i]
+    b, rb = sets[j]
+    if ra is not None:
+        return orc.pair_search(a, b, ra=ra, rb=rb, symmetric=symmetric, same_set=(i == j))
+    return orc.pair_search(a, b, radius=np.float32(radius), same_set=(i == j))

@@ -1,9 +1,11 @@
-"""world_size-2 test (gloo, CPU) of the slab decomposition + ghost-halo exchange of treensearch_amd/multi.py.
+"""Multi-process tests (gloo, CPU) of the slab layer in treensearch_amd/multi.py: decomposition (global AABB, x histogram,
+balanced cuts, redistribution), the ghost-halo exchange and the [owned | ghosts] search with global ids.
 
 The product has no CPU search path, so the per-rank search backend is injected: a stand-in with the TreeNSearch API
-whose run() calls the CPU oracle.  What is under test is the distributed logic: which points are exchanged, the
-64-bit global-id transport, the [owned | ghosts] point set and the translation of its lists back to global
-ids -- the union of the ranks' results must equal the single-process result on the union of the slabs."""
+whose run() calls the CPU oracle (tests/slab_helpers.py).  What is under test is the distributed logic: where the cuts are,
+which points travel, the 64-bit global-id transport, candidates-only ghosts and global ids in the lists -- the union of the
+ranks' results must equal the single-process result on the whole cloud.  tests/test_gpu_slabs.py runs the same SlabSearch
+code on the HIP engine."""
 import os
 import socket
 import sys
@@ -19,34 +21,28 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-
-class OracleEngine:
-    """TreeNSearch-shaped stand-in backed by oracle/tns_oracle.c (test infrastructure only)."""
-
-    def __init__(self):
-        from oracle import oracle as O
-        self.orc = O.Oracle()
-        self.sets, self.active, self.radius, self.res = [], set(), None, {}
-
-    def set_search_radius(self, r): self.radius = np.float32(r)
-    def add_point_set(self, pts, radii=None): self.sets.append(pts); return len(self.sets) - 1
-    def resize_point_set(self, s, pts, radii=None): self.sets[s] = pts
-    def set_active_search(self, i, j, on=True): (self.active.add if on else self.active.discard)((i, j))
-
-    def run(self):
-        self.res = {}
-        for (i, j) in self.active:
-            a = self.sets[i].cpu().numpy().reshape(-1, 3)
-            b = self.sets[j].cpu().numpy().reshape(-1, 3)
-            self.res[(i, j)] = self.orc.pair_search(a, b, radius=self.radius, same_set=(i == j))
-
-    def neighbor_csr(self, i, j): return self.res[(i, j)]
+from slab_helpers import OracleEngine, reference_lists   # noqa: E402
 
 
-def _worker(rank, world, port, n_per_rank, radius, tmpdir):
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fixed slabs (unit cubes side by side), single set, fixed radius: exact one-round / two-round protocol of the exchange
+# ----------------------------------------------------------------------------------------------------------------------
+def _worker_fixed(rank, world, port, n_per_rank, radius, tmpdir):
+    _init(rank, world, port)
     try:
         from treensearch_amd import datagen as D
         from treensearch_amd.multi import SlabSearch
@@ -73,19 +69,11 @@ def _worker(rank, world, port, n_per_rank, radius, tmpdir):
         dist.destroy_process_group()
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
 @pytest.mark.parametrize("world", [2, 3])
 def test_slab_halo_exchange_matches_single_process(world, tmp_path, oracle):
     from treensearch_amd import datagen as D
     n_per_rank, radius = 4000, np.float32(0.09)
-    mp.spawn(_worker, args=(world, _free_port(), n_per_rank, radius, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_fixed, args=(world, _free_port(), n_per_rank, radius, str(tmp_path)), nprocs=world, join=True)
     # single-process truth on the union of all slabs
     allp = []
     for k in range(world):
@@ -109,6 +97,93 @@ def test_slab_halo_exchange_matches_single_process(world, tmp_path, oracle):
         assert n_ghost < n_faces * n_per_rank * float(radius) * 1.5
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# the whole pipeline: arbitrary initial distribution -> global AABB -> histogram -> balanced cuts -> redistribution ->
+# slab search; clustered cloud (unequal cuts), per-point radii, two sets with asymmetric searches
+# ----------------------------------------------------------------------------------------------------------------------
+def _cloud(kind: str, n: int):
+    """(sets, fixed radius or None, max radius): sets = [(points, radii or None)], the GLOBAL cloud (same on every rank)"""
+    from treensearch_amd import datagen as D
+    if kind == "uniform":
+        return [(D.uniform_cloud(n, 99), None)], D.radius_for_neighbors(n, 30.0), None
+    if kind == "clustered_var":
+        pts, radii, r0 = D.dam_break_cloud(n, 7, neighbors=25.0)
+        return [(pts, radii)], None, float(2.0 * r0)
+    if kind == "two_sets":
+        f, b, r = D.two_set_cloud(int(0.8 * n), n - int(0.8 * n), 5)
+        return [(f, None), (b, None)], np.float32(1.2 * float(r) * (60.0 / 30.0) ** (-1 / 3)), None
+    raise ValueError(kind)
+
+
+def _worker_pipeline(rank, world, port, kind, n, tmpdir):
+    _init(rank, world, port)
+    try:
+        from treensearch_amd.multi import SlabDecomposition, SlabSearch
+        sets, radius, max_radius = _cloud(kind, n)
+        halo_r = float(radius) if radius is not None else max_radius
+        # initial distribution: a contiguous index range per rank (nothing to do with space)
+        mine = []
+        for (p, r) in sets:
+            lo, hi = (len(p) * rank) // world, (len(p) * (rank + 1)) // world
+            mine.append((torch.from_numpy(p[lo:hi]), torch.arange(lo, hi, dtype=torch.int64), None if r is None else torch.from_numpy(r[lo:hi])))
+        dec = SlabDecomposition()
+        bounds = dec.global_bounds([m[0] for m in mine])
+        cuts = dec.balanced_cuts([m[0] for m in mine], plane_width=halo_r * 1.001, bounds=bounds)
+        owned = [dec.redistribute(pp, gg, rr, cuts) for (pp, gg, rr) in mine]
+        slab = SlabSearch(float(cuts[rank]), float(cuts[rank + 1]), None if radius is None else float(radius), OracleEngine, max_radius=max_radius)
+        pairs = [(0, 0)] if len(sets) == 1 else [(0, 0), (0, 1)]
+        for (i, j) in pairs:
+            slab.set_active_search(i, j, True)
+        for _ in range(2):
+            slab.step(*[(pp, gg) + ((rr,) if rr is not None else ()) for (pp, gg, rr) in owned])
+        for (i, j) in pairs:
+            offs, nbr = slab.global_neighbors(i, j)
+            np.save(os.path.join(tmpdir, f"offs_{i}{j}_{rank}.npy"), offs)
+            np.save(os.path.join(tmpdir, f"nbr_{i}{j}_{rank}.npy"), nbr)
+        for k, (pp, gg, rr) in enumerate(owned):
+            np.save(os.path.join(tmpdir, f"gids_{k}_{rank}.npy"), gg.numpy())
+        np.save(os.path.join(tmpdir, f"cuts_{rank}.npy"), cuts)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind,n", [(8, "uniform", 24000), (4, "clustered_var", 20000), (3, "two_sets", 15000)])
+def test_decomposition_pipeline_matches_single_process(world, kind, n, tmp_path, oracle):
+    mp.spawn(_worker_pipeline, args=(world, _free_port(), kind, n, str(tmp_path)), nprocs=world, join=True)
+    sets, radius, max_radius = _cloud(kind, n)
+    pairs = [(0, 0)] if len(sets) == 1 else [(0, 0), (0, 1)]
+    cuts = np.load(tmp_path / "cuts_0.npy")
+    for k in range(1, world):
+        assert np.array_equal(cuts, np.load(tmp_path / f"cuts_{k}.npy")), "the ranks disagree on the cuts"
+    assert np.all(np.diff(cuts[1:-1]) > 0)
+    # balance: every slab of set 0 holds about 1/world of the points (plane granularity)
+    owned0 = [np.load(tmp_path / f"gids_0_{k}.npy") for k in range(world)]
+    sizes = np.array([len(g) for g in owned0])
+    assert sizes.sum() == len(sets[0][0]) and len(np.unique(np.concatenate(owned0))) == len(sets[0][0]), "points lost or duplicated"
+    x = sets[0][0][:, 0]
+    for k in range(world):
+        assert np.all((x[owned0[k]] >= cuts[k]) & (x[owned0[k]] < cuts[k + 1])), f"rank {k} owns points outside its slab"
+    if kind == "uniform":
+        assert sizes.max() < 1.35 * sizes.mean(), sizes
+    else:
+        assert len(set(np.round(np.diff(cuts[1:-1]), 6))) > 1 or world <= 3, "clustered cloud, yet equidistant cuts"
+    # lists
+    for (i, j) in pairs:
+        ref_o, ref_i = reference_lists(oracle, sets, i, j, radius)
+        cnt = np.diff(ref_o)
+        for k in range(world):
+            gids = np.load(tmp_path / f"gids_{i}_{k}.npy")
+            o = np.load(tmp_path / f"offs_{i}{j}_{k}.npy")
+            nb = np.load(tmp_path / f"nbr_{i}{j}_{k}.npy")
+            assert np.array_equal(np.diff(o), cnt[gids]), f"pair {i}->{j}, rank {k}: neighbour counts differ"
+            want = np.concatenate([ref_i[ref_o[g]:ref_o[g + 1]] for g in gids]) if len(gids) else np.zeros(0, np.int64)
+            assert np.array_equal(nb, want.astype(np.int64)), f"pair {i}->{j}, rank {k}: global neighbour ids differ"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# single-process pieces
+# ----------------------------------------------------------------------------------------------------------------------
 def test_halo_masks():
     from treensearch_amd.multi import slab_halo_masks
     x = torch.tensor([0.0, 0.04, 0.5, 0.96, 0.999])
@@ -137,3 +212,20 @@ def test_single_rank_has_no_ghosts():
     from oracle import oracle as O
     ro, ri = O.Oracle().pair_search(pts.numpy(), pts.numpy(), radius=np.float32(0.2), same_set=True)
     assert np.array_equal(offs, ro) and np.array_equal(nbr, ri.astype(np.int64))
+
+
+def test_balanced_cuts_single_process():
+    """world 1 has no cuts; the histogram helper agrees with numpy."""
+    from treensearch_amd.multi import SlabDecomposition
+    from treensearch_amd import datagen as D
+    pts = torch.from_numpy(D.uniform_cloud(5000, 3))
+    dec = SlabDecomposition()
+    lo, hi = dec.global_bounds([pts])
+    assert np.allclose(lo, pts.numpy().min(0)) and np.allclose(hi, pts.numpy().max(0))
+    h = dec.x_histogram([pts], float(lo[0]), 0.05, 20).numpy()
+    want = np.bincount(np.clip(((pts.numpy()[:, 0] - lo[0]) * np.float32(1.0 / np.float32(0.05))).astype(np.int64), 0, 19), minlength=20)
+    assert np.array_equal(h, want)
+    cuts = dec.balanced_cuts([pts], 0.05)
+    assert len(cuts) == 2 and cuts[0] == -np.inf and cuts[1] == np.inf
+    own = SlabDecomposition.owner_of(torch.tensor([0.1, 0.5, 0.9]), np.array([-np.inf, 0.3, 0.6, np.inf], np.float32))
+    assert own.tolist() == [0, 1, 2]

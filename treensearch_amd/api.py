@@ -71,7 +71,8 @@ ABI_SYMBOLS = [
     "tnsx_get_n_sets", "tnsx_get_n_points_in_set", "tnsx_get_total_n_points", "tnsx_is_search_active",
     "tnsx_does_set_exist", "tnsx_get_neighborlist_n_bytes",
     "tnsx_run", "tnsx_get_pair_view", "tnsx_mirror_pair_to_host", "tnsx_copy_pair",
-    "tnsx_prepare_zsort", "tnsx_get_zsort_order", "tnsx_apply_zsort", "tnsx_get_stats", "tnsx_halo_pack",
+    "tnsx_prepare_zsort", "tnsx_get_zsort_order", "tnsx_apply_zsort", "tnsx_get_stats",
+    "tnsx_halo_pack", "tnsx_x_histogram", "tnsx_set_query_count", "tnsx_translate_neighbors", "tnsx_set_point_ids", "tnsx_synchronize",
 ]
 
 _lib = None
@@ -100,7 +101,12 @@ def load_library():
     L.tnsx_destroy.restype = None
     L.tnsx_last_error.argtypes = [vp]
     L.tnsx_last_error.restype = C.c_char_p
-    L.tnsx_halo_pack.argtypes = [vp, vp, vp, vp, ci, C.c_float, C.c_float, vp, vp, C.c_ulonglong, vp, C.POINTER(C.c_uint)]
+    L.tnsx_halo_pack.argtypes = [vp, vp, vp, vp, ci, C.c_float, C.c_float, vp, vp, C.c_ulonglong, C.c_ulonglong, vp, C.POINTER(C.c_uint)]
+    L.tnsx_x_histogram.argtypes = [vp, vp, ci, C.c_float, C.c_float, ci, vp]
+    L.tnsx_set_query_count.argtypes = [vp, ci, ci]
+    L.tnsx_translate_neighbors.argtypes = [vp, ci, ci, vp]
+    L.tnsx_set_point_ids.argtypes = [vp, ci, vp]
+    L.tnsx_synchronize.argtypes = [vp]
     L.tnsx_add_point_set.argtypes = [vp, vp, vp, ci, C.c_uint]
     L.tnsx_resize_point_set.argtypes = [vp, ci, vp, vp, ci, C.c_uint]
     L.tnsx_set_search_radius.argtypes = [vp, C.c_float]
@@ -322,20 +328,73 @@ class TreeNSearch:
         return st.as_dict()
 
     # ------------------------------------------------------------------ multi-GPU support
-    def halo_pack(self, pts, gids, radii, left_cut, right_cut, out_left, out_right, counts):
-        """tnsx_halo_pack on device tensors (torch, CUDA): selects the points with x < left_cut / x >= right_cut and appends
-        them as rows [x, y, z, (r,) gid_lo, gid_hi] to out_left / out_right (None = side not wanted).  counts is a 2-element
-        int32 scratch tensor on the device.  Returns (n_left, n_right), the number of selected points per side (may exceed
-        the buffers: then only the first rows were written); the call has completed when it returns."""
+    @staticmethod
+    def _dev_ptr(t, dtype, what):
+        """data pointer of a contiguous CUDA tensor of the given dtype (None passes through)"""
+        if t is None:
+            return None
+        if not (_is_torch(t) and t.is_cuda and t.is_contiguous() and t.dtype == dtype):
+            raise TypeError(f"{what} must be a contiguous CUDA tensor of dtype {dtype}")
+        return C.c_void_p(t.data_ptr())
+
+    def _torch_sync_in(self):
         if self._own_stream:
             import torch
             torch.cuda.current_stream().synchronize()
-        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
-        cap = min(t.shape[0] for t in (out_left, out_right) if t is not None) if (out_left is not None or out_right is not None) else 0
+
+    def halo_pack(self, pts, gids, radii, left_cut, right_cut, out_left, out_right, counts, wait: bool = True):
+        """tnsx_halo_pack on device tensors (torch, CUDA): selects the points with x < left_cut / x >= right_cut and appends
+        them as rows [x, y, z, (r,) gid_lo, gid_hi] to out_left / out_right (None = side not wanted; each side has its own
+        capacity = its number of rows).  counts is a 2-element int32 scratch tensor on the device.  Returns (n_left, n_right), the
+        number of selected points per side (may exceed the buffers: then only the first rows were written); with wait=False the
+        call only enqueues and returns None (the counts are then in `counts` once the stream gets there)."""
+        import torch
+        self._torch_sync_in()
+        f32 = torch.float32
         host = (C.c_uint * 2)()
-        self._check(self._L.tnsx_halo_pack(self._h, ptr(pts), ptr(radii), ptr(gids), int(pts.shape[0]), float(left_cut), float(right_cut),
-                                           ptr(out_left), ptr(out_right), int(cap), ptr(counts), host))
-        return int(host[0]), int(host[1])
+        self._check(self._L.tnsx_halo_pack(
+            self._h, self._dev_ptr(pts, f32, "pts"), self._dev_ptr(radii, f32, "radii"), self._dev_ptr(gids, torch.int64, "gids"),
+            int(pts.shape[0]), float(left_cut), float(right_cut), self._dev_ptr(out_left, f32, "out_left"), self._dev_ptr(out_right, f32, "out_right"),
+            0 if out_left is None else int(out_left.shape[0]), 0 if out_right is None else int(out_right.shape[0]),
+            self._dev_ptr(counts, torch.int32, "counts"), host if wait else None))
+        return (int(host[0]), int(host[1])) if wait else None
+
+    def x_histogram(self, pts, x0: float, inv_dx: float, hist) -> None:
+        """tnsx_x_histogram: hist[clamp(trunc((x - x0) * inv_dx), 0, len(hist) - 1)] += 1 for every point of the CUDA tensor pts
+        (n,3); hist is a CUDA int32 tensor the caller has zeroed.  Enqueued on the engine's stream."""
+        import torch
+        self._torch_sync_in()
+        self._check(self._L.tnsx_x_histogram(self._h, self._dev_ptr(pts, torch.float32, "pts"), int(pts.shape[0]), float(x0), float(inv_dx),
+                                             int(hist.numel()), self._dev_ptr(hist, torch.int32, "hist")))
+
+    def set_query_count(self, set_i: int, n_query: int) -> None:
+        """Only the first n_query points of set_i get neighbour lists from the next run() on (-1: all)."""
+        self._check(self._L.tnsx_set_query_count(self._h, int(set_i), int(n_query)))
+
+    def set_point_ids(self, set_i: int, ids) -> None:
+        """The lists of every pair (* -> set_i) hold ids[j] instead of j from the next run() on (ids: CUDA int32 tensor with one
+        entry per point, re-read at every run; None switches back to indices)."""
+        import torch
+        self._ids_keep = getattr(self, "_ids_keep", {})
+        self._ids_keep[int(set_i)] = ids
+        self._check(self._L.tnsx_set_point_ids(self._h, int(set_i), self._dev_ptr(ids, torch.int32, "ids")))
+
+    def synchronize(self) -> None:
+        """waits for the engine's stream"""
+        self._check(self._L.tnsx_synchronize(self._h))
+
+    def order_after_engine(self) -> None:
+        """Work queued on torch's current stream from now on runs after what the engine has enqueued so far.  Nothing to do when
+        the engine was given that stream; an engine with a stream of its own is waited for."""
+        if self._own_stream:
+            self.synchronize()
+
+    def translate_neighbors(self, set_i: int, set_j: int, id_map) -> None:
+        """Every neighbour index j of pair (set_i -> set_j) becomes id_map[j], in place on the device (id_map: CUDA int32)."""
+        import torch
+        self._torch_sync_in()
+        self._views.pop((set_i, set_j), None)
+        self._check(self._L.tnsx_translate_neighbors(self._h, int(set_i), int(set_j), self._dev_ptr(id_map, torch.int32, "id_map")))
 
     def print_state(self) -> None:
         for k, v in self.get_stats().items():

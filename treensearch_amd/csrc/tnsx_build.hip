@@ -65,13 +65,16 @@ __device__ __forceinline__ int bin_coord(float p, float o, float inv_h, int n)
 	c = c < 0 ? 0 : c;
 	return c > n - 1 ? n - 1 : c;
 }
-// row-major cell key, x fastest: the three x-neighbours of a row are contiguous in sorted order
+// row-major cell key, x fastest: the three x-neighbours of a row are contiguous in sorted order.
+// A point whose x is NaN is NO POINT (the padding rows of a fixed-capacity ghost message, treensearch_amd/multi.py): it gets the
+// key one past the last cell, is sorted behind everything and enters no cell; every comparison with it is false anyway.
 __device__ __forceinline__ uint32_t cell_key(float x, float y, float z, const GridParams& g)
 {
 	const int ix = bin_coord(x, g.ox, g.inv_h, g.nx);
 	const int iy = bin_coord(y, g.oy, g.inv_h, g.ny);
 	const int iz = bin_coord(z, g.oz, g.inv_h, g.nz);
-	return (uint32_t)((iz * g.ny + iy) * g.nx + ix);
+	const uint32_t key = (uint32_t)((iz * g.ny + iy) * g.nx + ix);
+	return x != x ? (uint32_t)(g.nx * g.ny * g.nz) : key;
 }
 // the two sort keys: MORTON = false the cell key of the search grid, MORTON = true the Morton code of the cell on the reference's
 // grid (prepare_zsort; up to 63 bits)
@@ -80,7 +83,7 @@ __device__ __forceinline__ uint64_t sort_key(float x, float y, float z, const Gr
 {
 	if (!MORTON) return cell_key(x, y, z, g);
 	const uint64_t ux = (uint64_t)bin_coord(x, g.ox, g.inv_h, g.nx), uy = (uint64_t)bin_coord(y, g.oy, g.inv_h, g.ny), uz = (uint64_t)bin_coord(z, g.oz, g.inv_h, g.nz);
-	return spread3(ux) | (spread3(uy) << 1) | (spread3(uz) << 2);
+	return x != x ? ~0ull : (spread3(ux) | (spread3(uy) << 1) | (spread3(uz) << 2));   // NaN: behind everything
 }
 
 // ---- per-tile histogram of one digit -----------------------------------------------------------------------------
@@ -153,7 +156,7 @@ template <int BITS, bool FIRST, bool VARIABLE, bool MORTON>
 __global__ void __launch_bounds__(CS_THREADS) __attribute__((amdgpu_waves_per_eu(BITS <= 10 ? 4 : 3, 4)))
 k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, const float4* __restrict__ xyzi_in, const float* __restrict__ r2_in,
              float4* __restrict__ xyzi_out, float* __restrict__ r2_out, int n, GridParams g, int shift, const uint32_t* __restrict__ hist_scanned,
-             const uint32_t* __restrict__ totals, int ntiles)
+             const uint32_t* __restrict__ totals, int ntiles, const int* __restrict__ ids, uint32_t* __restrict__ orig_out)
 {
 	constexpr int RADIX = 1 << BITS;
 	constexpr int PER = RADIX / CS_THREADS;   // digit values per thread in the prefix steps
@@ -254,7 +257,15 @@ k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, con
 	for (int i = 0; i < CS_ITEMS; i++) {
 		if ((uint32_t)(i * WAVE + lane) < rem) {
 			const uint32_t pos = wcount[w][dig_rank[i] & 0xffffu] + (dig_rank[i] >> 16);
-			xyzi_out[pos] = make_float4(px[i], py[i], pz[i], pw[i]);
+			float wv = pw[i];
+			if (ids) {
+				// last pass of a set with user ids (tnsx_set_point_ids): the point carries its ID from here on -- that is what the
+				// query emits -- and its original index goes to a side array (the query needs it for the queries only)
+				const uint32_t o = __float_as_uint(wv);
+				wv = __int_as_float(ids[o]);
+				orig_out[pos] = o;
+			}
+			xyzi_out[pos] = make_float4(px[i], py[i], pz[i], wv);
 			if (VARIABLE) r2_out[pos] = rr[i];
 		}
 	}
@@ -275,11 +286,12 @@ static void cs_scan(uint32_t* hist, int ntiles, uint32_t* strip_sums, uint32_t* 
 }
 template <int BITS, bool MORTON>
 static void cs_scatter(bool first, bool variable, const float* xyz, const float* radii, const float4* xyzi_in, const float* r2_in, float4* xyzi_out,
-                       float* r2_out, int n, const GridParams& g, int shift, const uint32_t* hs, const uint32_t* totals, int ntiles, hipStream_t s)
+                       float* r2_out, int n, const GridParams& g, int shift, const uint32_t* hs, const uint32_t* totals, int ntiles, const int* ids,
+                       uint32_t* orig_out, hipStream_t s)
 {
 #define TNSX_CS_GO(F, V)                                                                                                                       \
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_scatter<BITS, F, V, MORTON>), dim3(cs_grid(ntiles)), dim3(CS_THREADS), 0, s, xyz, radii, xyzi_in, r2_in, xyzi_out, \
-	                   r2_out, n, g, shift, hs, totals, ntiles)
+	                   r2_out, n, g, shift, hs, totals, ntiles, ids, orig_out)
 	if (MORTON) { if (first) TNSX_CS_GO(true, false); else TNSX_CS_GO(false, false); }   // the z-order carries no radii
 	else if (first) { if (variable) TNSX_CS_GO(true, true); else TNSX_CS_GO(true, false); }
 	else            { if (variable) TNSX_CS_GO(false, true); else TNSX_CS_GO(false, false); }
@@ -295,7 +307,8 @@ static void cs_scatter(bool first, bool variable, const float* xyz, const float*
 	}
 
 template <bool MORTON>
-static int point_sort(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, hipStream_t s)
+static int point_sort(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, const int* ids,
+                      uint32_t* orig_out, hipStream_t s)
 {
 	const CellSortPlan plan = cell_sort_plan(key_bits);
 	if (n <= 0) return plan.passes & 1;
@@ -310,16 +323,18 @@ static int point_sort(const float* xyz, const float* radii, int n, GridParams g,
 		const int bits = plan.bits[p];
 		TNSX_CS_DISPATCH(bits, (cs_hist<B, MORTON>(p == 0, xyz, b.xyzi[cur], n, g, shift, hist, ntiles, s)));
 		TNSX_CS_DISPATCH(bits, cs_scan<B>(hist, ntiles, strip_sums, totals, s));
-		TNSX_CS_DISPATCH(bits, (cs_scatter<B, MORTON>(p == 0, variable && p == plan.passes - 1, xyz, radii, b.xyzi[cur], b.r2[cur], b.xyzi[cur ^ 1], b.r2[cur ^ 1], n, g, shift, hist,
-		                                              totals, ntiles, s)));
+		const bool last = p == plan.passes - 1;
+		TNSX_CS_DISPATCH(bits, (cs_scatter<B, MORTON>(p == 0, variable && last, xyz, radii, b.xyzi[cur], b.r2[cur], b.xyzi[cur ^ 1], b.r2[cur ^ 1], n, g, shift, hist,
+		                                              totals, ntiles, last ? ids : nullptr, orig_out, s)));
 		cur ^= 1;
 		shift += bits;
 	}
 	return cur;
 }
-int launch_cell_sort(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, hipStream_t s)
+int launch_cell_sort(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, const int* ids,
+                     uint32_t* orig_sorted, hipStream_t s)
 {
-	return point_sort<false>(xyz, radii, n, g, key_bits, b, temp, s);
+	return point_sort<false>(xyz, radii, n, g, key_bits, b, temp, ids, orig_sorted, s);
 }
 
 __global__ void __launch_bounds__(256) k_extract_order(const float4* __restrict__ xyzi, int n, int* __restrict__ order)
@@ -329,7 +344,7 @@ __global__ void __launch_bounds__(256) k_extract_order(const float4* __restrict_
 }
 int launch_morton_sort(const float* xyz, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, int* order_out, hipStream_t s)
 {
-	const int res = point_sort<true>(xyz, nullptr, n, g, key_bits, b, temp, s);
+	const int res = point_sort<true>(xyz, nullptr, n, g, key_bits, b, temp, nullptr, nullptr, s);
 	if (n > 0) hipLaunchKernelGGL(k_extract_order, dim3((n + 255) / 256), dim3(256), 0, s, b.xyzi[res], n, order_out);
 	return res;
 }
@@ -349,6 +364,7 @@ __global__ void __launch_bounds__(CT_THREADS) k_cell_table(const float4* __restr
 	__shared__ uint32_t block_base;
 	const int w = threadIdx.x / WAVE;
 	const size_t base = (size_t)blockIdx.x * CT_TILE;
+	const uint32_t n_cells = (uint32_t)(g.nx * g.ny * g.nz);
 	#pragma unroll
 	for (int i = 0; i < CT_ITEMS; i++) {
 		const size_t p = base + (size_t)i * CT_THREADS + threadIdx.x;
@@ -365,10 +381,12 @@ __global__ void __launch_bounds__(CT_THREADS) k_cell_table(const float4* __restr
 		bool is_start = false;
 		if (p < (size_t)n) {
 			const uint32_t k = sk[1 + t];
-			is_start = (p == 0) || (sk[t] != k);
-			const bool is_end = (p == (size_t)n - 1) || (sk[2 + t] != k);
-			if (is_start) table[k].x = (uint32_t)p;
-			if (is_end) table[k].y = (uint32_t)p + 1u;
+			if (k < n_cells) {                           // (k == n_cells: NaN points, behind all cells; they enter no cell)
+				is_start = (p == 0) || (sk[t] != k);
+				const bool is_end = (p == (size_t)n - 1) || (sk[2 + t] != k);
+				if (is_start) table[k].x = (uint32_t)p;
+				if (is_end) table[k].y = (uint32_t)p + 1u;
+			}
 		}
 		flags |= (is_start ? 1u : 0u) << i;
 		const uint64_t m = __builtin_amdgcn_ballot_w64(is_start);

@@ -70,8 +70,13 @@ struct PointSet {
 	const void* user_xyz = nullptr;
 	const void* user_radii = nullptr;
 	int n = 0;
-	bool is_double = false;
+	int n_query = -1;              // tnsx_set_query_count: only points [0, n_query) get lists (-1: all)
+	const int* user_ids = nullptr; // tnsx_set_point_ids: device array, ids[j] is what the lists hold instead of j
+	DevBuf orig_sorted;            // original index by sorted position (only with user ids: the sorted points then carry the id)
+	bool is_double = false;        // dtype / memory space of the coordinate array ...
 	bool on_device = false;
+	bool radii_double = false;     // ... and of the radii array (kept separately: a points-only resize may change the former only)
+	bool radii_on_device = false;
 	bool has_radii = false;
 	// staging (host inputs and/or double inputs)
 	DevBuf raw_xyz, raw_radii;       // uploaded user bytes (host inputs)
@@ -97,6 +102,7 @@ struct PointSet {
 struct PairResult {
 	bool valid = false;
 	int n_i = 0;
+	int n_query = 0;             // points of set i that have a list: min(n_i, tnsx_set_query_count)
 	uint64_t n_records = 0;      // ints of `records` in use (pool mode: including slab holes)
 	uint64_t n_neighbors = 0;
 	uint64_t need_hint = 0;      // neighbours + points of the previous run: sizes the pool of the next one
@@ -171,28 +177,31 @@ void new_point_set(tnsx_context* c)
 // world box update, TreeNSearch.cpp:474-521 (shared by the scalar and SIMD versions)
 tnsx_status update_world_box(tnsx_context* c, const float tight[6])
 {
-	float* bottom = c->world; float* top = c->world + 3;
-	if (bottom[0] <= tight[0] && tight[3] <= top[0] && bottom[1] <= tight[1] && tight[4] <= top[1] && bottom[2] <= tight[2] && tight[5] <= top[2]) {
+	const float* wb = c->world; const float* wt = c->world + 3;
+	if (wb[0] <= tight[0] && tight[3] <= wt[0] && wb[1] <= tight[1] && tight[4] <= wt[1] && wb[2] <= tight[2] && tight[5] <= wt[2]) {
 		return TNSX_OK;
 	}
+	// computed into temporaries: the stored box changes only when the new one is legal (the reference exits here; this engine
+	// returns an error and must stay consistent for the next call)
+	float bottom[3], top[3], center[3];
 	for (int d = 0; d < 3; d++) { bottom[d] = tight[d]; top[d] = tight[3 + d]; }
-	float center[3];
 	for (int d = 0; d < 3; d++) center[d] = 0.5f * (top[d] + bottom[d]);
 	float length = 0.0f;
 	for (int d = 0; d < 3; d++) length = std::max(length, top[d] - bottom[d]);
 	length += 100.0f * std::numeric_limits<float>::epsilon();
 	length *= 1.1f;   // domain_enlargment, TreeNSearch.h:401
-	const int n_cells = (int)(length / c->cell_size) + 1;
+	const float cells_f = length / c->cell_size;
+	if (!(cells_f < 32768.0f)) {   // (also catches inf / NaN; the cast below would be undefined for them)
+		TNSX_FAIL(c, TNSX_ERR_GRID_TOO_LARGE, "TreeNSearch error: Max allowed cells per dimension is 32768 (2^15). Use set_cell_size() to set a larger value.");
+	}
+	const int n_cells = (int)cells_f + 1;
 	int n_pow2 = 1;
 	while (n_pow2 < n_cells) n_pow2 *= 2;
 	length = c->cell_size * (float)n_pow2;
 	c->world_cells_pow2 = n_pow2;
-	if (n_pow2 > 32768) {
-		TNSX_FAIL(c, TNSX_ERR_GRID_TOO_LARGE, "TreeNSearch error: Max allowed cells per dimension is 32768 (2^15). Use set_cell_size() to set a larger value.");
-	}
 	for (int d = 0; d < 3; d++) {
-		bottom[d] = center[d] - 0.5f * length;
-		top[d] = center[d] + 0.5f * length;
+		c->world[d] = center[d] - 0.5f * length;
+		c->world[3 + d] = center[d] + 0.5f * length;
 	}
 	return TNSX_OK;
 }
@@ -205,27 +214,29 @@ tnsx_status stage_inputs(tnsx_context* c)
 		if (s.n == 0) continue;
 		if (!s.user_xyz) TNSX_FAIL(c, TNSX_ERR_INVALID, "point set with n > 0 has a null coordinate pointer");
 		const size_t esz = s.is_double ? sizeof(double) : sizeof(float);
+		const size_t resz = s.radii_double ? sizeof(double) : sizeof(float);
 		const void* dx = s.user_xyz;
 		const void* dr = s.user_radii;
+		if (s.has_radii && !s.user_radii) TNSX_FAIL(c, TNSX_ERR_INVALID, "variable-radius point set with n > 0 has a null radii pointer");
 		if (!s.on_device) {
 			HIPCHK(c, s.raw_xyz.reserve(3 * (size_t)s.n * esz));
 			HIPCHK(c, hipMemcpyAsync(s.raw_xyz.p, s.user_xyz, 3 * (size_t)s.n * esz, hipMemcpyHostToDevice, c->stream));
 			dx = s.raw_xyz.p;
-			if (s.has_radii) {
-				HIPCHK(c, s.raw_radii.reserve((size_t)s.n * esz));
-				HIPCHK(c, hipMemcpyAsync(s.raw_radii.p, s.user_radii, (size_t)s.n * esz, hipMemcpyHostToDevice, c->stream));
-				dr = s.raw_radii.p;
-			}
+		}
+		if (s.has_radii && !s.radii_on_device) {
+			HIPCHK(c, s.raw_radii.reserve((size_t)s.n * resz));
+			HIPCHK(c, hipMemcpyAsync(s.raw_radii.p, s.user_radii, (size_t)s.n * resz, hipMemcpyHostToDevice, c->stream));
+			dr = s.raw_radii.p;
 		}
 		if (s.is_double) {
 			HIPCHK(c, s.f32_xyz.reserve(3 * (size_t)s.n * sizeof(float)));
 			tnsx::launch_f64_to_f32((const double*)dx, s.f32_xyz.as<float>(), 3 * (size_t)s.n, c->stream);
 			dx = s.f32_xyz.p;
-			if (s.has_radii) {
-				HIPCHK(c, s.f32_radii.reserve((size_t)s.n * sizeof(float)));
-				tnsx::launch_f64_to_f32((const double*)dr, s.f32_radii.as<float>(), (size_t)s.n, c->stream);
-				dr = s.f32_radii.p;
-			}
+		}
+		if (s.has_radii && s.radii_double) {
+			HIPCHK(c, s.f32_radii.reserve((size_t)s.n * sizeof(float)));
+			tnsx::launch_f64_to_f32((const double*)dr, s.f32_radii.as<float>(), (size_t)s.n, c->stream);
+			dr = s.f32_radii.p;
 		}
 		s.d_xyz = (const float*)dx;
 		s.d_radii = s.has_radii ? (const float*)dr : nullptr;
@@ -381,9 +392,9 @@ int tnsx_add_point_set(tnsx_context* c, const void* xyz, const void* radii, int 
 	new_point_set(c);
 	PointSet& s = c->sets.back();
 	s.user_xyz = xyz; s.user_radii = radii; s.n = n;
-	s.is_double = (flags & TNSX_F64) != 0;
-	s.on_device = (flags & TNSX_DEVICE) != 0;
-	s.has_radii = radii != nullptr || false;
+	s.is_double = s.radii_double = (flags & TNSX_F64) != 0;
+	s.on_device = s.radii_on_device = (flags & TNSX_DEVICE) != 0;
+	s.has_radii = radii != nullptr;
 	// a set declared through the radii overload is a variable-radius set even when n == 0 and radii == nullptr
 	// (tests.cpp:453 hands null pointers for empty sets); the caller flags that case with TNSX_VARIABLE.
 	if (flags & TNSX_VARIABLE) s.has_radii = true;
@@ -402,9 +413,15 @@ tnsx_status tnsx_resize_point_set(tnsx_context* c, int set_id, const void* xyz, 
 		TNSX_FAIL(c, TNSX_ERR_INVALID, "TreeNSearch::resize_point_set error: Cannot resize a set with a radii array if it previously didn't have one.");
 	}
 	s.user_xyz = xyz; s.n = n;
-	if (with_radii) s.user_radii = radii;
 	s.is_double = (flags & TNSX_F64) != 0;
 	s.on_device = (flags & TNSX_DEVICE) != 0;
+	if (with_radii) {
+		// the flags describe the arrays handed over in THIS call; a points-only resize keeps the stored radii pointer together with
+		// the dtype / memory space it was registered with (the reference keeps set_radii and set_radii_double apart, TreeNSearch.h:379-383)
+		s.user_radii = radii;
+		s.radii_double = s.is_double;
+		s.radii_on_device = s.on_device;
+	}
 	s.zsort_ready = false;
 	return TNSX_OK;
 }
@@ -558,7 +575,7 @@ tnsx_status tnsx_run(tnsx_context* c)
 	else { g.nx = g.ny = g.nz = 1; g.inv_h = 1.0f; }
 	S.grid_dims[0] = g.nx; S.grid_dims[1] = g.ny; S.grid_dims[2] = g.nz;
 	S.n_grid_cells = n_cells;
-	const int key_bits = std::max(1, ceil_log2_u64(n_cells));
+	const int key_bits = std::max(1, ceil_log2_u64(n_cells + 1));   // + 1: the key behind the last cell, where NaN points ("no point") go
 	S.key_bits = key_bits;
 	S.radix_passes = tnsx::cell_sort_plan(key_bits).passes;
 
@@ -587,7 +604,9 @@ tnsx_status tnsx_run(tnsx_context* c)
 		tnsx::CellSortBuffers cb;
 		for (int k = 0; k < 2; k++) { cb.xyzi[k] = s.xyzi[k].as<float4>(); cb.r2[k] = s.r2[k].as<float>(); }
 		const int t1 = tm.mark();
-		s.sorted_buf = tnsx::launch_cell_sort(s.d_xyz, variable ? s.d_radii : nullptr, s.n, g, key_bits, cb, c->sort_temp.p, st);
+		if (s.user_ids) HIPCHK(c, s.orig_sorted.reserve((size_t)s.n * sizeof(uint32_t)));
+		s.sorted_buf = tnsx::launch_cell_sort(s.d_xyz, variable ? s.d_radii : nullptr, s.n, g, key_bits, cb, c->sort_temp.p, s.user_ids,
+		                                      s.user_ids ? s.orig_sorted.as<uint32_t>() : nullptr, st);
 		const int t2 = tm.mark();
 		tnsx::launch_cell_table(cb.xyzi[s.sorted_buf], s.n, g, s.table.as<uint2>(), s.occ.as<uint2>(), c->n_occ.as<uint32_t>() + si, st);
 		const int t3 = tm.mark();
@@ -614,8 +633,10 @@ tnsx_status tnsx_run(tnsx_context* c)
 		a.occ_i = A.occ.as<uint2>(); a.n_occ_i = c->n_occ.as<uint32_t>() + jb.i;
 		a.table_i = A.table.as<uint2>();
 		a.xyzi_i = A.xyzi[A.sorted_buf].as<float4>(); a.r2_i = A.r2[A.sorted_buf].as<float>();
+		a.orig_i = A.user_ids ? A.orig_sorted.as<uint32_t>() : nullptr;
 		a.table_j = B.table.as<uint2>(); a.xyzi_j = B.xyzi[B.sorted_buf].as<float4>(); a.r2_j = B.r2[B.sorted_buf].as<float>();
 		a.r2_fixed = c->radius_sq;
+		a.query_limit = A.n_query < 0 ? 0xffffffffu : (uint32_t)A.n_query;
 		a.g = g;
 		a.counts = pr.counts.as<uint32_t>();
 		a.offs_sorted = pr.offs_sorted.as<uint64_t>();
@@ -668,6 +689,7 @@ tnsx_status tnsx_run(tnsx_context* c)
 		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
 		const int n_i = c->sets[jb.i].n;
 		pr.n_i = n_i;
+		pr.n_query = c->sets[jb.i].n_query < 0 ? n_i : std::min(n_i, c->sets[jb.i].n_query);
 		HIPCHK(c, pr.offs_orig.reserve((size_t)std::max(n_i, 1) * sizeof(uint64_t)));
 		jb.pool = !c->opt.exact_layout && n_i > 0;
 		if (jb.pool) {
@@ -713,7 +735,7 @@ tnsx_status tnsx_run(tnsx_context* c)
 				if (pr.dry) {
 					// the dry pass counted every neighbour: size the real pass exactly
 					pr.dry = false;
-					const tnsx_status r = size_pool(pr, h_ctrl[2 * k + 1] + (uint64_t)pr.n_i);
+					const tnsx_status r = size_pool(pr, h_ctrl[2 * k + 1] + (uint64_t)pr.n_query);
 					if (r != TNSX_OK) return r;
 				}
 				else {
@@ -731,7 +753,7 @@ tnsx_status tnsx_run(tnsx_context* c)
 		}
 		else {
 			pr.n_records = h_ctrl[2 * k];
-			n_neighbors = pr.n_records - (uint64_t)pr.n_i;
+			n_neighbors = pr.n_records - (uint64_t)pr.n_query;
 			HIPCHK(c, pr.records.reserve(std::max<uint64_t>(pr.n_records, 1) * sizeof(int)));
 			const int t0 = tm.mark();
 			if (pr.n_i > 0) {
@@ -742,9 +764,9 @@ tnsx_status tnsx_run(tnsx_context* c)
 			span(ST_FILL, t0, t1);
 		}
 		pr.n_neighbors = n_neighbors;
-		pr.need_hint = n_neighbors + (uint64_t)pr.n_i;
+		pr.need_hint = n_neighbors + (uint64_t)pr.n_query;
 		pr.valid = true;
-		S.n_queries += (uint64_t)pr.n_i;
+		S.n_queries += (uint64_t)pr.n_query;
 		S.n_neighbors += n_neighbors;
 		if (jb.pool) S.n_pool_pairs++;
 	}
@@ -760,8 +782,8 @@ tnsx_status tnsx_run(tnsx_context* c)
 			PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
 			HIPCHK(c, pr.h_offs.reserve((size_t)std::max(pr.n_i, 1) * sizeof(uint64_t)));
 			HIPCHK(c, pr.h_records.reserve(std::max<uint64_t>(pr.n_records, 1) * sizeof(int)));
-			if (pr.n_i > 0) {
-				HIPCHK(c, hipMemcpyAsync(pr.h_offs.p, pr.offs_orig.p, (size_t)pr.n_i * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+			if (pr.n_query > 0) {
+				HIPCHK(c, hipMemcpyAsync(pr.h_offs.p, pr.offs_orig.p, (size_t)pr.n_query * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
 				HIPCHK(c, hipMemcpyAsync(pr.h_records.p, pr.records.p, pr.n_records * sizeof(int), hipMemcpyDeviceToHost, st));
 			}
 			pr.mirrored = true;
@@ -813,8 +835,8 @@ tnsx_status tnsx_mirror_pair_to_host(tnsx_context* c, int i, int j)
 	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
 	HIPCHK(c, pr->h_offs.reserve((size_t)std::max(pr->n_i, 1) * sizeof(uint64_t)));
 	HIPCHK(c, pr->h_records.reserve(std::max<uint64_t>(pr->n_records, 1) * sizeof(int)));
-	if (pr->n_i > 0) {
-		HIPCHK(c, hipMemcpyAsync(pr->h_offs.p, pr->offs_orig.p, (size_t)pr->n_i * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+	if (pr->n_query > 0) {
+		HIPCHK(c, hipMemcpyAsync(pr->h_offs.p, pr->offs_orig.p, (size_t)pr->n_query * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipMemcpyAsync(pr->h_records.p, pr->records.p, pr->n_records * sizeof(int), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 	}
@@ -827,7 +849,7 @@ tnsx_status tnsx_get_pair_view(tnsx_context* c, int i, int j, tnsx_csr_view* out
 	if (!c || !out) return TNSX_ERR_INVALID;
 	PairResult* pr = nullptr;
 	{ const tnsx_status r = find_pair(c, i, j, &pr); if (r != TNSX_OK) return r; }
-	out->n_points = pr->n_i;
+	out->n_points = pr->n_query;
 	out->n_records = pr->n_records;
 	out->n_neighbors = pr->n_neighbors;
 	out->offsets_device = pr->offs_orig.as<uint64_t>();
@@ -844,9 +866,23 @@ tnsx_status tnsx_copy_pair(tnsx_context* c, int i, int j, uint64_t* offsets_dst,
 	{ const tnsx_status r = find_pair(c, i, j, &pr); if (r != TNSX_OK) return r; }
 	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
 	const hipMemcpyKind kind = dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-	if (offsets_dst && pr->n_i > 0) HIPCHK(c, hipMemcpyAsync(offsets_dst, pr->offs_orig.p, (size_t)pr->n_i * sizeof(uint64_t), kind, c->stream));
+	if (offsets_dst && pr->n_query > 0) HIPCHK(c, hipMemcpyAsync(offsets_dst, pr->offs_orig.p, (size_t)pr->n_query * sizeof(uint64_t), kind, c->stream));
 	if (records_dst && pr->n_records > 0) HIPCHK(c, hipMemcpyAsync(records_dst, pr->records.p, pr->n_records * sizeof(int), kind, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return TNSX_OK;
+}
+
+tnsx_status tnsx_translate_neighbors(tnsx_context* c, int i, int j, const int* id_map_dev)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	PairResult* pr = nullptr;
+	{ const tnsx_status r = find_pair(c, i, j, &pr); if (r != TNSX_OK) return r; }
+	if (!id_map_dev) TNSX_FAIL(c, TNSX_ERR_INVALID, "tnsx_translate_neighbors: null id map");
+	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
+	tnsx::launch_translate_records(pr->records.as<int>(), pr->offs_orig.as<uint64_t>(), pr->n_query, id_map_dev, c->n_cus, c->stream);
+	HIPCHK(c, hipGetLastError());
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	pr->mirrored = false;   // a host mirror made before holds the untranslated indices
 	return TNSX_OK;
 }
 
@@ -954,14 +990,14 @@ tnsx_status tnsx_apply_zsort(tnsx_context* c, int set_i, void* data, size_t elem
 }
 
 tnsx_status tnsx_halo_pack(tnsx_context* c, const float* xyz, const float* radii, const long long* global_ids, int n_points, float left_cut,
-                           float right_cut, float* out_left, float* out_right, unsigned long long capacity_rows, unsigned int* counts_dev,
-                           unsigned int* counts_host)
+                           float right_cut, float* out_left, float* out_right, unsigned long long capacity_left, unsigned long long capacity_right,
+                           unsigned int* counts_dev, unsigned int* counts_host)
 {
 	if (!c) return TNSX_ERR_INVALID;
 	if (n_points < 0 || !counts_dev || (n_points > 0 && (!xyz || !global_ids))) TNSX_FAIL(c, TNSX_ERR_INVALID, "tnsx_halo_pack: null pointer or negative size");
 	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
 	HIPCHK(c, hipMemsetAsync(counts_dev, 0, 2 * sizeof(unsigned int), c->stream));
-	tnsx::launch_halo_pack(xyz, radii, global_ids, n_points, left_cut, right_cut, out_left, out_right, capacity_rows, counts_dev, c->stream);
+	tnsx::launch_halo_pack(xyz, radii, global_ids, n_points, left_cut, right_cut, out_left, out_right, capacity_left, capacity_right, counts_dev, c->stream);
 	HIPCHK(c, hipGetLastError());
 	if (counts_host) {
 		HIPCHK(c, c->h_small.reserve(64));
@@ -970,6 +1006,40 @@ tnsx_status tnsx_halo_pack(tnsx_context* c, const float* xyz, const float* radii
 		counts_host[0] = c->h_small.as<unsigned int>()[0];
 		counts_host[1] = c->h_small.as<unsigned int>()[1];
 	}
+	return TNSX_OK;
+}
+
+tnsx_status tnsx_x_histogram(tnsx_context* c, const float* xyz, int n_points, float x0, float inv_dx, int n_bins, unsigned int* hist_dev)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	if (n_points < 0 || n_bins <= 0 || !hist_dev || (n_points > 0 && !xyz)) TNSX_FAIL(c, TNSX_ERR_INVALID, "tnsx_x_histogram: null pointer or bad size");
+	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
+	tnsx::launch_x_histogram(xyz, n_points, x0, inv_dx, n_bins, hist_dev, c->stream);
+	HIPCHK(c, hipGetLastError());
+	return TNSX_OK;
+}
+
+tnsx_status tnsx_set_point_ids(tnsx_context* c, int set_i, const int* ids_dev)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	if (!set_ok(c, set_i)) TNSX_FAIL(c, TNSX_ERR_INVALID, "tnsx_set_point_ids: set does not exist (%d)", set_i);
+	c->sets[set_i].user_ids = ids_dev;
+	return TNSX_OK;
+}
+
+tnsx_status tnsx_synchronize(tnsx_context* c)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return TNSX_OK;
+}
+
+tnsx_status tnsx_set_query_count(tnsx_context* c, int set_i, int n_query)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	if (!set_ok(c, set_i)) TNSX_FAIL(c, TNSX_ERR_INVALID, "tnsx_set_query_count: set does not exist (%d)", set_i);
+	c->sets[set_i].n_query = n_query < 0 ? -1 : n_query;
 	return TNSX_OK;
 }
 

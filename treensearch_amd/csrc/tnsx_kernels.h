@@ -36,7 +36,10 @@ struct CellSortPlan { int passes; int bits[8]; };
 CellSortPlan cell_sort_plan(int key_bits);
 struct CellSortBuffers { float4* xyzi[2]; float* r2[2]; };
 size_t cell_sort_temp_bytes(int n);
-int launch_cell_sort(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, hipStream_t s);
+// ids != nullptr (tnsx_set_point_ids): the sorted points carry ids[original index] instead of the original index (that is what
+// the query emits), and orig_sorted[sorted position] receives the original index.
+int launch_cell_sort(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, const int* ids,
+                     uint32_t* orig_sorted, hipStream_t s);
 // The same sort on the Morton code of the point's cell on the REFERENCE grid (TreeNSearch.cpp:713-715 quantisation, libmorton bit
 // order; prepare_zsort): g.ox/oy/oz = world bottom, g.inv_h = 1 / cell size, g.nx = cells per axis (a power of two), 3 * log2(nx)
 // key bits.  order_out[p] = original index of the p-th point in z-order.
@@ -52,9 +55,11 @@ struct QueryArgs {
 	// query set i
 	const uint2* occ_i; const uint32_t* n_occ_i; const uint2* table_i;
 	const float4* xyzi_i; const float* r2_i;
+	const uint32_t* orig_i;   // original index by sorted position of set i, or nullptr: it is the w component of xyzi_i (no user ids)
 	// candidate set j
 	const uint2* table_j; const float4* xyzi_j; const float* r2_j;
 	float r2_fixed;
+	uint32_t query_limit;   // only query points with original index < query_limit get lists (the rest of set i are candidates only)
 	GridParams g;
 	// count pass: counts[p] = n_neighbours + 1 (record length), by sorted position of set i
 	uint32_t* counts;
@@ -90,9 +95,14 @@ struct QueryConfig {
 };
 void launch_query(const QueryArgs& a, const QueryConfig& c, int n_compute_units, hipStream_t s);
 
-// ---- ghost-halo selection of a slab decomposition along x (tnsx_kernels.hip); counts[2] must be zeroed before
+// ---- multi-GPU slab support (tnsx_kernels.hip) ----------------------------------------------------------------------
+// ghost-halo selection of a slab decomposition along x; counts[2] must be zeroed before
 void launch_halo_pack(const float* xyz, const float* radii, const long long* gids, int n, float left_cut, float right_cut, float* out_left,
-                      float* out_right, unsigned long long capacity_rows, unsigned int* counts, hipStream_t s);
+                      float* out_right, unsigned long long cap_left, unsigned long long cap_right, unsigned int* counts, hipStream_t s);
+// hist[clamp(trunc((x - x0) * inv_dx), 0, n_bins - 1)] += 1 for every point (hist is NOT zeroed here)
+void launch_x_histogram(const float* xyz, int n, float x0, float inv_dx, int n_bins, unsigned int* hist, hipStream_t s);
+// list entries j of the records of the first n_query points -> id_map[j], in place
+void launch_translate_records(int* records, const uint64_t* offs_by_orig, int n_query, const int* id_map, int n_cus, hipStream_t s);
 
 // ---- permutation of byte records: out[new] = in[perm[new]] ------------------------------------------
 void launch_permute_bytes(const void* in, void* out, const int* new_to_old, int n, size_t rec_bytes, hipStream_t s);

@@ -114,17 +114,6 @@ void launch_bounds_final(const float* partials, int n_partials, float* out8, hip
 }
 
 // =====================================================================================================
-// keys
-// =====================================================================================================
-__device__ __forceinline__ int cell_coord(float p, float o, float inv_h, int n)
-{
-	// fp32 sub, mul, truncate -- the same quantisation form as TreeNSearch.cpp:713-715
-	const float f = __fmul_rn(__fsub_rn(p, o), inv_h);
-	int c = (int)f;
-	c = c < 0 ? 0 : c;
-	return c > n - 1 ? n - 1 : c;
-}
-// =====================================================================================================
 // exclusive scan (reduce -> spine -> apply), tiles of 4096 elements, 16-byte vector loads
 // =====================================================================================================
 static constexpr int SCAN_THREADS = 256;
@@ -270,7 +259,7 @@ static constexpr int HP_ITEMS = 16;
 template <bool WITH_R>
 __global__ void __launch_bounds__(256) k_halo_pack(const float* __restrict__ xyz, const float* __restrict__ radii, const long long* __restrict__ gids, int n,
                                                    float left_cut, float right_cut, float* __restrict__ out_left, float* __restrict__ out_right,
-                                                   unsigned long long capacity, unsigned int* __restrict__ counts)
+                                                   unsigned long long cap_left, unsigned long long cap_right, unsigned int* __restrict__ counts)
 {
 	constexpr int COLS = WITH_R ? 6 : 5;
 	__shared__ uint32_t wcnt[2][HP_ITEMS * 4];   // [side][round * 4 + wave] -> exclusive prefix inside the tile
@@ -304,7 +293,7 @@ __global__ void __launch_bounds__(256) k_halo_pack(const float* __restrict__ xyz
 			const bool take = (flags >> (2 * i + side)) & 1u;
 			const uint64_t m = __ballot(take);
 			const unsigned long long row = (unsigned long long)bbase[side] + wcnt[side][i * 4 + w] + mbcnt64(m);
-			if (take && row < capacity) {
+			if (take && row < (side == 0 ? cap_left : cap_right)) {
 				float* o = (side == 0 ? out_left : out_right) + row * COLS;
 				o[0] = xyz[3 * p]; o[1] = xyz[3 * p + 1]; o[2] = xyz[3 * p + 2];
 				if (WITH_R) o[3] = radii[p];
@@ -316,12 +305,71 @@ __global__ void __launch_bounds__(256) k_halo_pack(const float* __restrict__ xyz
 	}
 }
 void launch_halo_pack(const float* xyz, const float* radii, const long long* gids, int n, float left_cut, float right_cut, float* out_left,
-                      float* out_right, unsigned long long capacity_rows, unsigned int* counts, hipStream_t s)
+                      float* out_right, unsigned long long cap_left, unsigned long long cap_right, unsigned int* counts, hipStream_t s)
 {
 	if (n <= 0 || (!out_left && !out_right)) return;
 	const dim3 grid((n + 256 * HP_ITEMS - 1) / (256 * HP_ITEMS)), block(256);
-	if (radii) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_halo_pack<true>), grid, block, 0, s, xyz, radii, gids, n, left_cut, right_cut, out_left, out_right, capacity_rows, counts);
-	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_halo_pack<false>), grid, block, 0, s, xyz, radii, gids, n, left_cut, right_cut, out_left, out_right, capacity_rows, counts);
+	if (radii) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_halo_pack<true>), grid, block, 0, s, xyz, radii, gids, n, left_cut, right_cut, out_left, out_right, cap_left, cap_right, counts);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_halo_pack<false>), grid, block, 0, s, xyz, radii, gids, n, left_cut, right_cut, out_left, out_right, cap_left, cap_right, counts);
+}
+
+// =====================================================================================================
+// x-plane histogram (multi-GPU slabs: balanced cuts).  hist[b] += points with clamp(trunc((x - x0) * inv_dx), 0, n_bins - 1) == b.
+// Every block keeps a private copy of the bins in LDS (n_bins <= XH_LDS_BINS) and adds its non-zero bins to the global
+// histogram at the end; wider histograms go straight to global atomics.
+// =====================================================================================================
+static constexpr int XH_LDS_BINS = 8192;
+template <bool LDS>
+__global__ void __launch_bounds__(256) k_x_histogram(const float* __restrict__ xyz, int n, float x0, float inv_dx, int n_bins, unsigned int* __restrict__ hist)
+{
+	__shared__ unsigned int h[LDS ? XH_LDS_BINS : 1];
+	if (LDS) {
+		for (int b = threadIdx.x; b < n_bins; b += 256) h[b] = 0u;
+		__syncthreads();
+	}
+	for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < (size_t)n; p += (size_t)gridDim.x * 256) {
+		const float x = xyz[3 * p];
+		if (x != x) continue;                                   // NaN: no point
+		int b = (int)__fmul_rn(__fsub_rn(x, x0), inv_dx);
+		b = b < 0 ? 0 : (b > n_bins - 1 ? n_bins - 1 : b);
+		atomicAdd(LDS ? &h[b] : &hist[b], 1u);
+	}
+	if (LDS) {
+		__syncthreads();
+		for (int b = threadIdx.x; b < n_bins; b += 256) { const unsigned int v = h[b]; if (v) atomicAdd(&hist[b], v); }
+	}
+}
+void launch_x_histogram(const float* xyz, int n, float x0, float inv_dx, int n_bins, unsigned int* hist, hipStream_t s)
+{
+	if (n <= 0 || n_bins <= 0) return;
+	int blocks = (n + 256 * 16 - 1) / (256 * 16);
+	blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+	if (n_bins <= XH_LDS_BINS) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_x_histogram<true>), dim3(blocks), dim3(256), 0, s, xyz, n, x0, inv_dx, n_bins, hist);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_x_histogram<false>), dim3(blocks), dim3(256), 0, s, xyz, n, x0, inv_dx, n_bins, hist);
+}
+
+// =====================================================================================================
+// neighbour-id translation: every list entry j of the first n_query records becomes id_map[j] (in place).  One wave per
+// record at a time (a record is ~60 consecutive ints: one coalesced read-modify-write), waves grid-stride over the points.
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_translate_records(int* __restrict__ records, const uint64_t* __restrict__ offs_by_orig, int n_query,
+                                                          const int* __restrict__ id_map)
+{
+	const int lane = lane_id();
+	const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) / WAVE, n_waves = (size_t)gridDim.x * (256 / WAVE);
+	for (size_t p = wave; p < (size_t)n_query; p += n_waves) {
+		int* rec = records + offs_by_orig[p];
+		const int cnt = rec[0];
+		for (int k = lane; k < cnt; k += WAVE) rec[1 + k] = id_map[rec[1 + k]];
+	}
+}
+void launch_translate_records(int* records, const uint64_t* offs_by_orig, int n_query, const int* id_map, int n_cus, hipStream_t s)
+{
+	if (n_query <= 0) return;
+	long long blocks = ((long long)n_query + 3) / 4;
+	const long long cap = (long long)n_cus * 32;
+	if (blocks > cap) blocks = cap;
+	hipLaunchKernelGGL(k_translate_records, dim3((unsigned)blocks), dim3(256), 0, s, records, offs_by_orig, n_query, id_map);
 }
 
 }  // namespace tnsx

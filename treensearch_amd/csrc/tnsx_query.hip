@@ -63,13 +63,13 @@ struct Runs {
 	uint32_t p1, p2, p3, p4, p5, p6, p7, p8;        // first slot of run r (run 0 starts at slot 0)
 	uint32_t d0, d1, d2, d3, d4, d5, d6, d7, d8;    // sorted position = slot + d_r
 	uint32_t total;
+	uint32_t p9, d9;                                // tenth run (own-cell-first order of the fast kernels, see extract_runs_own_first)
 };
 
 // What stays live across the query loop: the two VGPRs the 18 scalars are extracted from, plus two scalars.
 struct RunRef {
 	uint32_t run_start, run_len;   // per lane; lanes 0,3,..,24 hold run 0..8
 	uint32_t total;                // wave-uniform: number of candidates
-	uint32_t d_self;               // wave-uniform: sorted position of slot 0 = start of the centre run (holds the query cell itself)
 };
 
 __device__ __forceinline__ Runs extract_runs(uint32_t run_start, uint32_t run_len)
@@ -100,6 +100,52 @@ __device__ __forceinline__ uint32_t slot_to_src(uint32_t slot, const Runs R)
 	d = slot >= R.p6 ? R.d6 : d;
 	d = slot >= R.p7 ? R.d7 : d;
 	d = slot >= R.p8 ? R.d8 : d;
+	return slot + d;
+}
+
+// Slot order of the fast kernels when the query set is the candidate set: the query cell's OWN points come
+// first, so query t of the cell is candidate slot t -- always chunk 0, bit t -- and self exclusion is one scalar bit-clear
+// per query with no state.  The centre row [x-1 | own | x+1] (contiguous in sorted order) is split into
+// run 0 = [own | x+1] and run 1 = [x-1]; the other eight rows follow: ten runs, nine selects per slot.
+// (measured against the centre-row-first order with a self bit that is shifted along: C2 -8.6 %, C3 -5 %, C4 -2.5 % on the query)
+__device__ __forceinline__ Runs extract_runs_own_first(uint32_t run_start, uint32_t run_len, uint32_t q_first)
+{
+	Runs R;
+	uint32_t acc, rs, rn;
+	rs = readlane_u32(run_start, 12); rn = readlane_u32(run_len, 12);   // centre row
+	R.d0 = q_first; acc = rs + rn - q_first;                             // [own | x+1]
+	R.p1 = acc; R.d1 = rs - acc; acc += q_first - rs;                    // [x-1]
+#define TNSX_RUN(r, P, D)                                                       \
+	rs = readlane_u32(run_start, 3 * r); rn = readlane_u32(run_len, 3 * r); \
+	P = acc; D = rs - acc; acc += rn;
+	TNSX_RUN(0, R.p2, R.d2) TNSX_RUN(1, R.p3, R.d3) TNSX_RUN(2, R.p4, R.d4) TNSX_RUN(3, R.p5, R.d5)
+	TNSX_RUN(5, R.p6, R.d6) TNSX_RUN(6, R.p7, R.d7) TNSX_RUN(7, R.p8, R.d8) TNSX_RUN(8, R.p9, R.d9)
+#undef TNSX_RUN
+	R.total = acc;
+	return R;
+}
+template <bool OWN_FIRST>
+__device__ __forceinline__ Runs extract_runs_t(uint32_t run_start, uint32_t run_len, uint32_t q_first)
+{
+	if (OWN_FIRST) return extract_runs_own_first(run_start, run_len, q_first);
+	Runs R = extract_runs(run_start, run_len);
+	R.p9 = R.total; R.d9 = 0;
+	return R;
+}
+template <bool OWN_FIRST>
+__device__ __forceinline__ uint32_t slot_to_src_t(uint32_t slot, const Runs R)
+{
+	if (!OWN_FIRST) return slot_to_src(slot, R);
+	uint32_t d = R.d0;
+	d = slot >= R.p1 ? R.d1 : d;
+	d = slot >= R.p2 ? R.d2 : d;
+	d = slot >= R.p3 ? R.d3 : d;
+	d = slot >= R.p4 ? R.d4 : d;
+	d = slot >= R.p5 ? R.d5 : d;
+	d = slot >= R.p6 ? R.d6 : d;
+	d = slot >= R.p7 ? R.d7 : d;
+	d = slot >= R.p8 ? R.d8 : d;
+	d = slot >= R.p9 ? R.d9 : d;
 	return slot + d;
 }
 
@@ -182,12 +228,7 @@ __device__ __forceinline__ void emit_chunk(const int* rec, uint32_t pos, uint64_
 		: "memory");
 }
 
-// Emission of the fast kernels.  Up to four chunks in ONE asm statement: exec goes from mask to mask and is restored once at
-// the end (5 scalar moves for four chunks instead of 8), and the compiler cannot put instructions -- or its hazard s_nops --
-// between the pieces.  The store is a BUFFER store with index addressing: the record storage is described by a V# with
-// stride 4, so the hardware computes base + soffset + index * 4 and the lane's prefix count (v_mbcnt) is the index as it is:
-// two VALU instructions per chunk instead of three (no shift/add), in a kernel that is bound by VALU issue.
-// Chunk k appends the set lanes of m_k at byte offset pb_k (+4: the count word) of the record.
+// V# of the record storage (index-addressed buffer stores of the fast kernels)
 typedef int v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v4i record_rsrc(const int* base)
 {
@@ -201,54 +242,81 @@ __device__ __forceinline__ v4i record_rsrc(const int* base)
 	r.w = 0x00020000;
 	return r;
 }
-#define TNSX_EMIT_PIECE(K)                                                                   \
-	"s_mov_b64 exec, %[m" #K "]\n\t"                                                        \
-	"v_mbcnt_lo_u32_b32 %[t], %[l" #K "], 0\n\t"                                             \
-	"v_mbcnt_hi_u32_b32 %[t], %[h" #K "], %[t]\n\t"                                          \
-	"buffer_store_dword %[v" #K "], %[t], %[rsrc], %[p" #K "] idxen offset:4\n\t"
-#define TNSX_EMIT_IN(K, M, P, V) [m##K] "s"(M), [l##K] "s"((uint32_t)(M)), [h##K] "s"((uint32_t)((M) >> 32)), [p##K] "s"(P), [v##K] "v"(V)
-template <int N>
-__device__ __forceinline__ void emit_chunks(v4i rsrc, const uint64_t* m, const uint32_t* pb, const uint32_t* v)
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-staged emission.  Measured (profiles/r2_emit_ab.txt): the sparse global stores of the hit compaction, not
+// instruction issue, are what the fast kernel waits for -- ~6 store instructions per query with ~10 live lanes each keep the
+// texture-address FIFO full (SQ_VMEM_TA_ADDR_FIFO_FULL 94 % of busy cycles), and spreading a chunk's hits over the whole
+// record (lane-major order in global memory) made it worse.  So the hits of a query are compacted into the wave's LDS staging
+// area first, lane-major (P[l] from one v_mbcnt chain, then exec = mask: ds_write, address += 4), and the record leaves
+// with ONE full-wave coalesced store per 64 indices.  The count is what lane 63's address ends up at.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int SLOTS>
+__device__ __forceinline__ uint32_t* record_stage()
 {
-	uint32_t tmp;
+	__shared__ uint32_t s_stage[Q_WAVES * SLOTS];
+	return s_stage + readfirstlane_u32(threadIdx.x / WAVE) * SLOTS;
+}
+#define TNSX_LDS_PIECE(K)                   \
+	"s_mov_b64 exec, %[m" #K "]\n\t"       \
+	"ds_write_b32 %[addr], %[v" #K "]\n\t" \
+	"v_add_u32 %[addr], 4, %[addr]\n\t"
+#define TNSX_LDS_IN(K, M, V) [m##K] "s"(M), [v##K] "v"(V)
+template <int N>
+__device__ __forceinline__ void stage_chunks(uint32_t& addr, const uint64_t* m, const uint32_t* v)
+{
 	if (N == 1) {
-		asm volatile(TNSX_EMIT_PIECE(0) "s_mov_b64 exec, -1" : [t] "=&v"(tmp) : TNSX_EMIT_IN(0, m[0], pb[0], v[0]), [rsrc] "s"(rsrc) : "memory");
+		asm volatile(TNSX_LDS_PIECE(0) "s_mov_b64 exec, -1" : [addr] "+v"(addr) : TNSX_LDS_IN(0, m[0], v[0]) : "memory");
 	}
 	else if (N == 2) {
-		asm volatile(TNSX_EMIT_PIECE(0) TNSX_EMIT_PIECE(1) "s_mov_b64 exec, -1"
-		             : [t] "=&v"(tmp) : TNSX_EMIT_IN(0, m[0], pb[0], v[0]), TNSX_EMIT_IN(1, m[1], pb[1], v[1]), [rsrc] "s"(rsrc) : "memory");
+		asm volatile(TNSX_LDS_PIECE(0) TNSX_LDS_PIECE(1) "s_mov_b64 exec, -1" : [addr] "+v"(addr) : TNSX_LDS_IN(0, m[0], v[0]), TNSX_LDS_IN(1, m[1], v[1]) : "memory");
 	}
 	else if (N == 3) {
-		asm volatile(TNSX_EMIT_PIECE(0) TNSX_EMIT_PIECE(1) TNSX_EMIT_PIECE(2) "s_mov_b64 exec, -1"
-		             : [t] "=&v"(tmp)
-		             : TNSX_EMIT_IN(0, m[0], pb[0], v[0]), TNSX_EMIT_IN(1, m[1], pb[1], v[1]), TNSX_EMIT_IN(2, m[2], pb[2], v[2]), [rsrc] "s"(rsrc) : "memory");
+		asm volatile(TNSX_LDS_PIECE(0) TNSX_LDS_PIECE(1) TNSX_LDS_PIECE(2) "s_mov_b64 exec, -1"
+		             : [addr] "+v"(addr) : TNSX_LDS_IN(0, m[0], v[0]), TNSX_LDS_IN(1, m[1], v[1]), TNSX_LDS_IN(2, m[2], v[2]) : "memory");
 	}
 	else {
-		asm volatile(TNSX_EMIT_PIECE(0) TNSX_EMIT_PIECE(1) TNSX_EMIT_PIECE(2) TNSX_EMIT_PIECE(3) "s_mov_b64 exec, -1"
-		             : [t] "=&v"(tmp)
-		             : TNSX_EMIT_IN(0, m[0], pb[0], v[0]), TNSX_EMIT_IN(1, m[1], pb[1], v[1]), TNSX_EMIT_IN(2, m[2], pb[2], v[2]),
-		               TNSX_EMIT_IN(3, m[3], pb[3], v[3]), [rsrc] "s"(rsrc) : "memory");
+		asm volatile(TNSX_LDS_PIECE(0) TNSX_LDS_PIECE(1) TNSX_LDS_PIECE(2) TNSX_LDS_PIECE(3) "s_mov_b64 exec, -1"
+		             : [addr] "+v"(addr) : TNSX_LDS_IN(0, m[0], v[0]), TNSX_LDS_IN(1, m[1], v[1]), TNSX_LDS_IN(2, m[2], v[2]), TNSX_LDS_IN(3, m[3], v[3]) : "memory");
 	}
 }
-// all NC chunks of one query, four per asm statement
 template <int NC>
-__device__ __forceinline__ void emit_all(v4i rsrc, const uint64_t (&m)[NC], const uint32_t (&pb)[NC], const uint32_t* v)
+__device__ __forceinline__ void stage_all(uint32_t& addr, const uint64_t (&m)[NC], const uint32_t* v)
 {
 	#pragma unroll
 	for (int g = 0; g < NC; g += 4) {
-		if (NC - g >= 4) emit_chunks<4>(rsrc, m + g, pb + g, v + g);
-		else if (NC - g == 3) emit_chunks<3>(rsrc, m + g, pb + g, v + g);
-		else if (NC - g == 2) emit_chunks<2>(rsrc, m + g, pb + g, v + g);
-		else emit_chunks<1>(rsrc, m + g, pb + g, v + g);
+		if (NC - g >= 4) stage_chunks<4>(addr, m + g, v + g);
+		else if (NC - g == 3) stage_chunks<3>(addr, m + g, v + g);
+		else if (NC - g == 2) stage_chunks<2>(addr, m + g, v + g);
+		else stage_chunks<1>(addr, m + g, v + g);
 	}
+}
+// Lane with record index i stores v to int 1 + i of the record that starts at byte `pos` of the storage behind rsrc, if i < cnt.
+// TNSX_STAGE_RANGECHECK: the bound is left to the buffer hardware -- an index-addressed (structured) buffer store is dropped when
+// index >= NUM_RECORDS (the scalar offset does not take part in the check), so writing cnt into word 2 of the V# costs one
+// scalar move instead of a compare and two exec moves.
+#ifndef TNSX_STAGE_PIPE
+#define TNSX_STAGE_PIPE 1
+#endif
+#ifndef TNSX_STAGE_RANGECHECK
+#define TNSX_STAGE_RANGECHECK 0
+#endif
+__device__ __forceinline__ void store_record64(v4i rsrc, uint32_t pos, uint32_t cnt, uint32_t i, uint32_t v)
+{
+#if TNSX_STAGE_RANGECHECK
+	rsrc.z = (int)cnt;
+	asm volatile("buffer_store_dword %[v], %[i], %[rsrc], %[pos] idxen offset:4" : : [v] "v"(v), [i] "v"(i), [rsrc] "s"(rsrc), [pos] "s"(pos) : "memory");
+#else
+	const uint64_t live = __builtin_amdgcn_ballot_w64(i < cnt);
+	asm volatile("s_mov_b64 exec, %[m]\n\tbuffer_store_dword %[v], %[i], %[rsrc], %[pos] idxen offset:4\n\ts_mov_b64 exec, -1"
+	             : : [m] "s"(live), [v] "v"(v), [i] "v"(i), [rsrc] "s"(rsrc), [pos] "s"(pos) : "memory");
+#endif
 }
 
 // One batch of <= NC*64 candidates (register resident) against the nq query points held one per lane in qv.
 //   MODE_COUNT: run_cnt (lane t) += hits of query t
 //   MODE_FILL : record of query t starts at my_off (lane t); indices appended at my_off + 1 + run_cnt
 //   MODE_POOL : record allocated here (single-batch cells only); my_off (lane t) receives its offset
-// SELF: 0 = other set, 1 = exclude the query itself with an index compare in every chunk,
-//       2 = clear the query's own bit in chunk 0/1 with scalar ops (only legal when its slot is < 128, see the fast kernel)
+// SELF: 0 = other set, 1 = exclude the query itself with an index compare in every chunk (the fast kernels clear one mask bit instead)
 template <int ARITH, bool VARIABLE, bool SYM, int SELF, int MODE, int NC, bool EXACT_NC>
 __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef RR, uint32_t wb, int lane, const float4& qv, float qr2, uint32_t qb,
                                               uint32_t nq, uint64_t& my_off, uint32_t& run_cnt, PoolState& ps, uint32_t& wave_hits)
@@ -311,13 +379,6 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 					if (SELF == 1) m[k] &= __builtin_amdgcn_ballot_w64(cid[k] != qi);
 				}
 			}
-		}
-		if (SELF == 2) {
-			// the query is always a hit of itself (d2 == 0); its slot is its sorted position minus the start of the centre run
-			const uint32_t ss = (qb + t) - RR.d_self - wb;
-			const uint64_t bit = 1ull << (ss & 63u);
-			m[0] &= ~(ss < 64u ? bit : 0ull);
-			if (NC > 1) m[NC > 1 ? 1 : 0] &= ~((ss >= 64u && ss < 128u) ? bit : 0ull);
 		}
 		uint32_t cnt = 0;
 		#pragma unroll
@@ -402,7 +463,6 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 		{
 			const Runs R0 = extract_runs(RR.run_start, RR.run_len);
 			RR.total = R0.total;
-			RR.d_self = R0.d0;
 		}
 		const uint2 cur_q = qrange;
 
@@ -412,15 +472,20 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 
 		// ---- query points of this cell, 64 at a time
 		for (uint32_t qb = cur_q.x; qb < cur_q.y; qb += WAVE) {
-			const uint32_t nq = (cur_q.y - qb) < (uint32_t)WAVE ? (cur_q.y - qb) : (uint32_t)WAVE;
+			const uint32_t nq_all = (cur_q.y - qb) < (uint32_t)WAVE ? (cur_q.y - qb) : (uint32_t)WAVE;
 			float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
 			float qr2 = a.r2_fixed;
 			uint64_t my_off = 0;
-			if ((uint32_t)lane < nq) {
+			uint32_t qorig = 0;   // original index of the query (the w component, unless the points carry user ids there)
+			if ((uint32_t)lane < nq_all) {
 				qv = a.xyzi_i[qb + lane];
+				qorig = a.orig_i ? a.orig_i[qb + lane] : __float_as_uint(qv.w);
 				if (VARIABLE) qr2 = a.r2_i[qb + lane];
 				if (MODE == MODE_FILL) my_off = a.offs_sorted[qb + lane];   // start of the record (its count word)
 			}
+			// queries that want lists (original index < query_limit): a prefix of the cell, the sort is stable (see fast_query_loop)
+			const uint32_t nq = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((uint32_t)lane < nq_all && qorig < a.query_limit));
+			if (MODE == MODE_COUNT && (uint32_t)lane >= nq && (uint32_t)lane < nq_all) a.counts[qb + lane] = 0u;   // no record at all
 			uint32_t run_cnt = 0;
 			if (RR.total <= (uint32_t)Q_SLOTS) {
 				// ---- the normal case: all candidates of the cell fit into one register-resident batch
@@ -471,7 +536,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 				}
 				else if (MODE == MODE_FILL || my_off != ~0ull) {
 					a.records[my_off] = (int)run_cnt;
-					a.offs_by_orig[__float_as_uint(qv.w)] = my_off;
+					a.offs_by_orig[qorig] = my_off;
 				}
 			}
 		}
@@ -504,11 +569,12 @@ template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int NC>
 __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits,
                                                 const v2f (&cx)[(NC + 1) / 2], const v2f (&cy)[(NC + 1) / 2], const v2f (&cz)[(NC + 1) / 2],
                                                 const uint32_t (&cid)[2 * ((NC + 1) / 2)], const float (&cr2)[2 * ((NC + 1) / 2)], const float4 qv,
-                                                const float qr2)
+                                                const float qr2, const uint32_t qidx)
 {
 	constexpr int NP = (NC + 1) / 2;
-	const uint32_t nq = cur_q.y - cur_q.x;
-	const uint32_t qidx = __float_as_uint(qv.w);
+	// Only points with original index < query_limit get lists (tnsx_set_query_count: the tail of a set can be candidates only,
+	// e.g. the ghost points of a slab).  The cell sort is stable, so inside a cell these queries come first: a prefix.
+	const uint32_t nq = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((uint32_t)lane < cur_q.y - cur_q.x && qidx < a.query_limit));
 	// ---- allocator state in plain scalars.  Records of this cell go to records[base ...] + pos0 bytes: `base` (64-bit, and the
 	//      buffer resource made from it) changes only when a new slab is taken, everything per query is 32-bit: pos0 (BYTES used
 	//      since `base`), left (ints left in the slab).
@@ -531,14 +597,12 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 		flushed = upto;
 	};
 
+	uint32_t* const stage = record_stage<(NC > 8 ? 1024 : 512)>();
+	const uint32_t stage_base = readfirstlane_u32((uint32_t)(uintptr_t)stage);   // (the low half of a generic LDS address is the LDS offset)
+	uint32_t pend_v = 0, pend_cnt = 0, pend_pos = 0;   // TNSX_STAGE_PIPE: first 64 ints of the previous query's record, read back but not yet stored
 	// ---- the query loop.  (Fetching the query point with a scalar load one iteration ahead instead of v_readlane was
 	//      tried and dropped: the compiler is free to copy the destination SGPRs before the asynchronous load has landed.)
 	uint32_t hits = 0;
-	// slot of query 0 = its sorted position minus the start of the centre run (< 128: in chunk 0 or 1); one bit of a 128-bit
-	// mask that is shifted along with t -- cheaper than building the bit from the slot number for every query
-	const uint32_t ss0 = cur_q.x - RR.d_self;
-	uint64_t self0 = (SELF && ss0 < 64u) ? 1ull << (ss0 & 63u) : 0ull;
-	uint64_t self1 = (SELF && ss0 >= 64u) ? 1ull << (ss0 & 63u) : 0ull;
 	for (uint32_t t = 0; t < nq; t++) {
 		const float qx = readlane_f32(qv.x, (int)t), qy = readlane_f32(qv.y, (int)t), qz = readlane_f32(qv.z, (int)t);
 		const float r2q = VARIABLE ? readlane_f32(qr2, (int)t) : a.r2_fixed;
@@ -556,17 +620,24 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 			}
 		}
 		if (SELF) {
-			// the query is always a hit of itself (d2 == 0): clear its own slot, then move the bit on to the next query's slot
-			m[0] &= ~self0;
-			if (NC > 1) m[NC > 1 ? 1 : 0] &= ~self1;
-			self1 = (self1 << 1) | (self0 >> 63);
-			self0 <<= 1;
+			// the query is always a hit of itself (d2 == 0) and sits at slot t (own-cell-first slot order)
+			asm("s_bitset0_b64 %0, %1" : "+s"(m[0]) : "s"(t));
 		}
-		uint32_t p[NC];                                  // chunk k goes to byte 4 + p[k] ... of the storage at `base`
-		uint32_t run = pos0;
-		#pragma unroll
-		for (int k = 0; k < NC; k++) { p[k] = run; run += 4u * (uint32_t)__popcll(m[k]); }
-		const uint32_t cnt = (run - pos0) >> 2, len = cnt + 1u;
+		// hits -> LDS staging area, lane-major
+		uint32_t addr;
+		{
+			uint32_t P = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[0] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[0], 0u));
+			#pragma unroll
+			for (int k = 1; k < NC; k++) P = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[k], P));
+			addr = stage_base + (P << 2);
+		}
+		stage_all<NC>(addr, m, cid);
+		const uint32_t cnt = (readlane_u32(addr, WAVE - 1) - stage_base) >> 2, len = cnt + 1u;
+#if TNSX_STAGE_PIPE
+		// the record staged by the PREVIOUS query leaves now -- its ds_read has had this query's tests to land (and it refers to
+		// the current base, so it goes before a possible slab change)
+		if (pend_cnt != 0u) { store_record64(rsrc, pend_pos, pend_cnt, (uint32_t)lane, pend_v); pend_cnt = 0u; }
+#endif
 		if (len > left) {
 			// rare: new slab (one atomic on the global cursor).  The queries so far refer to the old base: write them out first.
 			flush(t);
@@ -576,11 +647,17 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 			rsrc = record_rsrc(a.records + base);
 			left = sz;
 			ok = readfirstlane_u32(base + sz <= a.pool_capacity ? 1u : 0u);
-			#pragma unroll
-			for (int k = 0; k < NC; k++) p[k] -= pos0;
 			pos0 = 0;
 		}
-		if (ok != 0u) emit_all<NC>(rsrc, m, p, cid);
+		if (ok != 0u) {
+			// the staged record -> global memory, 64 consecutive ints per store
+#if TNSX_STAGE_PIPE
+			pend_v = stage[lane]; pend_cnt = cnt; pend_pos = pos0;
+			for (uint32_t f = (uint32_t)WAVE; f < cnt; f += (uint32_t)WAVE) store_record64(rsrc, pos0, cnt, f + (uint32_t)lane, stage[f + (uint32_t)lane]);
+#else
+			for (uint32_t f = 0; f < cnt; f += (uint32_t)WAVE) store_record64(rsrc, pos0, cnt, f + (uint32_t)lane, stage[f + (uint32_t)lane]);
+#endif
+		}
 		// (lane select in m0: a VALU instruction of gfx9 may read only one SGPR besides it.  m0 is a reserved register that the
 		//  compiler loads right before each of its own uses -- none in this kernel -- so it is not, and cannot be, listed as clobbered)
 		asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(v_cnt), "+v"(v_pos) : "s"(cnt), "s"(pos0), "s"(t));
@@ -588,6 +665,11 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 		left -= len;
 		hits += cnt;
 	}
+#if TNSX_STAGE_PIPE
+	if (pend_cnt != 0u) store_record64(rsrc, pend_pos, pend_cnt, (uint32_t)lane, pend_v);
+#else
+	(void)pend_v; (void)pend_cnt; (void)pend_pos;
+#endif
 	flush(nq);
 	wave_hits += hits;
 	{
@@ -602,8 +684,9 @@ template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int NC>
 __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits)
 {
 	constexpr int NP = (NC + 1) / 2;
+	constexpr bool OWN_FIRST = SELF;
 	const uint32_t nq = cur_q.y - cur_q.x;
-	const Runs R = extract_runs(RR.run_start, RR.run_len);
+	const Runs R = extract_runs_t<OWN_FIRST>(RR.run_start, RR.run_len, cur_q.x);
 	// ---- candidates -> registers (branch-free, see process_batch)
 	v2f cx[NP], cy[NP], cz[NP];
 	uint32_t cid[2 * NP];
@@ -614,7 +697,7 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 	for (int k = 0; k < 2 * NP; k++) {
 		if (k < NC) {
 			const uint32_t slot = (uint32_t)(k * WAVE + lane);
-			const uint32_t src = (k < NC - 1 || slot < R.total) ? slot_to_src(slot, R) : R.d0;
+			const uint32_t src = (k < NC - 1 || slot < R.total) ? slot_to_src_t<OWN_FIRST>(slot, R) : R.d0;
 			craw[k] = a.xyzi_j[src];
 			if (SYM) r2raw[k] = a.r2_j[src];
 		}
@@ -622,6 +705,7 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 	// the cell's query points, one per lane (clamped, branch-free load)
 	const uint32_t qsrc = cur_q.x + ((uint32_t)lane < nq ? (uint32_t)lane : 0u);
 	const float4 qv = a.xyzi_i[qsrc];
+	const uint32_t qorig = a.orig_i ? a.orig_i[qsrc] : __float_as_uint(qv.w);
 	float qr2 = a.r2_fixed;
 	if (VARIABLE) qr2 = a.r2_i[qsrc];
 	#pragma unroll
@@ -643,7 +727,7 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 		cr2[k] = r2c;
 	}
 
-	fast_query_loop<ARITH, VARIABLE, SYM, SELF, NC>(a, RR, lane, cur_q, ps, wave_hits, cx, cy, cz, cid, cr2, qv, qr2);
+	fast_query_loop<ARITH, VARIABLE, SYM, SELF, NC>(a, RR, lane, cur_q, ps, wave_hits, cx, cy, cz, cid, cr2, qv, qr2, qorig);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -662,7 +746,7 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 // cell, and d2lb > (largest radius^2 that can accept the pair) means that the predicate itself rejects the pair.
 // The centre row (slots < R.p1: it holds the cell's own points) is kept as it is, so that the self-exclusion slot stays valid.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int ARITH, bool SYM>
+template <int ARITH, bool SYM, bool OWN_FIRST>
 __device__ __forceinline__ uint32_t cull_round(const QueryArgs& a, const Runs R, int lane, uint32_t base, uint32_t kept, float lox, float loy, float loz,
                                                float hix, float hiy, float hiz, float r2q_max, uint16_t* __restrict__ lds_slots)
 {
@@ -673,7 +757,7 @@ __device__ __forceinline__ uint32_t cull_round(const QueryArgs& a, const Runs R,
 	for (int k = 0; k < Q_MAXPAIRS * 2; k++) {
 		if ((uint32_t)k < nc) {
 			const uint32_t slot = base + (uint32_t)(k * WAVE + lane);
-			const uint32_t src = slot < R.total ? slot_to_src(slot, R) : R.d0;
+			const uint32_t src = slot < R.total ? slot_to_src_t<OWN_FIRST>(slot, R) : R.d0;
 			craw[k] = a.xyzi_j[src];
 			if (SYM) r2raw[k] = a.r2_j[src];
 		}
@@ -703,7 +787,8 @@ __device__ __forceinline__ uint32_t cull_round(const QueryArgs& a, const Runs R,
 // the query loop on the `kept` surviving candidates whose slot numbers are in lds_slots
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int NC>
 __device__ __forceinline__ void fast_cell_from_slots(const QueryArgs& a, const RunRef RR, const Runs R, int lane, const uint2 cur_q, PoolState& ps,
-                                                     uint32_t& wave_hits, const uint16_t* __restrict__ lds_slots, uint32_t kept, const float4 qv, const float qr2)
+                                                     uint32_t& wave_hits, const uint16_t* __restrict__ lds_slots, uint32_t kept, const float4 qv, const float qr2,
+                                                     const uint32_t qorig)
 {
 	constexpr int NP = (NC + 1) / 2;
 	v2f cx[NP], cy[NP], cz[NP];
@@ -716,7 +801,7 @@ __device__ __forceinline__ void fast_cell_from_slots(const QueryArgs& a, const R
 		if (k < NC) {
 			const uint32_t i = (uint32_t)(k * WAVE + lane);
 			const uint32_t slot = lds_slots[i];                     // (slots past `kept` hold stale numbers: clamped below)
-			const uint32_t src = (k < NC - 1 || i < kept) ? slot_to_src(slot < R.total ? slot : 0u, R) : R.d0;
+			const uint32_t src = (k < NC - 1 || i < kept) ? slot_to_src_t<SELF>(slot < R.total ? slot : 0u, R) : R.d0;
 			craw[k] = a.xyzi_j[src];
 			if (SYM) r2raw[k] = a.r2_j[src];
 		}
@@ -739,7 +824,7 @@ __device__ __forceinline__ void fast_cell_from_slots(const QueryArgs& a, const R
 		cid[k] = __float_as_uint(c.w);
 		cr2[k] = r2c;
 	}
-	fast_query_loop<ARITH, VARIABLE, SYM, SELF, NC>(a, RR, lane, cur_q, ps, wave_hits, cx, cy, cz, cid, cr2, qv, qr2);
+	fast_query_loop<ARITH, VARIABLE, SYM, SELF, NC>(a, RR, lane, cur_q, ps, wave_hits, cx, cy, cz, cid, cr2, qv, qr2, qorig);
 }
 
 // -> false: more than Q_SLOTS candidates survive; nothing has been written
@@ -748,10 +833,12 @@ __device__ __forceinline__ bool fast_cell_culled(const QueryArgs& a, const RunRe
                                                  uint16_t* __restrict__ lds_slots)
 {
 	const uint32_t nq = cur_q.y - cur_q.x;
-	const Runs R = extract_runs(RR.run_start, RR.run_len);
+	constexpr bool OWN_FIRST = SELF;
+	const Runs R = extract_runs_t<OWN_FIRST>(RR.run_start, RR.run_len, cur_q.x);
 	// the cell's query points, one per lane (clamped, branch-free load: the lanes beyond nq repeat the first point)
 	const uint32_t qsrc = cur_q.x + ((uint32_t)lane < nq ? (uint32_t)lane : 0u);
 	const float4 qv = a.xyzi_i[qsrc];
+	const uint32_t qorig = a.orig_i ? a.orig_i[qsrc] : __float_as_uint(qv.w);
 	float qr2 = a.r2_fixed;
 	if (VARIABLE) qr2 = a.r2_i[qsrc];
 	float lox = qv.x, loy = qv.y, loz = qv.z, hix = qv.x, hiy = qv.y, hiz = qv.z;
@@ -760,19 +847,19 @@ __device__ __forceinline__ bool fast_cell_culled(const QueryArgs& a, const RunRe
 
 	uint32_t kept = 0;
 	for (uint32_t base = 0; base < R.total; base += (uint32_t)Q_SLOTS)
-		kept = readfirstlane_u32(cull_round<ARITH, SYM>(a, R, lane, base, kept, lox, loy, loz, hix, hiy, hiz, r2q_max, lds_slots));
+		kept = readfirstlane_u32(cull_round<ARITH, SYM, OWN_FIRST>(a, R, lane, base, kept, lox, loy, loz, hix, hiy, hiz, r2q_max, lds_slots));
 	if (kept > (uint32_t)Q_SLOTS) return false;
 	wave_lds_fence();
 	switch ((kept + WAVE - 1) / WAVE) {
 	case 0:
-	case 1: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 1>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2); break;
-	case 2: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 2>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2); break;
-	case 3: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 3>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2); break;
-	case 4: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 4>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2); break;
-	case 5: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 5>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2); break;
-	case 6: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 6>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2); break;
-	case 7: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 7>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2); break;
-	default: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 8>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2); break;
+	case 1: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 1>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2, qorig); break;
+	case 2: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 2>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2, qorig); break;
+	case 3: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 3>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2, qorig); break;
+	case 4: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 4>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2, qorig); break;
+	case 5: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 5>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2, qorig); break;
+	case 6: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 6>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2, qorig); break;
+	case 7: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 7>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2, qorig); break;
+	default: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 8>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2, qorig); break;
 	}
 	wave_lds_fence();   // the next culled cell of this wave overwrites the staging buffer
 	return true;
@@ -906,7 +993,6 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 		{
 			const Runs R0 = extract_runs(RR.run_start, RR.run_len);
 			RR.total = R0.total;
-			RR.d_self = R0.d0;
 		}
 		const uint2 cur_q = qrange;
 		// ---- lookups of the next cell: in flight while this one is processed
@@ -914,7 +1000,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 		qrange = a.table_i[have_next ? key_next : key];
 
 		const uint32_t nq = cur_q.y - cur_q.x;
-		bool pass_on = RR.total > 2u * (uint32_t)Q_SLOTS || nq > (uint32_t)WAVE || (SELF && (cur_q.y - RR.d_self) > 2u * WAVE);
+		bool pass_on = RR.total > 2u * (uint32_t)Q_SLOTS || nq > (uint32_t)WAVE;
 		if (!pass_on && !FAT && RR.total > (uint32_t)TNSX_CULL_FROM) {
 			// more candidates than the loop holds: cull them against the bounding box of the query points; the cell is done
 			// here if at most 512 survive
@@ -929,11 +1015,14 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 		else if (!FAT && RR.total > (uint32_t)TNSX_CULL_FROM) { /* done by the culled path above */ }
 		else if (RR.total == 0u) {
 			// no candidate at all (set_j is another, sparser or empty set): nq empty records, one int each
+			const uint32_t qs0 = cur_q.x + ((uint32_t)lane < nq ? (uint32_t)lane : 0u);
+			const uint32_t qi0 = a.orig_i ? a.orig_i[qs0] : __float_as_uint(a.xyzi_i[qs0].w);
+			const uint32_t nqv = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((uint32_t)lane < nq && qi0 < a.query_limit));   // (a prefix, see fast_query_loop)
 			bool okz;
-			const uint64_t off = pool_alloc(a, ps, nq, lane, okz);
-			if ((uint32_t)lane < nq && okz) {
+			const uint64_t off = pool_alloc(a, ps, nqv, lane, okz);
+			if ((uint32_t)lane < nqv && okz) {
 				a.records[off + lane] = 0;
-				a.offs_by_orig[__float_as_uint(a.xyzi_i[cur_q.x + lane].w)] = off + lane;
+				a.offs_by_orig[qi0] = off + lane;
 			}
 		}
 		else fast_cell_nc<ARITH, VARIABLE, SYM, SELF, FAT>(a, RR, lane, cur_q, ps, wave_hits);
