@@ -1,24 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- neighbour build + query throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py                                   # N = 1, workload c2 = BASELINE.json configs[1], finishes in ~2 minutes
+    python bench.py --workload c3|c4|c5 [--points P]  # the other single-GPU configurations
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+           bench.py --gpus N --steps K --warmup W      # N > 1: configs[4], slabs along x + one halo exchange per step over RCCL
 
-A "step" is one tnsx run() -- world bounds, cell keys, radix sort, gather, cell table, 27-cell query (count, scan,
-fill) -- over a batch of synthetic points that are already resident in HBM; the neighbour lists stay in HBM.
-N = 1: BASELINE.json configs[1], 10 M uniform points, fixed radius (~59 neighbours).  N > 1: weak scaling, every rank
-owns one unit-cube slab of 10 M points (global cloud = N slabs along x) and exchanges one-radius ghost halos with its
-slab neighbours over RCCL every step (treensearch_amd/multi.py); value = all points of all ranks / max-over-ranks time.
+A "step" is one pass of the hot path -- tnsx run(): (bounds) -> cell sort -> cell table -> 27-cell query that writes the neighbour
+lists -- over points that are already resident in HBM; the lists stay in HBM.  The points MOVE between steps (every coordinate
+by up to +-0.058 r, |d| <= 0.1 r, alternating around the generated positions), as they do in the simulation the engine serves:
+nothing can be carried over from one step to the next except what a real time step would allow.
 
-Rank 0 prints ONE JSON line (metric/value/unit/... + "roofline" for the dominant kernel + "cpu_baseline").
+  c2  10 M uniform points, one set, fixed radius (~59 neighbours)                       BASELINE.json configs[1]   (default at N = 1)
+  c3  8 M fluid + 2 M static boundary, searches 0->0 and 0->1                            configs[2]
+  c4  50 M dam-break cloud, per-point radii, symmetric; every step: perturb in place,    configs[3]
+      prepare_zsort, apply_zsort(xyz), apply_zsort(radii), run
+  c5  200 M uniform points in total, fixed radius, `world` slabs along x (balanced cuts   configs[4]   (default at N > 1; strong scaling)
+      from the x histogram, redistribution once, ghosts over RCCL every step)
+
+Rank 0 prints ONE JSON line: metric / value / ... + "roofline" (the query kernel; whole run beside it) + "cpu_baseline".
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -26,41 +38,59 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the measured copy ceiling is reported beside it
+STAGES = ("ms_total", "ms_bounds", "ms_table_clear", "ms_sort", "ms_cells", "ms_count", "ms_scan", "ms_fill")
+QUERY_KERNEL = "k_query_pool_fast"
 
 
-def cpu_baseline(n_points: int, radius: float, seed: int):
-    """Times the reference's AVX2 path (oracle/_ref, built from /root/reference in the build container) on this
-    box's host cores; falls back to the CPU restatement (oracle/) on a smaller sample when the reference build did
-    not travel.  Protocol of BASELINE.md section 4: z-sort first, warm-up runs, median of the timed runs."""
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the REAL reference (oracle/_ref, compiled from /root/reference in the build container) on this box's cores
+# ----------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(workload: str, seed: int):
+    """Protocol of BASELINE.md section 4: z-sort first, warm-up runs, median of the timed runs.  Bounded to ~10-30 s of CPU work:
+    c2 / c3 at full size, c4 on a 10 M-point dam break, c5 on the 10 M-point cloud of c2 (the reference is a single-process
+    library; 200 M points would take minutes)."""
     from oracle import oracle as O
     from treensearch_amd import datagen as D
     cores = os.cpu_count() or 1
     try:
         if O.have_ref():
-            pts = D.uniform_cloud(n_points, seed)
             ref = O.RefTreeNSearch(strict=False)
-            ref.set_search_radius(radius)
-            s = ref.add_point_set(pts)
-            ref.set_active_search(s, s, True)
+            if workload == "c3":
+                f, b, radius = D.two_set_cloud(8_000_000, 2_000_000, seed)
+                sets, pairs, what = [(f, None), (b, None)], [(0, 0), (0, 1)], "8 M + 2 M two-set cloud of c3, searches 0->0 and 0->1"
+            elif workload == "c4":
+                p, rad, _ = D.dam_break_cloud(10_000_000, seed)
+                sets, pairs, radius, what = [(p, rad)], [(0, 0)], None, "10 M-point dam break with per-point radii (a fifth of c4), symmetric"
+            else:
+                n = 10_000_000
+                sets, pairs, radius, what = [(D.uniform_cloud(n, seed), None)], [(0, 0)], D.radius_for_neighbors(n), "10 M uniform points of c2"
+            if radius is not None:
+                ref.set_search_radius(radius)
+            for (p, r) in sets:
+                ref.add_point_set(p, r)
+            for (i, j) in pairs:
+                ref.set_active_search(i, j, True)
             ref.prepare_zsort()
-            ref.apply_zsort(s, pts, 3)
+            for s, (p, r) in enumerate(sets):
+                ref.apply_zsort(s, p, 3)
+                if r is not None:
+                    ref.apply_zsort(s, r, 1)
             times = []
             for it in range(3 + 5):
                 t0 = time.perf_counter()
                 ref.run()
-                t1 = time.perf_counter()
                 if it >= 3:
-                    times.append(t1 - t0)
+                    times.append(time.perf_counter() - t0)
             t = float(np.median(times))
-            return {"value": round(n_points / t / 1e6, 3), "unit": "Mpoints/s", "cores": O.Oracle().num_threads(),
-                    "kind": "reference", "host_cpus": cores,
-                    "sample": f"tns::TreeNSearch::run() (AVX2 path, reference flags, -march=haswell) on the same {n_points} "
-                              f"uniform points, z-sorted first, 3 warm-up + median of 5 runs ({t * 1e3:.1f} ms/run)"}
+            n_pts = sum(len(p) for p, _ in sets)
+            return {"value": round(n_pts / t / 1e6, 3), "unit": "Mpoints/s", "cores": O.Oracle().num_threads(), "kind": "reference", "host_cpus": cores,
+                    "sample": f"tns::TreeNSearch::run() (AVX2 path, reference flags, -march=haswell) on the {what}, z-sorted first, "
+                              f"3 warm-up + median of 5 runs ({t * 1e3:.1f} ms/run)"}
     except Exception as e:  # pragma: no cover - the reference library is optional on the GPU box
         sys.stderr.write(f"[bench] reference baseline unavailable: {e}\n")
     orc = O.Oracle()
-    n_s = min(n_points, 1_000_000)
+    n_s = 1_000_000
     pts = D.uniform_cloud(n_s, seed)
     r = D.radius_for_neighbors(n_s)
     t0 = time.perf_counter()
@@ -70,37 +100,77 @@ def cpu_baseline(n_points: int, radius: float, seed: int):
             "host_cpus": cores, "sample": f"oracle/tns_oracle.c grid search on {n_s} uniform points, 1 run ({t:.2f} s)"}
 
 
-def pmc_traffic(arith: str, pooled: bool):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_latest.json,
-    written by tools/prof_gpu.sh on the SAME workload): counters cannot be collected inside a timed run.  Corrections as
-    /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KiB) counts 128-byte requests of wide coalesced
-    reads as 64 bytes -> doubled; WRITE_SIZE (KiB) is taken as reported (uncalibrated)."""
-    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if not pooled or not os.path.exists(path):
-        return None, None
+# ----------------------------------------------------------------------------------------------------------------------
+# HBM traffic of the query kernel: rocprofv3 --pmc passes of THIS script (same workload, few steps), started from here
+# ----------------------------------------------------------------------------------------------------------------------
+def pmc_traffic(argv_workload):
+    """-> (bytes per launch or None, detail).  Two passes (FETCH_SIZE, WRITE_SIZE: separate runs, as the gfx950 guide prescribes),
+    kernel-filtered, mean per dispatch of the first query tier.  Corrections per /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE
+    (KiB) counts the 128-byte requests of wide coalesced reads as 64 bytes -> doubled; WRITE_SIZE (KiB) as reported."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or os.environ.get("TNSX_BENCH_NO_PMC") == "1":
+        return None, {"note": "no PMC pass (rocprofv3 not found or TNSX_BENCH_NO_PMC=1)"}
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="tnsx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", TNSX_BENCH_INNER="1")
     try:
-        prof = json.load(open(path))
-        name = f"k_query_pool_fast<{0 if arith == 'strict' else 1}, false, false, true, false>"
-        pmc = prof["kernels"][name]["pmc"]
-        fetch = 2.0 * pmc["FETCH_SIZE"] * 1024.0
-        write = pmc["WRITE_SIZE"] * 1024.0
-        return int(fetch + write), {"fetch_bytes": int(fetch), "write_bytes": int(write), "source": "profiles/pmc_latest.json (" + prof.get("source", "?") + ")",
-                                    "note": "L2<->fabric bytes (Infinity-Cache hits included); FETCH_SIZE x2 per the gfx950 guide, WRITE_SIZE uncalibrated"}
-    except (KeyError, ValueError, OSError):
-        return None, None
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-include-regex", QUERY_KERNEL, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--no-pmc"] + argv_workload
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420, check=False)
+            vals = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == counter and QUERY_KERNEL in r["Kernel_Name"]:
+                        vals.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+            if not vals:
+                return None, {"note": f"the {counter} pass produced no rows"}
+            # the first tier (FAT = false) is the kernel with the largest mean
+            out[counter] = max(sum(v) / len(v) for v in vals.values())
+        fetch, write = 2.0 * out["FETCH_SIZE"] * 1024.0, out["WRITE_SIZE"] * 1024.0
+        return int(fetch + write), {"fetch_bytes": int(fetch), "write_bytes": int(write), "source": "rocprofv3 --pmc passes started by this bench run "
+                                    "(2 warm-up + 2 timed steps each, mean per dispatch of the first query tier)",
+                                    "note": "L2<->fabric bytes (Infinity-Cache hits included); FETCH_SIZE x2 per the gfx950 guide, WRITE_SIZE as reported"}
+    except Exception as e:  # pragma: no cover
+        return None, {"note": f"PMC pass failed: {e}"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
+def measured_copy_peak(torch):
+    """device-to-device copy of 2 GiB (read + write), best of 5: the ceiling a streaming kernel reaches on THIS box"""
+    n = 1 << 29
+    a = torch.empty(n, dtype=torch.float32, device="cuda")
+    b = torch.empty_like(a)
+    a.fill_(1.0)
+    best = 0.0
+    for _ in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        best = max(best, 2.0 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    torch.cuda.empty_cache()
+    return round(best, 1)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--points", type=int, default=10_000_000, help="points per GPU")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default=None, help="default: c2 on one GPU, c5 on several")
+    ap.add_argument("--points", type=int, default=None, help="total points of the workload (default: the size BASELINE.json names)")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--arith", choices=["strict", "contracted"], default="strict")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
     ap.add_argument("--exact-layout", action="store_true", help="two-pass count/scan/fill result layout instead of the single pass")
-    ap.add_argument("--sorted-input", action="store_true", help="z-sort the cloud first (reported separately in DESIGN.md)")
+    ap.add_argument("--static-input", action="store_true", help="do not move the points between steps (the engine then reuses everything it may)")
     args = ap.parse_args()
 
     import torch
@@ -111,54 +181,124 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # TNSX_BENCH_FORCE_SLAB=1: exercise the slab / process-group path with a single rank (a 1-GPU box can check it)
+    workload = args.workload or ("c5" if args.gpus > 1 else "c2")
+    # TNSX_BENCH_FORCE_SLAB=1: exercise the process-group path with a single rank (a 1-GPU box can check it)
     distributed = world > 1 or (os.environ.get("TNSX_BENCH_FORCE_SLAB") == "1" and "RANK" in os.environ)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU path)"
     torch.cuda.set_device(local_rank)
     if distributed:
         assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        assert workload == "c5", "only c5 shards over several GPUs"
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
         assert args.gpus == 1, "launch N > 1 through torch.distributed.run"
-
-    n = args.points
-    # global cloud = `world` unit cubes side by side along x; rank k owns cube k (global ids k*n .. (k+1)*n-1)
-    radius = D.radius_for_neighbors(n)            # ~60 neighbours at the per-slab density
-    pts_h = D.uniform_cloud(n, args.seed, start=rank * n)
-    pts_h[:, 0] += np.float32(rank)
-    stream = torch.cuda.current_stream()
     arith = T.ARITH_STRICT if args.arith == "strict" else T.ARITH_CONTRACTED
+    # everything -- torch's copies, the exchange, the engine -- runs on ONE non-default stream, in stream order
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
 
     def make_engine():
         return T.TreeNSearch(arith=arith, stream=stream.cuda_stream, collect_stage_times=True, exact_layout=args.exact_layout)
 
-    if distributed:
-        from treensearch_amd.multi import SlabSearch
-        gids = torch.arange(rank * n, (rank + 1) * n, dtype=torch.int64, device="cuda")
-        slab = SlabSearch(float(rank), float(rank + 1), float(radius), make_engine)
-        # the owned points live in the slab's own buffer, the ghosts of every step are appended behind them
-        d_pts = slab.owned_buffer(n, "cuda", ghost_capacity=int(2.5 * n * float(radius)) + 4096)
-        d_pts.copy_(torch.from_numpy(pts_h))
-        ns = slab.engine
+    def osc(base: "torch.Tensor", amp: float, seed: int):
+        """two copies of the positions, base +- d with |d_k| <= amp / sqrt(3) per coordinate: step k uses copy k % 2"""
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        d = (torch.rand(base.shape, generator=g, device="cuda", dtype=torch.float32) - 0.5) * (2.0 * amp / 3.0 ** 0.5)
+        if args.static_input:
+            return [base, base]
+        return [base + d, base - d]
 
-        def step():
-            slab.step(d_pts, gids)
-    else:
+    points_total = args.points
+    extra = {}
+    # ------------------------------------------------------------------------------------------------ workloads
+    if workload == "c2":
+        n = points_total or 10_000_000
+        radius = D.radius_for_neighbors(n)
+        copies = osc(torch.from_numpy(D.uniform_cloud(n, args.seed)).cuda(), 0.1 * float(radius), 1)
         ns = make_engine()
         ns.set_search_radius(radius)
-        if args.sorted_input:
-            tmp = T.TreeNSearch()
-            tmp.set_search_radius(radius)
-            tmp.add_point_set(pts_h)
-            tmp.prepare_zsort()
-            tmp.apply_zsort(0, pts_h, 3)
-            del tmp
-        d_pts = torch.from_numpy(pts_h).cuda()
-        ns.add_point_set(d_pts)
+        ns.add_point_set(copies[0])
         ns.set_active_search(0, 0, True)
+        n_total = n
 
-        def step():
+        def step(k):
+            ns.resize_point_set(0, copies[k % 2])
             ns.run()
+        desc = (f"{n} uniform-random points in a unit cube, single set, fixed radius r={float(radius):.6f}, BASELINE.json configs[1]")
+    elif workload == "c3":
+        n = points_total or 10_000_000
+        nf = int(0.8 * n)
+        f, b, radius = D.two_set_cloud(nf, n - nf, args.seed)
+        copies = osc(torch.from_numpy(f).cuda(), 0.1 * float(radius), 2)
+        d_b = torch.from_numpy(b).cuda()
+        ns = make_engine()
+        ns.set_search_radius(radius)
+        ns.add_point_set(copies[0])
+        ns.add_point_set(d_b)
+        ns.set_active_search(0, 0, True)
+        ns.set_active_search(0, 1, True)
+        n_total = n
+
+        def step(k):
+            ns.resize_point_set(0, copies[k % 2])
+            ns.run()
+        desc = (f"{nf} fluid + {n - nf} static boundary points (2-layer lattice shell), fixed radius r={float(radius):.6f}, searches 0->0 and 0->1 "
+                f"only, BASELINE.json configs[2]; the fluid moves every step, the boundary never does")
+    elif workload == "c4":
+        n = points_total or 50_000_000
+        p, rad, r0 = D.dam_break_cloud(n, args.seed)
+        d_p, d_r = torch.from_numpy(p).cuda(), torch.from_numpy(rad).cuda()
+        g = torch.Generator(device="cuda").manual_seed(3)
+        d_delta = (torch.rand(d_p.shape, generator=g, device="cuda", dtype=torch.float32) - 0.5) * (2.0 * 0.1 * float(r0) / 3.0 ** 0.5)
+        ns = make_engine()
+        ns.add_point_set(d_p, d_r)
+        ns.set_active_search(0, 0, True)
+        ns.set_symmetric_search(True)
+        n_total = n
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        zs_ms = []
+
+        def step(k):
+            if not args.static_input:
+                d_p.add_(d_delta, alpha=1.0 if k % 2 == 0 else -1.0)      # (the z-sort permutes the points in between: a slow random walk)
+            ev[0].record()
+            ns.prepare_zsort()
+            ns.apply_zsort(0, d_p, 3)
+            ns.apply_zsort(0, d_r, 1)
+            ev[1].record()
+            ns.run()
+            ev[1].synchronize()
+            zs_ms.append(ev[0].elapsed_time(ev[1]))
+        extra["zsort_ms_per_step"] = zs_ms
+        desc = (f"{n}-point SPH dam break (70 % dense column, 25 % floor layer, 5 % spray), per-point radii r0*(1+u) with r0={float(r0):.6f}, "
+                f"symmetric search; every step: perturb <= 0.1 r0, prepare_zsort, apply_zsort(xyz), apply_zsort(radii), run; BASELINE.json configs[3]")
+    else:   # c5
+        from treensearch_amd.multi import SlabDecomposition, SlabSearch
+        n_total = points_total or 200_000_000
+        radius = D.radius_for_neighbors(n_total)
+        lo_i, hi_i = (n_total * rank) // world, (n_total * (rank + 1)) // world            # generated: a contiguous index range per rank
+        mine = torch.from_numpy(D.uniform_cloud(hi_i - lo_i, args.seed, start=lo_i)).cuda()
+        gids = torch.arange(lo_i, hi_i, dtype=torch.int64, device="cuda")
+        amp = 0.1 * float(radius)
+        dec = SlabDecomposition(engine=make_engine())
+        t_dec = time.perf_counter()
+        cuts = dec.balanced_cuts([mine], plane_width=float(radius) * 1.15)
+        owned, owned_gids, _ = dec.redistribute(mine, gids, None, cuts)
+        torch.cuda.synchronize()
+        extra["decomposition_s"] = round(time.perf_counter() - t_dec, 3)
+        del mine, gids, dec
+        n_owned = int(owned.shape[0])
+        # the points oscillate by <= 0.1 r around the positions the slabs were cut for: the halo is 0.11 r wider than the radius
+        slab = SlabSearch(float(cuts[rank]), float(cuts[rank + 1]), float(radius), make_engine, halo_margin=0.11)
+        copies = osc(owned, amp, 100 + rank)
+        ns = slab.engine
+
+        def step(k):
+            slab.step(copies[k % 2], owned_gids)
+        extra.update({"points_rank0": n_owned, "cuts": [float(c) for c in cuts[1:-1]]})
+        desc = (f"{n_total} uniform-random points in a unit cube in total, fixed radius r={float(radius):.6f}, BASELINE.json configs[4]: "
+                f"{world} slab(s) along x (balanced cuts from the all-reduced x histogram), ghosts of one halo width exchanged every step"
+                + (" over RCCL" if world > 1 else " (one rank: nothing to exchange)"))
 
     def sync_all():
         torch.cuda.synchronize()
@@ -166,16 +306,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    acc = {}
+    # ------------------------------------------------------------------------------------------------ timing
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    step(0)                                           # the cold run: allocations, the dry (count-only) pass of every pair, first grid
+    torch.cuda.synchronize()
+    cold_ms = (time.perf_counter() - t0) * 1e3
+    cold_stats = ns.get_stats()
+    for k in range(1, args.warmup):
+        step(k)
+    acc = {k: 0.0 for k in STAGES}
+    counts = {"pool_retries": 0, "speculation_redos": 0, "speculated": 0, "n_cached_sets": 0}
+    if "zsort_ms_per_step" in extra:
+        extra["zsort_ms_per_step"].clear()
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        step(k)
         st = ns.get_stats()
-        for k in ("ms_total", "ms_bounds", "ms_keys", "ms_sort", "ms_gather", "ms_cells", "ms_count", "ms_scan", "ms_fill"):
-            acc[k] = acc.get(k, 0.0) + st[k]
+        for key in STAGES:
+            acc[key] += st[key]
+        for key in counts:
+            counts[key] += st[key]
     sync_all()
     elapsed = time.perf_counter() - t0
     if distributed:
@@ -186,49 +338,67 @@ def main():
     st = ns.get_stats()
     steps = max(args.steps, 1)
     ms_per_step = elapsed / steps * 1e3
-    total_points = n * world
-    value = total_points / (elapsed / steps) / 1e6
+    value = n_total / (elapsed / steps) / 1e6
 
-    # ---- roofline of the dominant kernel, this rank: the single-pass query (k_query_pool_fast; its two follow-up tiers
-    #      run on empty worklists for this workload and are inside the same event bracket).  Algorithmic bytes per launch
-    #      (DESIGN.md section 4): 16 B per candidate point read once (sorted float4) in, 4 B per emitted index + 4 B count
-    #      word per query + 8 B per query (record offset by original index) out.  The exact two-pass layout
-    #      (--exact-layout) additionally reads the 8 B scanned record offset per query in its fill pass.
+    # ---- roofline of the dominant kernel, this rank: the single-pass query (k_query_pool_fast, first tier; its two follow-up tiers
+    #      are inside the same hipEvent bracket on the engine's stream).  Algorithmic bytes per launch (SURVEY.md section 8(d),
+    #      DESIGN.md section 4, evaluated with the measured N, Q, E): 16 B per candidate point read once (sorted float4) in,
+    #      4 B per emitted index + 4 B count word per query + 8 B per query (record offset by original index) out.  The exact
+    #      two-pass layout (--exact-layout) additionally reads the 8 B scanned record offset per query in its fill pass.
     n_pts, Q, E = st["n_points"], st["n_queries"], st["n_neighbors"]
     pooled = st.get("n_pool_pairs", 0) > 0
+    n_launches = max(st.get("n_pool_pairs", 0), 1)
     fill_bytes = 16 * n_pts + 4 * (E + Q) + 8 * Q + (0 if pooled else 8 * Q)
     fill_ms = acc["ms_fill"] / steps
     achieved = fill_bytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0
-    traffic, traffic_detail = pmc_traffic(args.arith, pooled)
     run_bytes = st["bytes_build"] + st["bytes_query"]
     dev_ms = acc["ms_total"] / steps
     out = {
         "metric": "Mpoints/sec neighbor build+query", "value": round(value, 3), "unit": "Mpoints/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{n} uniform-random points per GPU in a unit cube, single set, fixed radius "
-                               f"r={float(radius):.6f} (~{E / max(Q, 1):.1f} neighbours avg), BASELINE.json configs[1]"
-                               + ("" if world == 1 else f"; {world} slabs along x with one-radius ghost halos over RCCL"),
-                   "points_per_gpu": n, "arith": args.arith, "input_order": "z-sorted" if args.sorted_input else "as generated (random)",
-                   "neighbors_total_rank0": int(E), "grid": st["grid_dims"], "parallelism": f"slab{world}"},
-        "roofline": {"bound": "hbm", "kernel": "k_query_pool_fast" if pooled else "k_query<fill>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
-                     "bytes_per_launch": int(fill_bytes), "avg_launch_ms": round(fill_ms, 4),
+        "higher_is_better": True, "scaling": "strong" if workload == "c5" else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "name": workload, "points_total": int(n_total), "arith": args.arith,
+                   "input": "static" if args.static_input else "every coordinate moves by up to 0.058 r between steps (|d| <= 0.1 r)",
+                   "neighbors_rank0": int(E), "neighbors_per_query": round(E / max(Q, 1), 2), "queries_rank0": int(Q),
+                   "grid": st["grid_dims"], "parallelism": f"slab{world}", **{k: v for k, v in extra.items() if k != "zsort_ms_per_step"}},
+        "roofline": {"bound": "hbm", "kernel": QUERY_KERNEL if pooled else "k_query<fill>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_detail": None,
+                     "bytes_per_launch": int(fill_bytes // n_launches), "avg_launch_ms": round(fill_ms / n_launches, 4), "launches_per_step": n_launches,
                      "whole_run": {"algorithmic_bytes": int(run_bytes), "bytes_per_point": round(run_bytes / max(n_pts, 1), 1),
                                    "device_ms": round(dev_ms, 4),
                                    "achieved_gbs": round(run_bytes / (dev_ms * 1e-3) / 1e9, 1) if dev_ms > 0 else 0.0,
                                    "frac": round(run_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dev_ms > 0 else 0.0}},
         "stage_ms": {k[3:]: round(v / steps, 4) for k, v in acc.items()},
+        "steady_state": {"runs_that_reused_the_grid": counts["speculated"], "runs_repeated_after_a_failed_assumption": counts["speculation_redos"],
+                         "pool_retries": counts["pool_retries"], "cached_set_builds_skipped": counts["n_cached_sets"]},
+        "cold_run": {"ms": round(cold_ms, 3), "dry_passes": cold_stats["cold_passes"],
+                     "note": "first step of the process: allocations + one count-only pass per pair + the sized pass"},
     }
+    if "zsort_ms_per_step" in extra and extra["zsort_ms_per_step"]:
+        out["stage_ms"]["zsort_prepare_and_apply"] = round(float(np.mean(extra["zsort_ms_per_step"])), 4)
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(n, float(radius), args.seed)
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        if os.environ.get("TNSX_BENCH_INNER") != "1":
+            peak = measured_copy_peak(torch)
+            out["roofline"]["peak_measured"] = peak
+            out["roofline"]["frac_of_measured"] = round(achieved / peak, 4) if peak > 0 else None
+            out["roofline"]["whole_run"]["frac_of_measured"] = round(out["roofline"]["whole_run"]["achieved_gbs"] / peak, 4) if peak > 0 else None
+    sync_all()
     if distributed:
-        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # (the engine and its gigabytes of lists are released before the counter passes start a second process on the same GPU)
+        del ns
+        step = None
+        copies = None
+        torch.cuda.empty_cache()
+        if not args.no_pmc and world == 1 and pooled:
+            wl_args = ["--workload", workload, "--arith", args.arith] + (["--points", str(args.points)] if args.points else []) + \
+                      (["--static-input"] if args.static_input else [])
+            traffic, detail = pmc_traffic(wl_args)
+            out["roofline"]["traffic"] = None if traffic is None else int(traffic // n_launches)
+            out["roofline"]["traffic_detail"] = detail
+        out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(workload, args.seed)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -73,8 +73,14 @@ typedef struct tnsx_options {
 	                             records in memory unspecified, pool has unused gaps; the first run of a pair adds a dry,
 	                             count-only pass).  1: always count -> scan -> fill, records laid out in spatially sorted
 	                             point order without gaps (deterministic, ~2x more query work) */
-	uint64_t max_dense_cells; /* upper bound of the dense cell table (8 bytes per cell and point set); 0 = default = maximum (2^30) */
-	int reserved[7];
+	uint64_t max_dense_cells; /* upper bound of the dense cell table (8 bytes per cell and point set), at most 2^30.  0 = default:
+	                             max(2^22, 64 x the number of points) cells -- a sparse scene (one stray particle far away) gets coarser
+	                             cells, which is exact but slower for the affected cells, instead of a table of gigabytes */
+	int temporal_reuse;       /* 1 (default): a run lays the previous run's search grid over the points without computing their bounds
+	                             first, and point sets whose input did not change keep their sorted arrays and cell table; both are
+	                             verified on the device during the run and the run is repeated when an assumption was wrong (the
+	                             reference's own reuse, TreeNSearch.cpp:474-482 and :77-79).  0: bounds and full build every run */
+	int reserved[6];
 } tnsx_options;
 
 /* Neighbour lists of one active (set_i -> set_j) pair.  Record layout == the reference's chunk storage
@@ -100,14 +106,20 @@ typedef struct tnsx_stats {
 	uint64_t n_grid_cells;        /* cells of the search grid */
 	int grid_dims[3];
 	float grid_cell_size;
+	float grid_origin[3];         /* the grid covers the tight bounds of the points widened by two search radii (never beyond the world box) */
 	int key_bits, radix_passes;
 	/* algorithmic HBM bytes of the last run (SURVEY.md section 8d formula, evaluated with measured Q,E,C) */
 	uint64_t bytes_build, bytes_query;
-	/* stage times in ms (0 unless collect_stage_times) */
-	float ms_total, ms_upload, ms_bounds, ms_keys, ms_sort, ms_gather, ms_cells, ms_count, ms_scan, ms_fill, ms_mirror;
+	/* stage times in ms of the last attempt (0 unless collect_stage_times): H2D of host inputs; bounds kernels + their host round trip
+	 * (0 when the grid was reused); clearing the previous run's cell-table entries; cell sort; cell table; count / scan passes
+	 * (exact_layout only); the query pass(es) that write the lists; pinned host mirror */
+	float ms_total, ms_upload, ms_bounds, ms_table_clear, ms_sort, ms_cells, ms_count, ms_scan, ms_fill, ms_mirror;
 	int n_pool_pairs;             /* pairs built in single-pass pool mode in the last run */
 	int pool_retries;             /* pool passes repeated because the pool was too small */
-	int n_fast_builds;            /* reserved (always 0) */
+	int cold_passes;              /* dry (count-only) passes of pairs that ran for the first time */
+	int speculated;               /* 1: the last run reused the previous run's grid (no bounds pass, no host round trip before the build) */
+	int speculation_redos;        /* attempts of the last run that were thrown away because an assumption was wrong (0 or 1) */
+	int n_cached_sets;            /* point sets whose build was skipped in the last run (input unchanged) */
 	/* world box of the reference semantics (TreeNSearch.cpp:415-522) */
 	float world_bottom[3], world_top[3];
 	int world_cells_pow2;

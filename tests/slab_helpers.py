@@ -55,3 +55,66 @@ def reference_lists(orc, sets, i, j, radius, symmetric=True):
     if ra is not None:
         return orc.pair_search(a, b, ra=ra, rb=rb, symmetric=symmetric, same_set=(i == j))
     return orc.pair_search(a, b, radius=np.float32(radius), same_set=(i == j))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# all slabs of a decomposition inside ONE process (one thread per emulated rank, one GPU): tests/test_gpu_slabs.py
+# ----------------------------------------------------------------------------------------------------------------------
+class LocalTransport:
+    """Moves the messages of SlabExchange between the emulated ranks of one process: a FIFO per (source, destination).  The
+    receiver's buffer must have exactly the shape of the message -- that IS the agreement the wire protocol promises."""
+
+    def __init__(self, world: int, timeout: float = 120.0):
+        import queue
+        self.q = {(s, d): queue.Queue() for s in range(world) for d in range(world) if abs(s - d) == 1}
+        self.timeout = timeout
+
+    def round_trip(self, rank, peers, out_msgs, in_msgs):
+        for p in peers:
+            if p in out_msgs:
+                self.q[(rank, p)].put(out_msgs[p].clone())
+        for p in peers:
+            if p in in_msgs:
+                msg = self.q[(p, rank)].get(timeout=self.timeout)
+                assert tuple(msg.shape) == tuple(in_msgs[p].shape), f"rank {rank} expected {tuple(in_msgs[p].shape)} from {p}, got {tuple(msg.shape)}"
+                in_msgs[p].copy_(msg)
+
+
+def run_slabs_in_threads(world, make_slab, step_fn, n_steps=2):
+    """Runs `n_steps` steps of `world` SlabSearch objects concurrently (thread k = rank k).  make_slab(k, transport) -> slab;
+    step_fn(k, slab, step) performs one step.  -> list of slabs.  An exception in any thread is re-raised here."""
+    import threading
+    tr = LocalTransport(world)
+    slabs, errors = [None] * world, []
+
+    def work(k):
+        try:
+            slabs[k] = make_slab(k, tr)
+            for s in range(n_steps):
+                step_fn(k, slabs[k], s)
+        except BaseException as e:   # noqa: BLE001 - reported to the main thread
+            errors.append((k, e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0][1]
+    return slabs
+
+
+def union_csr(n_global, per_rank):
+    """per_rank: [(gids, offsets, indices)] -> (offsets, indices) of all n_global points in global order"""
+    counts = np.zeros(n_global, np.int64)
+    for gids, offs, _ in per_rank:
+        counts[gids] = np.diff(offs)
+    g_offs = np.zeros(n_global + 1, np.int64)
+    np.cumsum(counts, out=g_offs[1:])
+    out = np.empty(int(g_offs[-1]), np.int64)
+    for gids, offs, idx in per_rank:
+        cnt = np.diff(offs)
+        dst = np.repeat(g_offs[gids] - offs[:-1], cnt) + np.arange(len(idx), dtype=np.int64)
+        out[dst] = idx
+    return g_offs, out

@@ -219,6 +219,21 @@ def test_cpp_dropin_scenarios(built_library, tmp_path):
     assert "FAILED" not in out.stdout and "ALL PASSED" in out.stdout
 
 
+def test_cpp_dropin_stress(built_library, tmp_path):
+    """The reference's stress scenarios through the C++ shim, every configuration compared with an all-pairs search:
+    dynamic emitter (tests.cpp:434-514: two sets that start empty with null pointers, 400 random grow / shrink / replace steps)
+    and the size lattice (tests.cpp:287-427: 1-3 sets, all combinations of awkward sizes, run -> zsort -> run)."""
+    exe = tmp_path / "shim_stress"
+    lib_dir = os.path.dirname(built_library)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fopenmp", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "shim_stress.cpp"), "-o", str(exe),
+                           "-L" + lib_dir, "-ltnsx", "-Wl,-rpath," + lib_dir])
+    out = subprocess.run([str(exe), "400", "1"], capture_output=True, text=True, timeout=1500)
+    print(out.stdout[-3000:])
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "FAILED" not in out.stdout and "ALL PASSED" in out.stdout
+
+
 def test_halo_pack_kernel_matches_torch_selection():
     """tnsx_halo_pack (multi-GPU ghost selection): same rows as the torch compare / nonzero / index_select chain, as sets;
     too small buffers report the needed size instead of overflowing."""
@@ -255,10 +270,12 @@ def test_halo_pack_kernel_matches_torch_selection():
 
 @pytest.mark.parametrize("n", [1, 3, 4, 5, 1023, 100003])
 @pytest.mark.parametrize("on_device", [False, True])
-def test_grid_follows_the_tight_bounds(n, on_device):
-    """Binning clamps coordinates, so a wrong bounding box would not change a single neighbour list -- only the speed.  The grid
-    geometry is therefore checked on its own: per-axis cell counts = floor(extent / h) + 1 over the exact min / max of the
-    points (extreme points placed at the ends of the array and in odd positions, sizes around the 4-point vector width)."""
+def test_grid_and_world_box_follow_the_tight_bounds(n, on_device, oracle):
+    """Binning clamps coordinates, so a wrong bounding box would not change a single neighbour list -- only the speed.  The box
+    geometry is therefore checked on its own, from the exact min / max of the points (extreme points placed at the ends of the
+    array and in odd positions, sizes around the 4-point vector width): the world box is the reference's snapping of the tight
+    bounds (TreeNSearch.cpp:474-521, restated in the oracle), and the search grid covers the tight bounds widened by two radii,
+    clipped to the world box, with floor(extent / h) + 1 cells per axis."""
     import torch
     import treensearch_amd as T
     rng = np.random.default_rng(n)
@@ -266,13 +283,21 @@ def test_grid_follows_the_tight_bounds(n, on_device):
     pts[n - 1] += np.float32(0.4)          # maxima at the very end
     pts[(n - 1) // 2, 1] -= np.float32(0.3)
     pts = np.ascontiguousarray(pts)
+    r = np.float32(0.013)
     ns = T.TreeNSearch()
-    ns.set_search_radius(0.013)
+    ns.set_search_radius(r)
     ns.add_point_set(torch.from_numpy(pts).cuda() if on_device else pts)
     ns.set_active_search(0, 0, True)
     ns.run()
     st = ns.get_stats()
+    tight = np.concatenate([pts.min(axis=0), pts.max(axis=0)]).astype(np.float32)
+    box = np.array([np.finfo(np.float32).max] * 3 + [-np.finfo(np.float32).max] * 3, np.float32)    # the empty box every engine starts with
+    rc, n_pow2 = oracle.world_box_update(box, tight, np.float32(1.5) * r)
+    assert rc == 1                                           # (1: the box was replaced)
+    assert np.array_equal(np.array(st["world_bottom"] + st["world_top"], np.float32), box) and st["world_cells_pow2"] == n_pow2
     h = float(st["grid_cell_size"])
-    lo, hi = pts.min(axis=0).astype(np.float64), pts.max(axis=0).astype(np.float64)
-    expect = [int(np.floor((hi[d] - lo[d]) / h)) + 1 for d in range(3)]
+    lo = np.maximum(tight[:3] - np.float32(2.0) * r, box[:3])
+    hi = np.minimum(tight[3:] + np.float32(2.0) * r, box[3:])
+    assert np.array_equal(np.array(st["grid_origin"], np.float32), lo)
+    expect = [int(np.floor((float(hi[d]) - float(lo[d])) / h)) + 1 for d in range(3)]
     assert list(st["grid_dims"]) == expect

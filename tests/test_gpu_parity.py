@@ -187,7 +187,7 @@ def test_sparse_domain_and_lazy_table_clear(oracle):
         b = rng.random((15000, 3), dtype=np.float32) * np.float32(0.03) + np.float32(far)
         return np.ascontiguousarray(np.concatenate([a, b]))
     pts = cloud(0.0, 1.2)
-    ns = T.TreeNSearch()
+    ns = T.TreeNSearch(max_dense_cells=1 << 30)      # (the default bounds the table by the number of points: see the next test)
     ns.set_search_radius(r)
     ns.add_point_set(pts)
     ns.set_active_search(0, 0, True)

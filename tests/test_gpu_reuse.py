@@ -1,0 +1,176 @@
+"""Temporal reuse (TreeNSearch.cpp:474-482 / :77-79): a run lays the previous run's grid over the points without
+computing their bounds first, and unchanged sets keep their search structures.  Both are speculation that the device verifies
+during the run; these tests drive the engine through the cases where the speculation holds and where it must be repaired,
+and compare every step with the oracle (lists) and with the oracle's restatement of the reference's world-box rule."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import parity as P   # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+F32_MAX = np.finfo(np.float32).max
+
+
+def _oracle_box(oracle, box, pts_list, cell):
+    tight = np.array([F32_MAX] * 3 + [-F32_MAX] * 3, np.float32)
+    for p in pts_list:
+        if len(p):
+            tight[:3] = np.minimum(tight[:3], p.min(axis=0))
+            tight[3:] = np.maximum(tight[3:], p.max(axis=0))
+    oracle.world_box_update(box, tight, cell)
+    return box
+
+
+@pytest.mark.parametrize("on_device", [True, False])
+def test_moving_cloud_grid_reuse_and_world_box(on_device, oracle):
+    """A cloud that drifts and expands step by step.  Steps inside the margin of the grid reuse it (speculated, no redo); the
+    step that leaves the box is noticed on the device and repeated; lists are exact at every step and the world box follows the
+    reference's rule (kept while it contains the points, re-snapped otherwise)."""
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    n = 60000
+    base = D.uniform_cloud(n, 31) * np.float32(0.5) + np.float32(0.25)
+    r = D.radius_for_neighbors(n, 35.0, 0.125)
+    pts = base.copy()
+    d_pts = torch.from_numpy(pts).cuda() if on_device else None
+    ns = T.TreeNSearch()
+    ns.set_search_radius(r)
+    ns.add_point_set(d_pts if on_device else pts)
+    ns.set_active_search(0, 0, True)
+    box = np.array([F32_MAX] * 3 + [-F32_MAX] * 3, np.float32)
+    rng = np.random.default_rng(3)
+    seen = {"reused": 0, "redone": 0}
+    #        small jitter (stays in the margin) ... one point shoots out ... jitter ... the whole cloud scales up beyond the world box
+    moves = ["jitter", "jitter", "escape", "jitter", "jitter", "blow_up", "jitter"]
+    for step, mv in enumerate(["first"] + moves):
+        if mv == "jitter":
+            pts += (rng.random(pts.shape, dtype=np.float32) - np.float32(0.5)) * np.float32(0.2) * r
+        elif mv == "escape":
+            pts[12345] += np.float32(7.5) * r                      # beyond the two-radius margin of the grid, inside the world box
+        elif mv == "blow_up":
+            pts[:] = (pts - np.float32(0.5)) * np.float32(1.6) + np.float32(0.5)
+        if on_device:
+            d_pts.copy_(torch.from_numpy(pts))
+        ns.run()
+        st = ns.get_stats()
+        P.assert_same_csr(ns.neighbor_csr(0, 0), oracle.pair_search(pts, pts, radius=r, same_set=True), f"step {step} ({mv})")
+        _oracle_box(oracle, box, [pts], np.float32(1.5) * r)
+        assert np.array_equal(np.array(st["world_bottom"] + st["world_top"], np.float32), box), f"world box after step {step} ({mv})"
+        if mv == "first":
+            assert st["speculated"] == 0
+        if mv in ("escape", "blow_up"):
+            assert st["speculation_redos"] == 1 and st["speculated"] == 0, f"step {step} ({mv}): leaving the box must be noticed"
+            seen["redone"] += 1
+        elif mv == "jitter":
+            assert st["speculated"] == 1 and st["speculation_redos"] == 0 and st["ms_bounds"] == 0.0
+            seen["reused"] += 1
+    assert seen == {"reused": 5, "redone": 2}
+
+
+def test_growing_radius_invalidates_the_grid(oracle):
+    """per-point radii: the cell edge of a reused grid covers the largest radius it was built for; a larger one must be noticed"""
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    n = 40000
+    pts = D.uniform_cloud(n, 5)
+    r0 = D.radius_for_neighbors(n, 20.0)
+    radii = (r0 * (np.float32(1.0) + np.float32(0.5) * D.uniform01(6, 0, n))).astype(np.float32)
+    d_pts, d_r = torch.from_numpy(pts).cuda(), torch.from_numpy(radii).cuda()
+    ns = T.TreeNSearch()
+    ns.add_point_set(d_pts, d_r)
+    ns.set_active_search(0, 0, True)
+    for step in range(4):
+        if step == 2:
+            radii[777] = np.float32(2.5) * r0                      # above every radius the grid was laid out for
+            d_r.copy_(torch.from_numpy(radii))
+        ns.run()
+        st = ns.get_stats()
+        ref = oracle.pair_search(pts, pts, ra=radii, rb=radii, symmetric=True, same_set=True)
+        P.assert_same_csr(ns.neighbor_csr(0, 0), ref, f"step {step}")
+        assert st["speculation_redos"] == (1 if step == 2 else 0)
+        assert st["speculated"] == (1 if step in (1, 3) else 0)
+
+
+def test_static_set_is_cached_and_changes_are_noticed(oracle):
+    """C3 shape: a moving fluid searched in itself and in a boundary that never changes.  From the third run on the boundary keeps
+    its sorted arrays and cell table (n_cached_sets == 1); changing ONE coordinate of it in place -- same pointer, same size --
+    is noticed through the checksum, the run is repeated and the lists reflect the change."""
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    fluid, boundary, r = D.two_set_cloud(40000, 10000)
+    d_f, d_b = torch.from_numpy(fluid).cuda(), torch.from_numpy(boundary).cuda()
+    ns = T.TreeNSearch()
+    ns.set_search_radius(r)
+    ns.add_point_set(d_f)
+    ns.add_point_set(d_b)
+    ns.set_active_search(0, 0, True)
+    ns.set_active_search(0, 1, True)
+    rng = np.random.default_rng(1)
+    for step in range(7):
+        fluid += (rng.random(fluid.shape, dtype=np.float32) - np.float32(0.5)) * np.float32(0.05) * r
+        d_f.copy_(torch.from_numpy(fluid))
+        if step == 4:
+            boundary[4321, 1] += np.float32(0.3) * r
+            d_b.copy_(torch.from_numpy(boundary))
+        ns.run()
+        st = ns.get_stats()
+        for (i, j, a, b) in ((0, 0, fluid, fluid), (0, 1, fluid, boundary)):
+            P.assert_same_csr(ns.neighbor_csr(i, j), oracle.pair_search(a, b, radius=r, same_set=(i == j)), f"step {step} pair {i}->{j}")
+        if step in (2, 3, 6):
+            assert st["n_cached_sets"] == 1 and st["speculation_redos"] == 0, f"step {step}: {st['n_cached_sets']} cached, {st['speculation_redos']} redos"
+        if step == 4:
+            assert st["speculation_redos"] == 1 and st["n_cached_sets"] == 0
+        if step in (0, 1, 5):
+            assert st["n_cached_sets"] == 0
+
+
+def test_reuse_can_be_switched_off(oracle):
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    pts = D.uniform_cloud(20000, 9)
+    r = D.radius_for_neighbors(20000, 30.0)
+    ns = T.TreeNSearch(temporal_reuse=False, collect_stage_times=True)
+    ns.set_search_radius(r)
+    ns.add_point_set(torch.from_numpy(pts).cuda())
+    ns.set_active_search(0, 0, True)
+    for _ in range(3):
+        ns.run()
+        st = ns.get_stats()
+        assert st["speculated"] == 0 and st["n_cached_sets"] == 0 and st["ms_bounds"] > 0.0
+    P.assert_same_csr(ns.neighbor_csr(0, 0), oracle.pair_search(pts, pts, radius=r, same_set=True), "no reuse")
+
+
+def test_zsort_between_runs_invalidates_cached_structures(oracle):
+    """prepare_zsort uses the ping-pong arrays of the search structures as scratch: a cached (static) set must be rebuilt after it"""
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    pts = D.uniform_cloud(30000, 13)
+    r = D.radius_for_neighbors(30000, 30.0)
+    d = torch.from_numpy(pts).cuda()
+    ns = T.TreeNSearch()
+    ns.set_search_radius(r)
+    ns.add_point_set(d)
+    ns.set_active_search(0, 0, True)
+    ref = oracle.pair_search(pts, pts, radius=r, same_set=True)
+    for step in range(5):
+        ns.run()
+        if step == 2:
+            assert ns.get_stats()["n_cached_sets"] == 1
+            ns.prepare_zsort()                                     # (the order is not applied: the points stay as they are)
+        if step == 3:
+            assert ns.get_stats()["n_cached_sets"] == 0
+        P.assert_same_csr(ns.neighbor_csr(0, 0), ref, f"step {step}")

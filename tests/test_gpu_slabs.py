@@ -1,0 +1,248 @@
+"""configs[4] on ONE GPU: the slab path (treensearch_amd/multi.py) on the real HIP engine.
+
+A cloud is cut into 2 / 4 / 8 x-slabs with SlabDecomposition's balanced cuts; every slab runs the SAME SlabSearch code the
+multi-GPU bench runs -- tnsx_halo_pack, [owned | ghosts], candidates-only ghosts, global ids from the engine -- one thread per
+emulated rank, the messages moved by an in-process transport instead of RCCL.  The union of the slabs' lists must equal the
+single-device result of the engine AND the digest the real reference produced for the same cloud (tests/golden)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import cases as CS                 # noqa: E402
+from conftest import load_golden   # noqa: E402
+from slab_helpers import run_slabs_in_threads, union_csr   # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine_factory():
+    import torch
+    import treensearch_amd as T
+    return T.TreeNSearch(stream=torch.cuda.current_stream().cuda_stream)
+
+
+def _single_device(case):
+    """(offsets, indices unsorted) of pair 0->0 from one engine over the whole cloud"""
+    import torch
+    import treensearch_amd as T
+    ns = T.TreeNSearch()
+    variable = case.radii is not None
+    if not variable:
+        ns.set_search_radius(case.radius)
+    pts = torch.from_numpy(case.points[0]).cuda()
+    rad = torch.from_numpy(case.radii[0]).cuda() if variable else None
+    ns.add_point_set(pts, rad)
+    ns.set_active_search(0, 0, True)
+    ns.set_symmetric_search(case.symmetric)
+    ns.run()
+    return ns.neighbor_csr(0, 0, sort_each=False)
+
+
+def _run_slabs(case, world, n_steps=2, speculative=True, shrink_caps_before_step=None):
+    import torch
+    from treensearch_amd.multi import SlabDecomposition, SlabSearch
+    pts_h = case.points[0]
+    variable = case.radii is not None
+    rad_h = case.radii[0] if variable else None
+    max_r = float(rad_h.max()) if variable else float(case.radius)
+    halo = max_r * 1.001
+    d_all = torch.from_numpy(pts_h).cuda()
+    dec = SlabDecomposition(engine=_engine_factory())
+    cuts = dec.balanced_cuts([d_all], plane_width=halo * 1.001, n_slabs=world)
+    owner = SlabDecomposition.owner_of(d_all[:, 0], cuts).cpu().numpy()
+    owned = []
+    for k in range(world):
+        g = np.nonzero(owner == k)[0]
+        owned.append((torch.from_numpy(pts_h[g]).cuda(), torch.from_numpy(g.astype(np.int64)).cuda(),
+                      torch.from_numpy(rad_h[g]).cuda() if variable else None))
+
+    def make_slab(k, tr):
+        s = SlabSearch(float(cuts[k]), float(cuts[k + 1]), None if variable else float(case.radius), _engine_factory,
+                       max_radius=max_r if variable else None, transport=tr, rank=k, world=world, speculative=speculative)
+        s.set_symmetric_search(case.symmetric)
+        return s
+
+    log = [[] for _ in range(world)]
+
+    def step(k, slab, s):
+        if shrink_caps_before_step == s:
+            # pretend the halos were much thinner when the capacities were agreed: the speculative exchange overflows
+            for p in list(slab.ex._caps):
+                slab.ex._caps[p] = (8, 8)
+        pp, gg, rr = owned[k]
+        slab.step(pp, gg, rr) if variable else slab.step(pp, gg)
+        log[k].append((slab.ex.speculative_last, slab.redone_last, slab.ex.rounds_last))
+
+    slabs = run_slabs_in_threads(world, make_slab, step, n_steps)
+    per_rank = []
+    for k in range(world):
+        offs, idx = slabs[k].engine.neighbor_csr(slabs[k].sets[0].set_id, slabs[k].sets[0].set_id, sort_each=False)
+        assert len(offs) == len(owned[k][1]) + 1, "ghosts must not get lists"
+        per_rank.append((owned[k][1].cpu().numpy(), offs, idx.astype(np.int64)))
+    return union_csr(len(pts_h), per_rank), log, [len(o[1]) for o in owned], slabs
+
+
+def _check_union(case, union, single, oracle, golden_key="0->0"):
+    g_offs, g_idx = union
+    s_offs, s_idx = single
+    assert np.array_equal(g_offs, s_offs), "neighbour counts of the slab union differ from the single-device run"
+    d_union = oracle.digest(g_offs, g_idx.astype(np.int32))
+    assert d_union == oracle.digest(s_offs, s_idx), "lists of the slab union differ from the single-device run"
+    fx = load_golden(case.name)["pairs"][golden_key]["strict"]
+    assert int(g_offs[-1]) == fx["total"]
+    assert (f"{d_union[0]:016x}", f"{d_union[1]:016x}") == (fx["digest_sum"], fx["digest_xor"]), "slab union differs from the reference's digest"
+    # a few full lists, element by element
+    rng = np.random.default_rng(5)
+    for p in rng.integers(0, len(g_offs) - 1, 200):
+        assert np.array_equal(np.sort(g_idx[g_offs[p]:g_offs[p + 1]]), np.sort(s_idx[s_offs[p]:s_offs[p + 1]]).astype(np.int64))
+
+
+@pytest.fixture(scope="module")
+def uniform_2m():
+    case = CS.by_name("uniform_fixed_2000000")
+    return case, _single_device(case)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_c5_scaled_uniform_slab_union(world, uniform_2m, oracle):
+    """configs[4] at 2 M points: union of 2 / 4 / 8 slabs == single device == reference digest; the second step is speculative"""
+    case, single = uniform_2m
+    union, log, sizes, _ = _run_slabs(case, world)
+    _check_union(case, union, single, oracle)
+    assert max(sizes) < 1.2 * (len(case.points[0]) / world), f"unbalanced slabs {sizes}"
+    for k in range(world):
+        assert log[k][0][0] is False and log[k][0][2] == 2, "first step: exact mode, two rounds"
+        assert log[k][1] == (True, False, 1), f"rank {k}: second step should be one speculative round without a redo, got {log[k][1]}"
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_dam_break_slab_union_variable_radii(world, oracle):
+    """clustered cloud (unequal cuts), per-point radii, symmetric search"""
+    case = CS.by_name("dam_break_sym_1000000")
+    single = _single_device(case)
+    union, log, sizes, _ = _run_slabs(case, world)
+    _check_union(case, union, single, oracle)
+
+
+def test_speculative_overflow_is_redone(oracle):
+    """a capacity that turns out too small: validate() fails after the run, the step is repeated in exact mode, results stay exact"""
+    case = CS.by_name("uniform_fixed_1000000")
+    single = _single_device(case)
+    union, log, _, _ = _run_slabs(case, 4, n_steps=3, shrink_caps_before_step=1)
+    _check_union(case, union, single, oracle)
+    assert any(l[1][1] for l in log), "the overflow should have forced a redo"
+    assert all(l[2] == (True, False, 1) for l in log), "the step after the redo is speculative again"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the device-side pieces on their own
+# ----------------------------------------------------------------------------------------------------------------------
+def test_query_count_point_ids_and_nan_points(oracle):
+    """tnsx_set_query_count (candidates-only tail), tnsx_set_point_ids (ids instead of indices), NaN x = no point"""
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    n, nq = 30000, 21000
+    pts = D.uniform_cloud(n, 321)
+    r = D.radius_for_neighbors(n, 40.0)
+    absent = np.arange(n - 500, n)                       # the last 500 rows are padding
+    pts_nan = pts.copy()
+    pts_nan[absent, 0] = np.nan
+    ids = (np.arange(n, dtype=np.int32)[::-1] * 3 + 7).copy()
+    ns = T.TreeNSearch()
+    ns.set_search_radius(r)
+    d_pts, d_ids = torch.from_numpy(pts_nan).cuda(), torch.from_numpy(ids).cuda()
+    s = ns.add_point_set(d_pts)
+    ns.set_active_search(s, s, True)
+    ns.set_query_count(s, nq)
+    ns.set_point_ids(s, d_ids)
+    for _ in range(2):
+        ns.run()
+    offs, idx = ns.neighbor_csr(s, s)
+    ro, ri = oracle.pair_search(pts[:n - 500], pts[:n - 500], radius=r, same_set=True)
+    assert len(offs) == nq + 1 and np.array_equal(offs, ro[:nq + 1])
+    want = ids[ri[:ro[nq]]]
+    lid = np.repeat(np.arange(nq), np.diff(ro[:nq + 1]))
+    want = want[np.lexsort((want, lid))]
+    assert np.array_equal(idx, want)
+    # back to plain indices, every real point a query (absent points have no list: their offsets are unspecified)
+    ns.set_point_ids(s, None)
+    ns.set_query_count(s, n - 500)
+    ns.run()
+    offs, idx = ns.neighbor_csr(s, s)
+    assert np.array_equal(offs, ro) and np.array_equal(idx, ri)
+
+
+def test_translate_neighbors_kernel(oracle):
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    n = 20000
+    pts = D.uniform_cloud(n, 11)
+    r = D.radius_for_neighbors(n, 30.0)
+    ns = T.TreeNSearch()
+    ns.set_search_radius(r)
+    s = ns.add_point_set(torch.from_numpy(pts).cuda())
+    ns.set_active_search(s, s, True)
+    ns.run()
+    id_map = np.random.default_rng(1).permutation(n).astype(np.int32) + 1000
+    ns.translate_neighbors(s, s, torch.from_numpy(id_map).cuda())
+    offs, idx = ns.neighbor_csr(s, s)
+    ro, ri = oracle.pair_search(pts, pts, radius=r, same_set=True)
+    want = id_map[ri]
+    lid = np.repeat(np.arange(n), np.diff(ro))
+    assert np.array_equal(offs, ro) and np.array_equal(idx, want[np.lexsort((want, lid))])
+
+
+def test_x_histogram_kernel():
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    pts = D.uniform_cloud(300000, 8) * np.float32(3.0) - np.float32(1.0)
+    pts[::1000, 0] = np.nan
+    ns = T.TreeNSearch()
+    d = torch.from_numpy(pts).cuda()
+    for n_bins, x0, w in ((64, -1.0, 0.05), (5000, -0.5, 0.0004), (20000, -1.0, 0.00015)):
+        h = torch.zeros(n_bins, dtype=torch.int32, device="cuda")
+        inv = float(np.float32(1.0) / np.float32(w))
+        ns.x_histogram(d, x0, inv, h)
+        ns.synchronize()
+        x = pts[:, 0][~np.isnan(pts[:, 0])]
+        b = np.clip(((x - np.float32(x0)) * np.float32(inv)).astype(np.int64), 0, n_bins - 1)
+        assert np.array_equal(h.cpu().numpy(), np.bincount(b, minlength=n_bins))
+
+
+def test_halo_pack_asymmetric_capacities():
+    """each side has its own capacity -- a big left halo with a small right buffer (and the other way round)
+    must neither truncate the big side nor overrun the small one"""
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    n = 400000
+    pts = D.uniform_cloud(n, 77)
+    d_pts = torch.from_numpy(pts).cuda()
+    gids = torch.arange(n, dtype=torch.int64, device="cuda") + (1 << 33)
+    ns = T.TreeNSearch()
+    counts = torch.zeros(2, dtype=torch.int32, device="cuda")
+    left_cut, right_cut = 0.30, 0.995                    # ~120 k rows to the left, ~2 k to the right
+    n_l, n_r = int((pts[:, 0] < np.float32(left_cut)).sum()), int((pts[:, 0] >= np.float32(right_cut)).sum())
+    for cap_l, cap_r in ((n_l + 10, n_r + 3), (n_l + 10, 100), (1000, n_r + 3)):
+        out_l = torch.full((cap_l, 5), -1.0, device="cuda")
+        out_r = torch.full((cap_r + 1, 5), -1.0, device="cuda")           # one guard row behind the right buffer
+        cl, cr = ns.halo_pack(d_pts, gids, None, left_cut, right_cut, out_l, out_r[:cap_r], counts)
+        assert (cl, cr) == (n_l, n_r)
+        assert torch.all(out_r[cap_r] == -1.0), "the right buffer was overrun"
+        for out, cap, cnt, sel in ((out_l, cap_l, n_l, pts[:, 0] < np.float32(left_cut)), (out_r, cap_r, n_r, pts[:, 0] >= np.float32(right_cut))):
+            rows = out[:min(cap, cnt)].cpu()
+            got = rows[:, 3:5].contiguous().view(torch.int64).view(-1).numpy() - (1 << 33)
+            assert len(np.unique(got)) == len(got) and np.all(sel[got]), "rows that do not belong to the selection"
+            assert np.array_equal(rows[:, 0:3].numpy(), pts[got])
+            if cnt <= cap:
+                assert len(got) == cnt

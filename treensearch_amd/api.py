@@ -34,7 +34,8 @@ class TnsxError(RuntimeError):
 
 class _Options(C.Structure):
     _fields_ = [("device_id", C.c_int), ("stream", C.c_void_p), ("arith", C.c_int), ("mirror_to_host", C.c_int),
-                ("collect_stage_times", C.c_int), ("exact_layout", C.c_int), ("max_dense_cells", C.c_uint64), ("reserved", C.c_int * 7)]
+                ("collect_stage_times", C.c_int), ("exact_layout", C.c_int), ("max_dense_cells", C.c_uint64), ("temporal_reuse", C.c_int),
+                ("reserved", C.c_int * 6)]
 
 
 class _CsrView(C.Structure):
@@ -46,12 +47,13 @@ class _CsrView(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("n_sets", C.c_int), ("n_points", C.c_uint64), ("n_queries", C.c_uint64), ("n_neighbors", C.c_uint64),
                 ("n_occupied_cells", C.c_uint64), ("n_grid_cells", C.c_uint64), ("grid_dims", C.c_int * 3),
-                ("grid_cell_size", C.c_float), ("key_bits", C.c_int), ("radix_passes", C.c_int),
+                ("grid_cell_size", C.c_float), ("grid_origin", C.c_float * 3), ("key_bits", C.c_int), ("radix_passes", C.c_int),
                 ("bytes_build", C.c_uint64), ("bytes_query", C.c_uint64),
-                ("ms_total", C.c_float), ("ms_upload", C.c_float), ("ms_bounds", C.c_float), ("ms_keys", C.c_float),
-                ("ms_sort", C.c_float), ("ms_gather", C.c_float), ("ms_cells", C.c_float), ("ms_count", C.c_float),
+                ("ms_total", C.c_float), ("ms_upload", C.c_float), ("ms_bounds", C.c_float), ("ms_table_clear", C.c_float),
+                ("ms_sort", C.c_float), ("ms_cells", C.c_float), ("ms_count", C.c_float),
                 ("ms_scan", C.c_float), ("ms_fill", C.c_float), ("ms_mirror", C.c_float),
-                ("n_pool_pairs", C.c_int), ("pool_retries", C.c_int), ("n_fast_builds", C.c_int),
+                ("n_pool_pairs", C.c_int), ("pool_retries", C.c_int), ("cold_passes", C.c_int), ("speculated", C.c_int),
+                ("speculation_redos", C.c_int), ("n_cached_sets", C.c_int),
                 ("world_bottom", C.c_float * 3), ("world_top", C.c_float * 3), ("world_cells_pow2", C.c_int)]
 
     def as_dict(self):
@@ -183,7 +185,7 @@ class NeighborList:
 class TreeNSearch:
     def __init__(self, *, arith: int = ARITH_STRICT, mirror_to_host: bool = False, device_id: int = -1,
                  stream: Optional[int] = None, collect_stage_times: bool = False, max_dense_cells: int = 0,
-                 exact_layout: bool = False):
+                 exact_layout: bool = False, temporal_reuse: bool = True):
         self._L = load_library()
         opt = _Options()
         self._L.tnsx_default_options(C.byref(opt))
@@ -194,6 +196,7 @@ class TreeNSearch:
         opt.collect_stage_times = int(collect_stage_times)
         opt.max_dense_cells = max_dense_cells
         opt.exact_layout = int(exact_layout)
+        opt.temporal_reuse = int(temporal_reuse)
         h = C.c_void_p()
         st = self._L.tnsx_create(C.byref(opt), C.byref(h))
         if st != 0:

@@ -86,28 +86,85 @@ __device__ __forceinline__ uint64_t sort_key(float x, float y, float z, const Gr
 	return x != x ? ~0ull : (spread3(ux) | (spread3(uy) << 1) | (spread3(uz) << 2));   // NaN: behind everything
 }
 
+// ---- run-time validation of what tnsx_run speculates on (both ride on the first histogram pass, which reads every point anyway):
+//   guard     the search grid of the previous run is reused without looking at the bounds first; a point outside the box the
+//             grid was laid out for (or a radius above the one its cell edge covers) raises *flag and the host repeats the run
+//   checksum  order-sensitive 64-bit sum over the raw bits of all points (and radii): a set whose checksum, pointer and size did
+//             not change keeps its sorted arrays and cell table (the static boundary of an SPH scene)
+__device__ __forceinline__ unsigned long long point_hash(uint32_t i, float x, float y, float z, float r)
+{
+	unsigned long long a = ((unsigned long long)__float_as_uint(y) << 32) | __float_as_uint(x);
+	unsigned long long b = ((unsigned long long)__float_as_uint(r) << 32) | __float_as_uint(z);
+	a = (a ^ (a >> 29)) * 0xBF58476D1CE4E5B9ull;
+	b = (b + 0x9E3779B97F4A7C15ull * (2ull * i + 1ull)) * 0x94D049BB133111EBull;
+	unsigned long long h = a ^ b ^ (a >> 31) ^ (b >> 27);
+	return h * (2ull * i + 1ull);
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+	#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+	return v;
+}
+__device__ __forceinline__ bool outside(const BuildGuard& gd, float x, float y, float z)
+{
+	// (NaN x = "no point": not outside; NaN in y or z fails the comparisons and is reported)
+	return x == x && !(x >= gd.lo[0] && x <= gd.hi[0] && y >= gd.lo[1] && y <= gd.hi[1] && z >= gd.lo[2] && z <= gd.hi[2]);
+}
+
 // ---- per-tile histogram of one digit -----------------------------------------------------------------------------
 template <int BITS, bool FIRST, bool MORTON>
 __global__ void __launch_bounds__(CS_THREADS) k_cs_hist(const float* __restrict__ xyz, const float4* __restrict__ xyzi, int n, GridParams g, int shift,
-                                                        uint32_t* __restrict__ hist, int ntiles)
+                                                        uint32_t* __restrict__ hist, int ntiles, const float* __restrict__ radii, BuildGuard gd)
 {
 	constexpr int RADIX = 1 << BITS;
 	__shared__ uint32_t h[RADIX];
 	for (int b = threadIdx.x; b < RADIX; b += CS_THREADS) h[b] = 0;
 	__syncthreads();
 	const size_t base = (size_t)blockIdx.x * CS_TILE;
+	bool bad = false;
+	unsigned long long chk = 0;
 	#pragma unroll 8
 	for (int i = 0; i < CS_ITEMS; i++) {
 		const size_t e = base + (size_t)i * CS_THREADS + threadIdx.x;
 		if (e < (size_t)n) {
 			uint64_t key;
-			if (FIRST) { const F3 q = reinterpret_cast<const F3*>(xyz)[e]; key = sort_key<MORTON>(q.x, q.y, q.z, g); }
+			if (FIRST) {
+				const F3 q = reinterpret_cast<const F3*>(xyz)[e];
+				key = sort_key<MORTON>(q.x, q.y, q.z, g);
+				if (!MORTON) {
+					if (gd.flag) bad |= outside(gd, q.x, q.y, q.z);
+					if (gd.checksum) chk += point_hash((uint32_t)e, q.x, q.y, q.z, radii ? radii[e] : 0.0f);
+				}
+			}
 			else { const float4 q = xyzi[e]; key = sort_key<MORTON>(q.x, q.y, q.z, g); }
 			atomicAdd(&h[(uint32_t)(key >> shift) & (RADIX - 1)], 1u);
 		}
 	}
+	if (FIRST && !MORTON) {
+		if (gd.flag && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane_id() == 0) atomicOr(gd.flag, 1u);
+		if (gd.checksum) { chk = wave_sum_u64(chk); if (lane_id() == 0 && chk) atomicAdd(gd.checksum, chk); }
+	}
 	__syncthreads();
 	for (int b = threadIdx.x; b < RADIX; b += CS_THREADS) hist[(size_t)blockIdx.x * RADIX + b] = h[b];   // row = tile: coalesced
+}
+// the checksum alone (a set that is taken to be static skips its build; this verifies the assumption)
+__global__ void __launch_bounds__(256) k_set_checksum(const float* __restrict__ xyz, const float* __restrict__ radii, int n, unsigned long long* __restrict__ out)
+{
+	unsigned long long chk = 0;
+	for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < (size_t)n; e += (size_t)gridDim.x * 256) {
+		const F3 q = reinterpret_cast<const F3*>(xyz)[e];
+		chk += point_hash((uint32_t)e, q.x, q.y, q.z, radii ? radii[e] : 0.0f);
+	}
+	chk = wave_sum_u64(chk);
+	if (lane_id() == 0 && chk) atomicAdd(out, chk);
+}
+void launch_set_checksum(const float* xyz, const float* radii, int n, unsigned long long* out, hipStream_t s)
+{
+	if (n <= 0) return;
+	int blocks = (n + 256 * 16 - 1) / (256 * 16);
+	blocks = blocks > 4096 ? 4096 : blocks;
+	hipLaunchKernelGGL(k_set_checksum, dim3(blocks), dim3(256), 0, s, xyz, radii, n, out);
 }
 
 // ---- scan of the tile histograms down the columns: hist[tile][value] -> exclusive prefix over the tiles, totals[value].
@@ -156,7 +213,7 @@ template <int BITS, bool FIRST, bool VARIABLE, bool MORTON>
 __global__ void __launch_bounds__(CS_THREADS) __attribute__((amdgpu_waves_per_eu(BITS <= 10 ? 4 : 3, 4)))
 k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, const float4* __restrict__ xyzi_in, const float* __restrict__ r2_in,
              float4* __restrict__ xyzi_out, float* __restrict__ r2_out, int n, GridParams g, int shift, const uint32_t* __restrict__ hist_scanned,
-             const uint32_t* __restrict__ totals, int ntiles, const int* __restrict__ ids, uint32_t* __restrict__ orig_out)
+             const uint32_t* __restrict__ totals, int ntiles, const int* __restrict__ ids, uint32_t* __restrict__ orig_out, BuildGuard gd)
 {
 	constexpr int RADIX = 1 << BITS;
 	constexpr int PER = RADIX / CS_THREADS;   // digit values per thread in the prefix steps
@@ -170,6 +227,7 @@ k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, con
 
 	float px[CS_ITEMS], py[CS_ITEMS], pz[CS_ITEMS], pw[CS_ITEMS];   // (scalar arrays: a float4 array ends up in scratch)
 	float rr[CS_ITEMS];
+	bool bad_r = false;
 	// this wave's CS_ITEMS*64 consecutive elements: wave-uniform 64-bit base + 32-bit lane offsets (scalar-base addressing)
 	const size_t wbase = (size_t)tile * CS_TILE + (size_t)w * (CS_ITEMS * WAVE);
 	const uint32_t rem = wbase < (size_t)n ? (uint32_t)((size_t)n - wbase < (size_t)(CS_ITEMS * WAVE) ? (size_t)n - wbase : (size_t)(CS_ITEMS * WAVE)) : 0u;
@@ -183,7 +241,7 @@ k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, con
 		if (FIRST) {
 			const F3 q = (reinterpret_cast<const F3*>(xyz) + lbase)[lc];
 			px[i] = q.x; py[i] = q.y; pz[i] = q.z; pw[i] = __uint_as_float((uint32_t)wbase + li);
-			if (VARIABLE) { const float r = (radii + lbase)[lc]; rr[i] = __fmul_rn(r, r); }   // single pass: index = position
+			if (VARIABLE) { const float r = (radii + lbase)[lc]; rr[i] = __fmul_rn(r, r); bad_r |= r > gd.r_max; }   // single pass: index = position
 		}
 		else {
 			const float4 q = (xyzi_in + lbase)[lc];
@@ -193,8 +251,10 @@ k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, con
 	if (VARIABLE && !FIRST) {
 		// gather by original index (the radii array of a 50 M-point set is 200 MB: it stays in the 256 MB Infinity Cache)
 		#pragma unroll
-		for (int i = 0; i < CS_ITEMS; i++) { const float r = radii[__float_as_uint(pw[i])]; rr[i] = __fmul_rn(r, r); }
+		for (int i = 0; i < CS_ITEMS; i++) { const float r = radii[__float_as_uint(pw[i])]; rr[i] = __fmul_rn(r, r); bad_r |= r > gd.r_max; }
 	}
+	// (speculated grid: a radius above the one the cell edge was chosen for -> the host repeats the run with fresh bounds)
+	if (VARIABLE && gd.flag && __builtin_amdgcn_ballot_w64(bad_r) != 0ull && lane == 0) atomicOr(gd.flag, 1u);
 
 	// global base of every digit value for this tile = (exclusive scan of the totals) + (scanned tile count).  Thread t owns the
 	// PER consecutive values [t*PER, t*PER + PER).
@@ -272,10 +332,11 @@ k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, con
 }
 
 template <int BITS, bool MORTON>
-static void cs_hist(bool first, const float* xyz, const float4* xyzi, int n, const GridParams& g, int shift, uint32_t* hist, int ntiles, hipStream_t s)
+static void cs_hist(bool first, const float* xyz, const float4* xyzi, int n, const GridParams& g, int shift, uint32_t* hist, int ntiles, const float* radii,
+                    const BuildGuard& gd, hipStream_t s)
 {
-	if (first) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_hist<BITS, true, MORTON>), dim3(ntiles), dim3(CS_THREADS), 0, s, xyz, xyzi, n, g, shift, hist, ntiles);
-	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_hist<BITS, false, MORTON>), dim3(ntiles), dim3(CS_THREADS), 0, s, xyz, xyzi, n, g, shift, hist, ntiles);
+	if (first) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_hist<BITS, true, MORTON>), dim3(ntiles), dim3(CS_THREADS), 0, s, xyz, xyzi, n, g, shift, hist, ntiles, radii, gd);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_hist<BITS, false, MORTON>), dim3(ntiles), dim3(CS_THREADS), 0, s, xyz, xyzi, n, g, shift, hist, ntiles, radii, gd);
 }
 template <int BITS>
 static void cs_scan(uint32_t* hist, int ntiles, uint32_t* strip_sums, uint32_t* totals, hipStream_t s)
@@ -287,11 +348,11 @@ static void cs_scan(uint32_t* hist, int ntiles, uint32_t* strip_sums, uint32_t* 
 template <int BITS, bool MORTON>
 static void cs_scatter(bool first, bool variable, const float* xyz, const float* radii, const float4* xyzi_in, const float* r2_in, float4* xyzi_out,
                        float* r2_out, int n, const GridParams& g, int shift, const uint32_t* hs, const uint32_t* totals, int ntiles, const int* ids,
-                       uint32_t* orig_out, hipStream_t s)
+                       uint32_t* orig_out, const BuildGuard& gd, hipStream_t s)
 {
 #define TNSX_CS_GO(F, V)                                                                                                                       \
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_scatter<BITS, F, V, MORTON>), dim3(cs_grid(ntiles)), dim3(CS_THREADS), 0, s, xyz, radii, xyzi_in, r2_in, xyzi_out, \
-	                   r2_out, n, g, shift, hs, totals, ntiles, ids, orig_out)
+	                   r2_out, n, g, shift, hs, totals, ntiles, ids, orig_out, gd)
 	if (MORTON) { if (first) TNSX_CS_GO(true, false); else TNSX_CS_GO(false, false); }   // the z-order carries no radii
 	else if (first) { if (variable) TNSX_CS_GO(true, true); else TNSX_CS_GO(true, false); }
 	else            { if (variable) TNSX_CS_GO(false, true); else TNSX_CS_GO(false, false); }
@@ -308,7 +369,7 @@ static void cs_scatter(bool first, bool variable, const float* xyz, const float*
 
 template <bool MORTON>
 static int point_sort(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, const int* ids,
-                      uint32_t* orig_out, hipStream_t s)
+                      uint32_t* orig_out, const BuildGuard& gd, hipStream_t s)
 {
 	const CellSortPlan plan = cell_sort_plan(key_bits);
 	if (n <= 0) return plan.passes & 1;
@@ -321,20 +382,20 @@ static int point_sort(const float* xyz, const float* radii, int n, GridParams g,
 	int cur = 0, shift = 0;
 	for (int p = 0; p < plan.passes; p++) {
 		const int bits = plan.bits[p];
-		TNSX_CS_DISPATCH(bits, (cs_hist<B, MORTON>(p == 0, xyz, b.xyzi[cur], n, g, shift, hist, ntiles, s)));
+		TNSX_CS_DISPATCH(bits, (cs_hist<B, MORTON>(p == 0, xyz, b.xyzi[cur], n, g, shift, hist, ntiles, radii, gd, s)));
 		TNSX_CS_DISPATCH(bits, cs_scan<B>(hist, ntiles, strip_sums, totals, s));
 		const bool last = p == plan.passes - 1;
 		TNSX_CS_DISPATCH(bits, (cs_scatter<B, MORTON>(p == 0, variable && last, xyz, radii, b.xyzi[cur], b.r2[cur], b.xyzi[cur ^ 1], b.r2[cur ^ 1], n, g, shift, hist,
-		                                              totals, ntiles, last ? ids : nullptr, orig_out, s)));
+		                                              totals, ntiles, last ? ids : nullptr, orig_out, gd, s)));
 		cur ^= 1;
 		shift += bits;
 	}
 	return cur;
 }
 int launch_cell_sort(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, const int* ids,
-                     uint32_t* orig_sorted, hipStream_t s)
+                     uint32_t* orig_sorted, const BuildGuard& gd, hipStream_t s)
 {
-	return point_sort<false>(xyz, radii, n, g, key_bits, b, temp, ids, orig_sorted, s);
+	return point_sort<false>(xyz, radii, n, g, key_bits, b, temp, ids, orig_sorted, gd, s);
 }
 
 __global__ void __launch_bounds__(256) k_extract_order(const float4* __restrict__ xyzi, int n, int* __restrict__ order)
@@ -344,7 +405,7 @@ __global__ void __launch_bounds__(256) k_extract_order(const float4* __restrict_
 }
 int launch_morton_sort(const float* xyz, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, int* order_out, hipStream_t s)
 {
-	const int res = point_sort<true>(xyz, nullptr, n, g, key_bits, b, temp, nullptr, nullptr, s);
+	const int res = point_sort<true>(xyz, nullptr, n, g, key_bits, b, temp, nullptr, nullptr, BuildGuard{}, s);
 	if (n > 0) hipLaunchKernelGGL(k_extract_order, dim3((n + 255) / 256), dim3(256), 0, s, b.xyzi[res], n, order_out);
 	return res;
 }

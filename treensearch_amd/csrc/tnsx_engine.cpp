@@ -92,6 +92,12 @@ struct PointSet {
 	// are set, 2 = unknown (a run failed half way): full memset.
 	int table_state = 0;
 	uint32_t table_dirty = 0;
+	// static-set cache: checksum / identity of the input of the last run, and whether the two last runs saw the same input
+	bool chk_valid = false, predicted_static = false, chk_double = false;
+	uint64_t chk_value = 0;
+	const void* chk_xyz = nullptr; const void* chk_radii = nullptr;
+	int chk_n = -1;
+	uint32_t built_gen = 0;        // grid generation the sorted arrays / table were built for (0: none)
 	// zsort
 	std::vector<int> zsort_host;    // filled on demand (zsort_host_order)
 	int zsort_n = 0;
@@ -137,10 +143,16 @@ struct tnsx_context {
 	float world[6] = { FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX };   // bottom, top (octree_internals.h:29-30)
 	int world_cells_pow2 = 0;
 	bool ran = false;
+	// the search grid of the last run and what it was laid out for (temporal reuse, see run_once)
+	tnsx::GridParams grid{};
+	float grid_h = 0.0f, grid_lo[3] = { 0, 0, 0 }, grid_hi[3] = { 0, 0, 0 }, grid_r_max = 0.0f;
+	bool grid_valid = false, grid_variable = false;
+	uint32_t grid_gen = 0;
+	bool auto_dense_cells = true;
 	bool debug_nostore = std::getenv("TNSX_DEBUG_NOSTORE") != nullptr;   // timing experiments only: pool pass without its stores
 
 	// scratch
-	DevBuf bounds_partials, bounds_out, sort_temp, scan_temp, n_occ, permute_tmp, pool_ctrl;
+	DevBuf bounds_partials, bounds_out, sort_temp, scan_temp, n_occ, permute_tmp, pool_ctrl, run_words;
 	PinnedBuf h_small;
 	tnsx_stats stats{};
 	std::vector<hipEvent_t> events;
@@ -333,6 +345,7 @@ tnsx_status tnsx_default_options(tnsx_options* opt)
 	opt->collect_stage_times = 0;
 	opt->exact_layout = 0;
 	opt->max_dense_cells = 0;
+	opt->temporal_reuse = 1;
 	return TNSX_OK;
 }
 
@@ -349,6 +362,7 @@ tnsx_status tnsx_create(const tnsx_options* opt, tnsx_context** out)
 	}
 	tnsx_context* c = new tnsx_context();
 	if (opt) c->opt = *opt; else tnsx_default_options(&c->opt);
+	c->auto_dense_cells = c->opt.max_dense_cells == 0;   // default: bounded by the number of points (see run_once)
 	if (c->opt.max_dense_cells == 0) c->opt.max_dense_cells = (uint64_t)1 << 30;
 	if (c->opt.max_dense_cells > ((uint64_t)1 << 30)) c->opt.max_dense_cells = (uint64_t)1 << 30;   // 32-bit keys, int cell arithmetic
 	int dev = c->opt.device_id;
@@ -500,10 +514,15 @@ uint64_t tnsx_get_neighborlist_n_bytes(const tnsx_context* c)
 // ------------------------------------------------------------------------------------------------ run
 enum Stage { ST_UPLOAD, ST_BOUNDS, ST_KEYS, ST_SORT, ST_GATHER, ST_CELLS, ST_COUNT, ST_SCAN, ST_FILL, ST_MIRROR, ST_N };
 
-tnsx_status tnsx_run(tnsx_context* c)
+// One attempt of run().  `speculate`: the search grid of the previous run is laid over the points without looking at their
+// bounds first (no bounds kernel, no host round trip before the build), and sets that did not change between the last two runs
+// keep their sorted arrays and cell table.  Both assumptions are checked on the device while the run proceeds (BuildGuard) and
+// read back with the record totals at the one synchronisation every run has anyway; *redo tells the caller that one of them
+// was wrong -- the run is then repeated without speculation.  This is the reference's own temporal reuse (the world box
+// persists while it contains the points, TreeNSearch.cpp:474-482; unchanged sets, :77-79) moved off the critical path.
+static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 {
-	if (!c) return TNSX_ERR_INVALID;
-	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
+	*redo = false;
 	StageTimer tm(c);
 	struct Span { int stage, a, b; };
 	std::vector<Span> spans;
@@ -512,7 +531,9 @@ tnsx_status tnsx_run(tnsx_context* c)
 	const int n_sets = (int)c->sets.size();
 	hipStream_t st = c->stream;
 	tnsx_stats& S = c->stats;
+	const int retries_so_far = S.speculation_redos;
 	std::memset(&S, 0, sizeof(S));
+	S.speculation_redos = retries_so_far;
 	S.n_sets = n_sets;
 	c->ran = false;
 
@@ -522,9 +543,20 @@ tnsx_status tnsx_run(tnsx_context* c)
 	const int e_up = tm.mark();
 	span(ST_UPLOAD, e_begin, e_up);
 
-	// ---- bounds (tight AABB, radius range) -> host
-	float b8[8];
-	{ const tnsx_status r = compute_bounds(c, b8); if (r != TNSX_OK) return r; }
+	int64_t n_total = 0;
+	for (const PointSet& s : c->sets) n_total += s.n;
+	S.n_points = (uint64_t)n_total;
+	const bool variable = !c->radius_set;
+
+	// ---- bounds (tight AABB, radius range) -> host, unless the previous run's grid is reused
+	float b8[8] = { FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX, FLT_MAX, -FLT_MAX };
+	if (!speculate) {
+		const tnsx_status r = compute_bounds(c, b8);
+		if (r != TNSX_OK) return r;
+		for (int k = 0; k < 6; k++) {
+			if (n_total > 0 && !std::isfinite(b8[k])) TNSX_FAIL(c, TNSX_ERR_INVALID, "a point coordinate is not finite (inf, or NaN in y / z)");
+		}
+	}
 	const int e_bounds = tm.mark();
 	span(ST_BOUNDS, e_up, e_bounds);
 	{ const tnsx_status r = setup_and_check(c, b8); if (r != TNSX_OK) return r; }
@@ -534,58 +566,101 @@ tnsx_status tnsx_run(tnsx_context* c)
 	for (PairResult& p : c->pairs) { p.valid = false; p.mirrored = false; }
 	c->n_sets_at_last_run = n_sets;
 
-	int64_t n_total = 0;
-	for (const PointSet& s : c->sets) n_total += s.n;
-	S.n_points = (uint64_t)n_total;
-
-	// ---- world box of the reference semantics (kept for zsort + the 2^15 cells/dimension limit)
-	if (n_total > 0) { const tnsx_status r = update_world_box(c, b8); if (r != TNSX_OK) return r; }
-	for (int d = 0; d < 3; d++) { S.world_bottom[d] = c->world[d]; S.world_top[d] = c->world[3 + d]; }
-	S.world_cells_pow2 = c->world_cells_pow2;
-
-	const bool variable = !c->radius_set;
-	const float r_max = variable ? b8[7] : c->radius;
-	if (n_total > 0 && !(r_max > 0.0f)) TNSX_FAIL(c, TNSX_ERR_CONFIG, "TreeNSearch error: search radius must be > 0");
-
-	// ---- search grid: cell edge h >= r_max with a margin that covers the fp32 rounding of the binning, so that any
-	//      pair the fp32 predicate can accept lies in adjacent cells.  Coarsened until the dense table fits.
 	tnsx::GridParams g{};
 	uint64_t n_cells = 1;
-	if (n_total > 0) {
-		const double ext[3] = { (double)b8[3] - b8[0], (double)b8[4] - b8[1], (double)b8[5] - b8[2] };
-		const double max_ext = std::max(ext[0], std::max(ext[1], ext[2]));
-		const double n0 = std::floor(max_ext / (double)r_max) + 2.0;
-		double h = (double)r_max * (1.0 + 8.0 * 5.9604644775390625e-08 * (n0 + 2.0)) * (1.0 + 1e-6);
-		for (;;) {
-			const double nx = std::floor(ext[0] / h) + 1.0, ny = std::floor(ext[1] / h) + 1.0, nz = std::floor(ext[2] / h) + 1.0;
-			if (nx * ny * nz <= (double)c->opt.max_dense_cells && nx < 2.0e9 && ny < 2.0e9 && nz < 2.0e9) {
-				g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz;
-				break;
+	if (!speculate) {
+		// ---- world box of the reference semantics (kept for zsort + the 2^15 cells/dimension limit)
+		if (n_total > 0) { const tnsx_status r = update_world_box(c, b8); if (r != TNSX_OK) return r; }
+		const float r_max = variable ? b8[7] : c->radius;
+		if (n_total > 0 && !(r_max > 0.0f) ) TNSX_FAIL(c, TNSX_ERR_CONFIG, "TreeNSearch error: search radius must be > 0");
+		if (n_total > 0 && !std::isfinite(r_max)) TNSX_FAIL(c, TNSX_ERR_INVALID, "a search radius is not finite");
+		// ---- the box the grid is laid over: the tight bounds widened by two cell edges on every side, but never beyond the
+		//      world box -- as long as every point stays inside it, the reference would keep its world box too
+		//      (TreeNSearch.cpp:474-482), so a later run may reuse this grid AND the world box without seeing the bounds.
+		// ---- search grid: cell edge h >= r_max with a margin that covers the fp32 rounding of the binning, so that any
+		//      pair the fp32 predicate can accept lies in adjacent cells.  Coarsened until the dense table fits.
+		c->grid_valid = false;
+		if (n_total > 0) {
+			float lo[3], hi[3];
+			for (int d = 0; d < 3; d++) {
+				const float m = 2.0f * r_max;
+				lo[d] = std::max(b8[d] - m, c->world[d]);
+				hi[d] = std::min(b8[3 + d] + m, c->world[3 + d]);
+				if (!(lo[d] <= b8[d])) lo[d] = b8[d];            // (a world box that does not contain the points: a failed update)
+				if (!(hi[d] >= b8[3 + d])) hi[d] = b8[3 + d];
 			}
-			h *= 1.26;
+			const double ext[3] = { (double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2] };
+			const double max_ext = std::max(ext[0], std::max(ext[1], ext[2]));
+			const double n0 = std::floor(max_ext / (double)r_max) + 2.0;
+			double h = (double)r_max * (1.0 + 8.0 * 5.9604644775390625e-08 * (n0 + 2.0)) * (1.0 + 1e-6);
+			// the dense table costs 8 bytes per cell and set: bounded by the number of points (a sparse scene coarsens its cells
+			// instead of allocating gigabytes), and by the option
+			const uint64_t cell_cap = c->auto_dense_cells ? std::min<uint64_t>(c->opt.max_dense_cells, std::max<uint64_t>((uint64_t)1 << 22, 64ull * (uint64_t)n_total))
+			                                              : c->opt.max_dense_cells;
+			bool fits = false;
+			for (int it = 0; it < 400 && !fits; it++) {
+				const double nx = std::floor(ext[0] / h) + 1.0, ny = std::floor(ext[1] / h) + 1.0, nz = std::floor(ext[2] / h) + 1.0;
+				if (nx * ny * nz <= (double)cell_cap && nx < 2.0e9 && ny < 2.0e9 && nz < 2.0e9) {
+					g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz;
+					fits = true;
+				}
+				else h *= 1.26;
+			}
+			if (!fits) TNSX_FAIL(c, TNSX_ERR_INVALID, "no search grid fits the extent of the points");
+			g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2];
+			float hf = (float)h;
+			if ((double)hf < h) hf = std::nextafter(hf, FLT_MAX);
+			g.inv_h = 1.0f / hf;
+			if ((double)g.inv_h * (double)hf > 1.0) g.inv_h = std::nextafter(g.inv_h, 0.0f);   // never overestimate 1/h
+			c->grid = g;
+			c->grid_h = hf;
+			for (int d = 0; d < 3; d++) { c->grid_lo[d] = lo[d]; c->grid_hi[d] = hi[d]; }
+			c->grid_r_max = r_max;
+			c->grid_variable = variable;
+			c->grid_valid = true;
+			c->grid_gen++;
 		}
-		g.ox = b8[0]; g.oy = b8[1]; g.oz = b8[2];
-		float hf = (float)h;
-		if ((double)hf < h) hf = std::nextafter(hf, FLT_MAX);
-		g.inv_h = 1.0f / hf;
-		if ((double)g.inv_h * (double)hf > 1.0) g.inv_h = std::nextafter(g.inv_h, 0.0f);   // never overestimate 1/h
-		n_cells = (uint64_t)g.nx * g.ny * g.nz;
-		S.grid_cell_size = hf;
+		else { g.nx = g.ny = g.nz = 1; g.inv_h = 1.0f; c->grid = g; c->grid_h = 0.0f; }
 	}
-	else { g.nx = g.ny = g.nz = 1; g.inv_h = 1.0f; }
+	g = c->grid;
+	n_cells = (uint64_t)g.nx * g.ny * g.nz;
+	S.grid_cell_size = c->grid_h;
+	for (int d = 0; d < 3; d++) { S.world_bottom[d] = c->world[d]; S.world_top[d] = c->world[3 + d]; }
+	S.world_cells_pow2 = c->world_cells_pow2;
 	S.grid_dims[0] = g.nx; S.grid_dims[1] = g.ny; S.grid_dims[2] = g.nz;
+	S.grid_origin[0] = g.ox; S.grid_origin[1] = g.oy; S.grid_origin[2] = g.oz;
 	S.n_grid_cells = n_cells;
 	const int key_bits = std::max(1, ceil_log2_u64(n_cells + 1));   // + 1: the key behind the last cell, where NaN points ("no point") go
 	S.key_bits = key_bits;
 	S.radix_passes = tnsx::cell_sort_plan(key_bits).passes;
+	S.speculated = speculate ? 1 : 0;
 
-	// ---- per set: keys -> sort -> gather -> cell table
-	HIPCHK(c, c->n_occ.reserve(sizeof(uint32_t) * (size_t)std::max(n_sets, 1)));
-	HIPCHK(c, hipMemsetAsync(c->n_occ.p, 0, sizeof(uint32_t) * (size_t)std::max(n_sets, 1), st));
+	// ---- device words of this attempt: [0] guard flag, [1 + si] checksum of set si (64-bit each)
+	HIPCHK(c, c->run_words.reserve(sizeof(uint64_t) * (size_t)(n_sets + 1)));
+	HIPCHK(c, hipMemsetAsync(c->run_words.p, 0, sizeof(uint64_t) * (size_t)(n_sets + 1), st));
+	unsigned long long* const d_words = c->run_words.as<unsigned long long>();
+
+	// ---- per set: cell sort -> cell table (or nothing: a set that did not change keeps what it has)
+	{
+		const void* old = c->n_occ.p;
+		HIPCHK(c, c->n_occ.reserve(sizeof(uint32_t) * (size_t)std::max(n_sets, 1)));
+		if (c->n_occ.p != old) for (PointSet& s : c->sets) s.built_gen = 0;   // the occupied-cell counts of cached sets lived in the old buffer
+	}
+	std::vector<char> skipped((size_t)n_sets, 0);
 	for (int si = 0; si < n_sets; si++) {
 		PointSet& s = c->sets[si];
+		const bool same_input = s.chk_valid && s.chk_xyz == s.user_xyz && s.chk_radii == s.user_radii && s.chk_n == s.n && s.chk_double == s.is_double;
+		const bool cacheable = !s.user_ids && s.n > 0;
+		if (speculate && cacheable && s.predicted_static && same_input && s.built_gen == c->grid_gen && s.table_state == 1) {
+			// taken to be unchanged: only its checksum is computed (and compared after the run)
+			tnsx::launch_set_checksum(s.d_xyz, variable ? s.d_radii : nullptr, s.n, d_words + 1 + si, st);
+			skipped[(size_t)si] = 1;
+			S.n_cached_sets++;
+			continue;
+		}
 		// the table is needed even for empty sets (they can be searched into)
 		const int t0 = tm.mark();
+		HIPCHK(c, hipMemsetAsync(c->n_occ.as<uint32_t>() + si, 0, sizeof(uint32_t), st));
 		{
 			const void* old_table = s.table.p;
 			HIPCHK(c, s.table.reserve(n_cells * sizeof(uint2)));
@@ -594,6 +669,7 @@ tnsx_status tnsx_run(tnsx_context* c)
 			s.table_state = 0; s.table_dirty = 0;
 		}
 		HIPCHK(c, s.occ.reserve((size_t)std::max(s.n, 1) * sizeof(uint2)));   // (after the clear: it reads the previous list)
+		s.built_gen = 0;
 		if (s.n == 0) continue;
 		s.table_state = 2;   // until this run's occupied-cell count has reached the host
 		for (int k = 0; k < 2; k++) {
@@ -603,10 +679,17 @@ tnsx_status tnsx_run(tnsx_context* c)
 		HIPCHK(c, c->sort_temp.reserve(tnsx::cell_sort_temp_bytes(s.n)));
 		tnsx::CellSortBuffers cb;
 		for (int k = 0; k < 2; k++) { cb.xyzi[k] = s.xyzi[k].as<float4>(); cb.r2[k] = s.r2[k].as<float>(); }
+		tnsx::BuildGuard gd;
+		if (speculate) {
+			for (int d = 0; d < 3; d++) { gd.lo[d] = c->grid_lo[d]; gd.hi[d] = c->grid_hi[d]; }
+			gd.r_max = c->grid_r_max;
+			gd.flag = reinterpret_cast<uint32_t*>(d_words);
+		}
+		if (cacheable) gd.checksum = d_words + 1 + si;
 		const int t1 = tm.mark();
 		if (s.user_ids) HIPCHK(c, s.orig_sorted.reserve((size_t)s.n * sizeof(uint32_t)));
 		s.sorted_buf = tnsx::launch_cell_sort(s.d_xyz, variable ? s.d_radii : nullptr, s.n, g, key_bits, cb, c->sort_temp.p, s.user_ids,
-		                                      s.user_ids ? s.orig_sorted.as<uint32_t>() : nullptr, st);
+		                                      s.user_ids ? s.orig_sorted.as<uint32_t>() : nullptr, gd, st);
 		const int t2 = tm.mark();
 		tnsx::launch_cell_table(cb.xyzi[s.sorted_buf], s.n, g, s.table.as<uint2>(), s.occ.as<uint2>(), c->n_occ.as<uint32_t>() + si, st);
 		const int t3 = tm.mark();
@@ -619,9 +702,10 @@ tnsx_status tnsx_run(tnsx_context* c)
 	struct Job { int i, j; bool pool; };
 	std::vector<Job> jobs;
 	for (int i = 0; i < n_sets; i++) for (int j = 0; j < n_sets; j++) if (c->active[i][j]) jobs.push_back({ i, j, false });
-	HIPCHK(c, c->h_small.reserve(sizeof(uint64_t) * (2 * jobs.size() + 2) + sizeof(uint32_t) * (size_t)(n_sets + 1) + 64));
+	HIPCHK(c, c->h_small.reserve(sizeof(uint64_t) * (2 * jobs.size() + 2 + (size_t)n_sets + 1) + sizeof(uint32_t) * (size_t)(n_sets + 1) + 64));
 	uint64_t* h_ctrl = c->h_small.as<uint64_t>();                       // per job: {cursor | total, hit_total}
-	uint32_t* h_nocc = reinterpret_cast<uint32_t*>(h_ctrl + 2 * jobs.size() + 2);
+	uint64_t* h_words = h_ctrl + 2 * jobs.size() + 2;                   // guard flag, checksums
+	uint32_t* h_nocc = reinterpret_cast<uint32_t*>(h_words + n_sets + 1);
 	HIPCHK(c, c->pool_ctrl.reserve(tnsx::CTRL_BYTES * (jobs.size() + 1)));   // per job: cursor, hit_total, 2 x (8 tickets, n_heavy), spread out
 	auto ctrl_slot = [&](size_t k, int slot) { return c->pool_ctrl.as<uint32_t>() + (k * tnsx::CTRL_SLOTS + (size_t)slot) * tnsx::CTRL_STRIDE_U32; };
 	const int query_waves = c->n_cus * 8 * 4;
@@ -722,7 +806,29 @@ tnsx_status tnsx_run(tnsx_context* c)
 		}
 	}
 	HIPCHK(c, hipMemcpyAsync(h_nocc, c->n_occ.p, sizeof(uint32_t) * (size_t)std::max(n_sets, 1), hipMemcpyDeviceToHost, st));
-	HIPCHK(c, hipStreamSynchronize(st));   // record totals / pool cursors are needed on the host
+	HIPCHK(c, hipMemcpyAsync(h_words, c->run_words.p, sizeof(uint64_t) * (size_t)(n_sets + 1), hipMemcpyDeviceToHost, st));
+	HIPCHK(c, hipStreamSynchronize(st));   // record totals / pool cursors / what was speculated on are needed on the host
+
+	// ---- were the assumptions of this attempt right?
+	for (int si = 0; si < n_sets; si++) {
+		PointSet& s = c->sets[si];
+		if (s.n > 0) { s.table_state = 1; if (!skipped[(size_t)si]) s.table_dirty = h_nocc[si]; }
+	}
+	bool wrong = speculate && (h_words[0] & 0xffffffffull) != 0;   // a point left the box of the grid / a radius outgrew its cell edge
+	if (wrong) c->grid_valid = false;
+	for (int si = 0; si < n_sets; si++) {
+		PointSet& s = c->sets[si];
+		const bool cacheable = !s.user_ids && s.n > 0;
+		const bool same_input = s.chk_valid && s.chk_xyz == s.user_xyz && s.chk_radii == s.user_radii && s.chk_n == s.n && s.chk_double == s.is_double;
+		const bool unchanged = cacheable && same_input && s.chk_value == h_words[1 + si];
+		if (skipped[(size_t)si] && !unchanged) { wrong = true; s.predicted_static = false; s.chk_valid = false; continue; }
+		if (wrong) continue;                      // (an attempt that is thrown away teaches nothing)
+		s.predicted_static = unchanged;           // two equal checksums in a row: the next run keeps the structures
+		s.chk_valid = cacheable; s.chk_value = h_words[1 + si];
+		s.chk_xyz = s.user_xyz; s.chk_radii = s.user_radii; s.chk_n = s.n; s.chk_double = s.is_double;
+		if (!skipped[(size_t)si] && s.n > 0) s.built_gen = c->grid_gen;
+	}
+	if (wrong) { *redo = true; S.speculation_redos++; return TNSX_OK; }
 
 	for (size_t k = 0; k < jobs.size(); k++) {
 		const Job& jb = jobs[k];
@@ -735,6 +841,7 @@ tnsx_status tnsx_run(tnsx_context* c)
 				if (pr.dry) {
 					// the dry pass counted every neighbour: size the real pass exactly
 					pr.dry = false;
+					S.cold_passes++;
 					const tnsx_status r = size_pool(pr, h_ctrl[2 * k + 1] + (uint64_t)pr.n_query);
 					if (r != TNSX_OK) return r;
 				}
@@ -770,10 +877,7 @@ tnsx_status tnsx_run(tnsx_context* c)
 		S.n_neighbors += n_neighbors;
 		if (jb.pool) S.n_pool_pairs++;
 	}
-	for (int si = 0; si < n_sets; si++) {
-		S.n_occupied_cells += h_nocc[si];
-		if (c->sets[si].n > 0) { c->sets[si].table_state = 1; c->sets[si].table_dirty = h_nocc[si]; }
-	}
+	for (int si = 0; si < n_sets; si++) S.n_occupied_cells += h_nocc[si];
 
 	// ---- optional pinned host mirror (what get_neighborlist needs on the CPU side)
 	const int e_m0 = tm.mark();
@@ -804,13 +908,34 @@ tnsx_status tnsx_run(tnsx_context* c)
 	if (c->opt.collect_stage_times) {
 		float acc[ST_N] = { 0 };
 		for (const Span& sp : spans) acc[sp.stage] += tm.ms(sp.a, sp.b);
-		S.ms_upload = acc[ST_UPLOAD]; S.ms_bounds = acc[ST_BOUNDS]; S.ms_keys = acc[ST_KEYS]; S.ms_sort = acc[ST_SORT];
-		S.ms_gather = acc[ST_GATHER]; S.ms_cells = acc[ST_CELLS]; S.ms_count = acc[ST_COUNT]; S.ms_scan = acc[ST_SCAN];
+		S.ms_upload = acc[ST_UPLOAD]; S.ms_bounds = acc[ST_BOUNDS]; S.ms_table_clear = acc[ST_KEYS]; S.ms_sort = acc[ST_SORT];
+		S.ms_cells = acc[ST_CELLS]; S.ms_count = acc[ST_COUNT]; S.ms_scan = acc[ST_SCAN];
 		S.ms_fill = acc[ST_FILL]; S.ms_mirror = acc[ST_MIRROR];
 		S.ms_total = tm.ms(e_begin, e_end);
 	}
 	c->ran = true;
 	return TNSX_OK;
+}
+
+tnsx_status tnsx_run(tnsx_context* c)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
+	c->stats.speculation_redos = 0;
+	// the previous run's grid can be laid over this run's points unseen if nothing it was derived from has changed on the host side
+	bool speculate = c->opt.temporal_reuse != 0 && c->grid_valid && c->cell_size > 0.0f && c->grid_variable == !c->radius_set &&
+	                 (c->radius_set ? c->grid_r_max == c->radius : true);
+	int64_t n_total = 0;
+	for (const PointSet& s : c->sets) n_total += s.n;
+	if (n_total == 0) speculate = false;
+	for (int attempt = 0; attempt < 3; attempt++) {
+		bool redo = false;
+		const tnsx_status r = run_once(c, speculate, &redo);
+		if (r != TNSX_OK) { c->grid_valid = false; return r; }
+		if (!redo) return TNSX_OK;
+		speculate = false;
+	}
+	TNSX_FAIL(c, TNSX_ERR_STATE, "run(): the speculative build kept failing its validation");
 }
 
 // ------------------------------------------------------------------------------------------------ results
@@ -917,6 +1042,7 @@ tnsx_status tnsx_prepare_zsort(tnsx_context* c)
 	mg.nx = mg.ny = mg.nz = n_pow2;
 	for (PointSet& s : c->sets) {
 		s.zsort_n = s.n;
+		s.built_gen = 0;               // (the ping-pong arrays of the search structure are the scratch of this sort)
 		s.zsort_host.clear();          // fetched from the device when somebody asks for it (get_zsort_order, host-side apply_zsort)
 		s.zsort_ready = true;
 		if (s.n == 0) continue;

@@ -36,10 +36,21 @@ struct CellSortPlan { int passes; int bits[8]; };
 CellSortPlan cell_sort_plan(int key_bits);
 struct CellSortBuffers { float4* xyzi[2]; float* r2[2]; };
 size_t cell_sort_temp_bytes(int n);
+// What a run of the engine speculates on, validated by the first pass of the sort (see tnsx_build.hip): flag (or nullptr) is
+// raised when a point lies outside [lo, hi] or a radius exceeds r_max; checksum (or nullptr, must be zeroed) receives the
+// order-sensitive 64-bit checksum of the set's points (+ radii).
+struct BuildGuard {
+	float lo[3] = { 0.f, 0.f, 0.f }, hi[3] = { 0.f, 0.f, 0.f };
+	float r_max = 3.402823466e+38f;
+	uint32_t* flag = nullptr;
+	unsigned long long* checksum = nullptr;
+};
 // ids != nullptr (tnsx_set_point_ids): the sorted points carry ids[original index] instead of the original index (that is what
 // the query emits), and orig_sorted[sorted position] receives the original index.
 int launch_cell_sort(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, const int* ids,
-                     uint32_t* orig_sorted, hipStream_t s);
+                     uint32_t* orig_sorted, const BuildGuard& gd, hipStream_t s);
+// the same checksum on its own (sets whose build is skipped)
+void launch_set_checksum(const float* xyz, const float* radii, int n, unsigned long long* out, hipStream_t s);
 // The same sort on the Morton code of the point's cell on the REFERENCE grid (TreeNSearch.cpp:713-715 quantisation, libmorton bit
 // order; prepare_zsort): g.ox/oy/oz = world bottom, g.inv_h = 1 / cell size, g.nx = cells per axis (a power of two), 3 * log2(nx)
 // key bits.  order_out[p] = original index of the p-th point in z-order.

@@ -95,26 +95,36 @@ class SlabDecomposition:
                     hist += torch.bincount(b, minlength=n_planes)
         return self._all_reduce(hist, dist.ReduceOp.SUM)
 
-    def balanced_cuts(self, point_sets: Sequence[torch.Tensor], plane_width: float, bounds=None) -> np.ndarray:
+    def balanced_cuts(self, point_sets: Sequence[torch.Tensor], plane_width: float, bounds=None, n_slabs: Optional[int] = None) -> np.ndarray:
+        """n_slabs: number of slabs to cut into (default: one per rank)"""
         lo, hi = bounds if bounds is not None else self.global_bounds(point_sets)
+        return self._cuts(point_sets, plane_width, lo, hi, self.world if n_slabs is None else int(n_slabs))
+
+    def _cuts(self, point_sets, plane_width, lo, hi, world):
         x0, x1 = float(lo[0]), float(hi[0])
         if not (math.isfinite(x0) and math.isfinite(x1)):      # no points anywhere
             x0, x1 = 0.0, 0.0
         n_planes = int((x1 - x0) / float(plane_width)) + 1
         if n_planes > self.MAX_PLANES:
             raise ValueError(f"{n_planes} x planes of width {plane_width}: more than {self.MAX_PLANES}")
-        if n_planes < self.world:
-            raise ValueError(f"the cloud spans {n_planes} cell planes along x, fewer than the {self.world} slabs asked for")
+        if n_planes < world:
+            raise ValueError(f"the cloud spans {n_planes} cell planes along x, fewer than the {world} slabs asked for")
         hist = self.x_histogram(point_sets, x0, plane_width, n_planes).cpu().numpy()
         cum = np.cumsum(hist)
         total = int(cum[-1]) if len(cum) else 0
-        cuts = np.empty(self.world + 1, np.float32)
+        cuts = np.empty(world + 1, np.float32)
         cuts[0], cuts[-1] = -np.inf, np.inf
         prev = 0
-        for k in range(1, self.world):
-            # first plane boundary with at least k/world of the points to its left; at least one plane per slab on either side
-            b = int(np.searchsorted(cum, (total * k + self.world - 1) // self.world, side="left")) + 1 if total else k
-            b = min(max(b, prev + 1), n_planes - (self.world - k))
+        for k in range(1, world):
+            # the plane boundary whose count of points to its left is closest to k/world of all; at least one plane per slab
+            if total:
+                target = total * k / world
+                b = int(np.searchsorted(cum, target, side="left")) + 1             # boundary b has cum[b - 1] points to its left
+                if b >= 2 and abs(cum[b - 2] - target) <= abs(cum[min(b, n_planes) - 1] - target):
+                    b -= 1
+            else:
+                b = k
+            b = min(max(b, prev + 1), n_planes - (world - k))
             cuts[k] = np.float32(np.float32(x0) + np.float32(b) * np.float32(plane_width))
             prev = b
         return cuts
@@ -123,7 +133,7 @@ class SlabDecomposition:
     def owner_of(x: torch.Tensor, cuts: np.ndarray) -> torch.Tensor:
         """slab index of every x (cuts[k] <= x < cuts[k+1])"""
         inner = torch.as_tensor(np.asarray(cuts[1:-1], np.float32), device=x.device)
-        return torch.bucketize(x, inner, right=True)
+        return torch.bucketize(x.contiguous(), inner, right=True)
 
     def redistribute(self, pts: torch.Tensor, gids: torch.Tensor, radii: Optional[torch.Tensor], cuts: np.ndarray):
         """Moves every point to the rank that owns its slab (one all-to-all of counts, one of rows).  -> (pts, gids, radii)"""
@@ -167,8 +177,14 @@ class SlabExchange:
                         (the engine ignores points whose x is NaN) and `validate()` -- called after the search, which has
                         synchronised anyway -- tells whether a capacity was exceeded; the step is then repeated in exact mode."""
 
-    def __init__(self, slab_lo: float, slab_hi: float, halo: float, group=None, packer=None):
+    def __init__(self, slab_lo: float, slab_hi: float, halo: float, group=None, packer=None, transport=None, rank=None, world=None):
+        """transport: an object with round_trip(rank, peers, out_msgs, in_msgs) that moves the messages instead of
+        torch.distributed (tests/test_gpu_slabs.py runs all slabs of a decomposition inside one process on one GPU); rank and
+        world then say which slab this is."""
         self.rank, self.world = _world(group)
+        if rank is not None:
+            self.rank, self.world = int(rank), int(world)
+        self.transport = transport
         self.group = group
         self.lo, self.hi, self.halo = float(slab_lo), float(slab_hi), float(halo)
         self.bytes_sent = 0
@@ -232,6 +248,10 @@ class SlabExchange:
         return out
 
     def _round_trip(self, peers, out_msgs, in_msgs):
+        if self.transport is not None:
+            self.bytes_sent += sum(m.numel() * 4 for m in out_msgs.values())
+            self.transport.round_trip(self.rank, peers, out_msgs, in_msgs)
+            return
         ops = []
         for p in peers:
             if p in out_msgs:
@@ -408,8 +428,10 @@ class SlabSearch:
     rank (it sizes the halo; checked on the owned radii every step)."""
 
     def __init__(self, slab_lo: float, slab_hi: float, radius: Optional[float], engine_factory: Callable[[], object],
-                 halo_margin: float = 1.0e-3, group=None, max_radius: Optional[float] = None, speculative: bool = True):
+                 halo_margin: float = 1.0e-3, group=None, max_radius: Optional[float] = None, speculative: bool = True,
+                 transport=None, rank=None, world=None):
         self.group = group
+        self._ex_args = dict(transport=transport, rank=rank, world=world)
         self.lo, self.hi = float(slab_lo), float(slab_hi)
         self.radius = None if radius is None else float(radius)
         self.variable = radius is None
@@ -441,7 +463,7 @@ class SlabSearch:
     def _set(self, k: int) -> _SlabSet:
         while len(self.sets) <= k:
             s = _SlabSet()
-            s.ex = SlabExchange(self.lo, self.hi, self.halo, self.group, packer=self.engine)
+            s.ex = SlabExchange(self.lo, self.hi, self.halo, self.group, packer=self.engine, **self._ex_args)
             self.sets.append(s)
         return self.sets[k]
 
