@@ -26,6 +26,19 @@ namespace tns
 			tnsx_options opt;
 			tnsx_default_options(&opt);
 			opt.mirror_to_host = 1;
+			// TNSX_DEVICES="0,1,2,3": shard every run over these GPUs (multi-device mode of the engine, include/tnsx.h) -- the
+			// knob for callers whose source cannot change; one ordinal (or nothing) = one GPU
+			if (const char* e = std::getenv("TNSX_DEVICES")) {
+				int n = 0;
+				for (const char* q = e; *q && n < 8;) {
+					char* end = nullptr;
+					const long v = std::strtol(q, &end, 10);
+					if (end == q) break;
+					opt.device_ids[n++] = (int)v;
+					q = (*end == ',') ? end + 1 : end;
+				}
+				if (n > 1) opt.n_devices = n; else if (n == 1) opt.device_id = opt.device_ids[0];
+			}
 			if (tnsx_create(&opt, &ctx_) != TNSX_OK) {
 				std::cout << "tns::TreeNSearch error: " << tnsx_last_error(nullptr) << std::endl;
 				exit(-1);
@@ -64,6 +77,14 @@ namespace tns
 
 		NeighborList get_neighborlist(const int set_i, const int set_j, const int point_i) const
 		{
+			// (the reference only asserts here, TreeNSearch.cpp:243-246, and dereferences a null pointer in release builds when the
+			//  pair was not active at the last run; this shim says so and exits like every other misuse does)
+			if (set_i < 0 || set_j < 0 || set_i >= n_sets_at_run_ || set_j >= n_sets_at_run_ ||
+			    views_[(size_t)set_i * (size_t)n_sets_at_run_ + (size_t)set_j].records == nullptr) {
+				std::cout << "tns::TreeNSearch::get_neighborlist error: no neighbour lists for (" << set_i << " -> " << set_j
+				          << "): the search was not active at the last run()." << std::endl;
+				exit(-1);
+			}
 			const View& v = views_[(size_t)set_i * (size_t)n_sets_at_run_ + (size_t)set_j];
 			return NeighborList(v.records + v.offsets[point_i]);
 		}
@@ -78,13 +99,9 @@ namespace tns
 		void prepare_zsort()
 		{
 			ok_(tnsx_prepare_zsort(ctx_));
-			const int n_sets = tnsx_get_n_sets(ctx_);
-			zsort_.resize((size_t)n_sets);
-			for (int s = 0; s < n_sets; s++) {
-				const int* host = nullptr; int n = 0;
-				ok_(tnsx_get_zsort_order(ctx_, s, &host, nullptr, &n));
-				zsort_[(size_t)s].assign(host, host + n);
-			}
+			// the orders stay in HBM; a set's order is copied to the host when somebody asks for it (order_of_)
+			zsort_.assign((size_t)tnsx_get_n_sets(ctx_), std::vector<int>());
+			zsort_fetched_.assign(zsort_.size(), 0);
 		}
 		template<typename T>
 		void apply_zsort(const int set_i, T* data_ptr, const int stride = 1) const
@@ -97,8 +114,8 @@ namespace tns
 				std::cout << "tns::TreeNSearch::apply_zsort error: no zsort order ready for set_i (" << set_i << ")." << std::endl;
 				exit(-1);
 			}
-			const std::vector<int>& map = zsort_[(size_t)set_i];
-			const size_t n = (size_t)this->get_n_points_in_set(set_i);
+			const std::vector<int>& map = order_of_(set_i);
+			const size_t n = map.size();
 			const size_t st = (size_t)stride;
 			std::vector<T> old(data_ptr, data_ptr + n * st);
 			#pragma omp parallel for schedule(static)
@@ -135,7 +152,7 @@ namespace tns
 		int get_total_n_points() const { return (int)tnsx_get_total_n_points(ctx_); }
 		bool is_search_active(const int set_i, const int set_j) const { return tnsx_is_search_active(ctx_, set_i, set_j) != 0; }
 		bool does_set_exist(const int set_i) const { return tnsx_does_set_exist(ctx_, set_i) != 0; }
-		const std::vector<int>& get_zsort_order(const int set_i) const { return zsort_[(size_t)set_i]; }
+		const std::vector<int>& get_zsort_order(const int set_i) const { return order_of_(set_i); }
 
 		/** Extension: the underlying engine handle (device-side CSR views, stats, arithmetic mode). */
 		tnsx_context* engine() const { return ctx_; }
@@ -155,6 +172,20 @@ namespace tns
 			if (id_or_neg_status < 0) ok_((tnsx_status)(-id_or_neg_status));
 			return id_or_neg_status;
 		}
+		// host copy of one set's z-order, fetched from the engine on first use (the engine itself keeps it on the device)
+		const std::vector<int>& order_of_(const int set_i) const
+		{
+			if (!zsort_fetched_[(size_t)set_i]) {
+				#pragma omp critical(tnsx_zsort_fetch)
+				if (!zsort_fetched_[(size_t)set_i]) {
+					const int* host = nullptr; int n = 0;
+					ok_(tnsx_get_zsort_order(ctx_, set_i, &host, nullptr, &n));
+					zsort_[(size_t)set_i].assign(host, host + n);
+					zsort_fetched_[(size_t)set_i] = 1;
+				}
+			}
+			return zsort_[(size_t)set_i];
+		}
 		void refresh_views_()
 		{
 			n_sets_at_run_ = tnsx_get_n_sets(ctx_);
@@ -173,7 +204,8 @@ namespace tns
 		tnsx_context* ctx_ = nullptr;
 		std::vector<View> views_;
 		int n_sets_at_run_ = 0;
-		std::vector<std::vector<int>> zsort_;
+		mutable std::vector<std::vector<int>> zsort_;
+		mutable std::vector<char> zsort_fetched_;
 		int n_threads_ = -1;
 	};
 }

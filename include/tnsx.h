@@ -80,7 +80,16 @@ typedef struct tnsx_options {
 	                             first, and point sets whose input did not change keep their sorted arrays and cell table; both are
 	                             verified on the device during the run and the run is repeated when an assumption was wrong (the
 	                             reference's own reuse, TreeNSearch.cpp:474-482 and :77-79).  0: bounds and full build every run */
-	int reserved[6];
+	int sorted_lists;         /* 1: every neighbour list is put into ascending index order after the query (one wave per record, bitonic
+	                             network), as the reference's lists are by construction (TreeNSearch.cpp:2474-2500) -- sums over
+	                             neighbours are then evaluated in the same order as on the CPU.  0 (default): order unspecified */
+	int n_devices;            /* > 1: multi-device mode for HOST-resident inputs (the C++ drop-in): every run is cut into that many slabs
+	                             along x (balanced cuts from an x histogram, one-halo ghosts added to each slab's upload), one engine per
+	                             device, lists gathered into one pinned host buffer -- N PCIe links instead of one for the copy that
+	                             bounds drop-in mode.  Device pointers, device views and the tnsx_halo_pack family are not available on
+	                             such a context.  0 / 1: single device (device_id) */
+	int device_ids[8];        /* HIP device ordinals of the n_devices engines (an ordinal may repeat: several engines on one GPU) */
+	int reserved[4];
 } tnsx_options;
 
 /* Neighbour lists of one active (set_i -> set_j) pair.  Record layout == the reference's chunk storage
@@ -114,12 +123,14 @@ typedef struct tnsx_stats {
 	 * (0 when the grid was reused); clearing the previous run's cell-table entries; cell sort; cell table; count / scan passes
 	 * (exact_layout only); the query pass(es) that write the lists; pinned host mirror */
 	float ms_total, ms_upload, ms_bounds, ms_table_clear, ms_sort, ms_cells, ms_count, ms_scan, ms_fill, ms_mirror;
+	float ms_sort_lists;          /* sorted_lists: the pass that orders every record */
 	int n_pool_pairs;             /* pairs built in single-pass pool mode in the last run */
 	int pool_retries;             /* pool passes repeated because the pool was too small */
 	int cold_passes;              /* dry (count-only) passes of pairs that ran for the first time */
 	int speculated;               /* 1: the last run reused the previous run's grid (no bounds pass, no host round trip before the build) */
 	int speculation_redos;        /* attempts of the last run that were thrown away because an assumption was wrong (0 or 1) */
 	int n_cached_sets;            /* point sets whose build was skipped in the last run (input unchanged) */
+	int n_devices_used;           /* multi-device mode: slabs the last run was cut into (0 on a single-device context) */
 	/* world box of the reference semantics (TreeNSearch.cpp:415-522) */
 	float world_bottom[3], world_top[3];
 	int world_cells_pow2;

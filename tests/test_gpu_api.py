@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import cases as CS
+from conftest import load_golden
 import parity as P
 
 pytestmark = pytest.mark.gpu
@@ -301,3 +302,107 @@ def test_grid_and_world_box_follow_the_tight_bounds(n, on_device, oracle):
     assert np.array_equal(np.array(st["grid_origin"], np.float32), lo)
     expect = [int(np.floor((float(hi[d]) - float(lo[d])) / h)) + 1 for d in range(3)]
     assert list(st["grid_dims"]) == expect
+
+
+@pytest.mark.parametrize("name", ["uniform_fixed_100000", "random_var_asym_12000_6000_ratio10", "dense_blob"])
+def test_sorted_lists_equal_the_reference_without_sorting(name, oracle):
+    """tnsx_options.sorted_lists: the records are ascending as they come out of the engine -- compared with the
+    reference-checked lists element by element with NO sort on either side (what BruteforceNSearch.cpp:129-137 needs a sort for).
+    Covers all three tiers of the record sort: <= 64 entries (lanes), <= 2048 (LDS), longer (in place in global memory)."""
+    import treensearch_amd as T
+    if name == "dense_blob":
+        from treensearch_amd import datagen as D
+        blob = D.uniform_cloud(2600, 4) * np.float32(0.004) + np.float32(0.5)          # 2600 points inside one search sphere
+        rest = D.uniform_cloud(20000, 5)
+        case = CS.Case("dense_blob", [np.ascontiguousarray(np.concatenate([rest[:10000], blob, rest[10000:]]))], None, np.float32(0.02), [(0, 0)])
+    else:
+        case = CS.by_name(name)
+    ref = P.run_oracle_case(case, 0, oracle)
+    ns = P.make_engine(case, 0, device_inputs=True, sorted_lists=True, collect_stage_times=True)
+    for _ in range(2):
+        ns.run()
+    assert ns.get_stats()["ms_sort_lists"] > 0.0
+    longest = 0
+    for pr in case.active:
+        offs, idx = ns.neighbor_csr(*pr, sort_each=False)
+        assert np.array_equal(offs, ref[pr][0]) and np.array_equal(idx, ref[pr][1]), f"{name} pair {pr}: records are not the ascending lists"
+        longest = max(longest, int(np.diff(offs).max()) if len(offs) > 1 else 0)
+    assert longest > {"uniform_fixed_100000": 64, "random_var_asym_12000_6000_ratio10": 200, "dense_blob": 2048}[name], longest
+    # and the default leaves the order alone (same sets)
+    plain = P.make_engine(case, 0, device_inputs=True)
+    plain.run()
+    for pr in case.active:
+        P.assert_same_csr(plain.neighbor_csr(*pr), ref[pr], f"{name} {pr} unsorted engine, sorted for the comparison")
+
+
+def test_cpp_shim_inactive_pair_is_an_error_message(built_library, tmp_path):
+    """get_neighborlist for a pair that was not active at the last run(): message on stdout + exit(-1), as INTEGRATION.md says
+    (the reference asserts in debug builds and reads through a null pointer otherwise, TreeNSearch.cpp:243-246)"""
+    src = tmp_path / "inactive.cpp"
+    src.write_text("""
+#include <TreeNSearch>
+#include <cstdio>
+#include <vector>
+int main() {
+    std::vector<float> a = {0.f, 0.f, 0.f, 0.1f, 0.f, 0.f}, b = {0.05f, 0.f, 0.f};
+    tns::TreeNSearch ns;
+    ns.set_search_radius(0.2f);
+    ns.add_point_set(a.data(), 2);
+    ns.add_point_set(b.data(), 1);
+    ns.set_active_search(0, 1, true);
+    ns.run();
+    std::printf("active %d\\n", ns.get_neighborlist(0, 1, 0).size());
+    std::fflush(stdout);
+    return ns.get_neighborlist(1, 0, 0).size();      // never activated
+}
+""")
+    exe = tmp_path / "inactive"
+    lib_dir = os.path.dirname(built_library)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fopenmp", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L" + lib_dir, "-ltnsx", "-Wl,-rpath," + lib_dir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert "active 1" in out.stdout
+    assert out.returncode == 255 and "not active at the last run" in out.stdout, (out.returncode, out.stdout, out.stderr)
+
+
+@pytest.mark.parametrize("name", ["uniform_fixed_100000", "two_set_asym_80000_20000", "dam_break_sym_100000", "lattice_mixed_double_10000",
+                                  "edge_empty_and_tiny"])
+def test_multi_device_context_matches_golden(name, oracle):
+    """tnsx_options.n_devices: ONE context that cuts every run into slabs, runs one engine per device and gathers the lists into one
+    host view (the mode the C++ drop-in uses for more than one GPU).  Here three engines share GPU 0: the whole path -- balanced
+    cuts, ghosts in the upload, candidates-only ghosts, global ids, gathered offsets -- against the reference-generated fixtures."""
+    import treensearch_amd as T
+    case = CS.by_name(name)
+    ns = T.TreeNSearch(devices=[0, 0, 0])
+    variable = case.radii is not None
+    if not variable:
+        ns.set_search_radius(case.radius)
+    for s, p in enumerate(case.points):
+        ns.add_point_set(p, case.radii[s] if variable else None)
+    for (i, j) in case.active:
+        ns.set_active_search(i, j, True)
+    ns.set_symmetric_search(case.symmetric)
+    for step in range(2):
+        ns.run()
+        res = {pr: ns.neighbor_csr(*pr) for pr in case.active}
+        P.assert_matches_golden(res, load_golden(case.name), 0, oracle, f"{name} on three engines (run {step})")
+    st = ns.get_stats()
+    assert st["n_devices_used"] == (3 if case.n_total() > 1000 else st["n_devices_used"]) and st["n_neighbors"] == sum(int(res[pr][0][-1]) for pr in case.active)
+    # z-sort through the same context: a permutation that is Morton-sorted on the reported world box
+    ns.prepare_zsort()
+    for s, p in enumerate(case.points):
+        order = ns.get_zsort_order(s)
+        assert np.array_equal(np.sort(order), np.arange(len(p)))
+
+
+def test_cpp_dropin_scenarios_on_two_engines(built_library, tmp_path):
+    """the reference's test scenarios through the C++ shim with TNSX_DEVICES=0,0 (multi-device mode, two engines on GPU 0)"""
+    exe = tmp_path / "shim_scenarios"
+    lib_dir = os.path.dirname(built_library)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fopenmp", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "shim_scenarios.cpp"), "-o", str(exe),
+                           "-L" + lib_dir, "-ltnsx", "-Wl,-rpath," + lib_dir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, env=dict(os.environ, TNSX_DEVICES="0,0"))
+    print(out.stdout[-3000:])
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "FAILED" not in out.stdout and "ALL PASSED" in out.stdout

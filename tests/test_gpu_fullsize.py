@@ -1,0 +1,169 @@
+"""BASELINE.json configs[2] and configs[3] at FULL size (8 M + 2 M; 20 M dam break) through size-independent properties that hold
+for any correct neighbour search, evaluated on the device (the lists never leave HBM): symmetry of the pair set (moments with
+random 64-bit weights, wrapping arithmetic), self exclusion, distinct entries, index range, idempotence, invariance under the
+z-sort; plus the configs[3] step -- perturb, prepare_zsort, apply_zsort(xyz), apply_zsort(radii), run -- against the oracle at a
+size the oracle finishes in seconds."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import parity as P   # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_csr(ns, i, j):
+    """(counts int64[n], owner int64[E], idx int64[E]) of pair (i, j) on the device; owner / idx are set-local indices"""
+    import ctypes as C
+    import torch
+    v = ns.pair_view(i, j)
+    offs = torch.empty(max(v.n_points, 1), dtype=torch.int64, device="cuda")
+    recs = torch.empty(max(v.n_records, 1), dtype=torch.int32, device="cuda")
+    ns._check(ns._L.tnsx_copy_pair(ns._h, int(i), int(j), C.c_void_p(offs.data_ptr()), C.c_void_p(recs.data_ptr()), 1))
+    offs = offs[:v.n_points]
+    counts = recs[offs].to(torch.int64)
+    total = int(counts.sum().item())
+    assert total == v.n_neighbors
+    start = torch.cumsum(counts, 0) - counts
+    src = torch.repeat_interleave(offs + 1 - start, counts) + torch.arange(total, device="cuda", dtype=torch.int64)
+    idx = recs[src].to(torch.int64)
+    owner = torch.repeat_interleave(torch.arange(v.n_points, device="cuda", dtype=torch.int64), counts)
+    return counts, owner, idx
+
+
+def _weights(n, seed):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.randint(1, 1 << 62, (n,), generator=g, device="cuda", dtype=torch.int64)
+
+
+def _moment(owner, idx, w_owner, w_idx):
+    """sum over directed pairs (i, j) of w_owner[i] * w_idx[j]  (mod 2^64)"""
+    return int((w_owner[owner] * w_idx[idx]).sum().item())
+
+
+def _assert_lists_wellformed(owner, idx, n_j, same_set, what):
+    import torch
+    assert int(idx.min().item()) >= 0 and int(idx.max().item()) < n_j, f"{what}: index out of range"
+    if same_set:
+        assert not bool((idx == owner).any().item()), f"{what}: a point lists itself"
+    key = torch.sort(owner * (1 << 31) + idx).values
+    assert bool((key[1:] > key[:-1]).all().item()), f"{what}: duplicate entries inside a list"
+
+
+def test_c3_full_size_properties():
+    """8 M fluid + 2 M boundary.  0->0 is symmetric; 0->1 is checked against the reverse search 1->0 of a second engine (the roles of
+    query and candidate set swapped); both are idempotent while the fluid stands still and the boundary build is served from the cache."""
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    f, b, r = D.two_set_cloud(8_000_000, 2_000_000)
+    d_f, d_b = torch.from_numpy(f).cuda(), torch.from_numpy(b).cuda()
+    ns = T.TreeNSearch()
+    ns.set_search_radius(r)
+    ns.add_point_set(d_f)
+    ns.add_point_set(d_b)
+    ns.set_active_search(0, 0, True)
+    ns.set_active_search(0, 1, True)
+    ns.run()
+    a0, b0, a1 = _weights(len(f), 1), _weights(len(f), 2), _weights(len(b), 3)
+    c00, own00, idx00 = _device_csr(ns, 0, 0)
+    assert 40 < float(c00.float().mean().item()) < 80
+    _assert_lists_wellformed(own00, idx00, len(f), True, "0->0")
+    m = _moment(own00, idx00, a0, b0)
+    assert m == _moment(own00, idx00, b0, a0), "0->0: the pair set is not symmetric"
+    c01, own01, idx01 = _device_csr(ns, 0, 1)
+    _assert_lists_wellformed(own01, idx01, len(b), False, "0->1")
+    m01 = _moment(own01, idx01, a0, a1)
+    n01 = int(c01.sum().item())
+    del own00, idx00, own01, idx01
+    # the reverse search with another engine instance
+    rev = T.TreeNSearch()
+    rev.set_search_radius(r)
+    rev.add_point_set(d_f)
+    rev.add_point_set(d_b)
+    rev.set_active_search(1, 0, True)
+    rev.run()
+    c10, own10, idx10 = _device_csr(rev, 1, 0)
+    assert int(c10.sum().item()) == n01 and n01 > 1_000_000
+    assert _moment(own10, idx10, a1, a0) == m01, "0->1 and 1->0 disagree on the pair set"
+    del rev, own10, idx10
+    # idempotence (second and third run: grid reused, boundary cached)
+    for _ in range(2):
+        ns.run()
+    assert ns.get_stats()["n_cached_sets"] == 2 and ns.get_stats()["speculated"] == 1
+    c00b, own, idx = _device_csr(ns, 0, 0)
+    assert torch.equal(c00, c00b) and _moment(own, idx, a0, b0) == m
+    c01b, own, idx = _device_csr(ns, 0, 1)
+    assert torch.equal(c01, c01b) and _moment(own, idx, a0, a1) == m01
+
+
+def test_c4_20m_properties_and_zsort_invariance():
+    """20 M-point dam break, per-point radii, symmetric search: symmetric pair set, no self, distinct entries; after prepare_zsort +
+    apply_zsort(xyz, radii, ids) the SAME pairs come out in terms of the points' identities."""
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    n = 20_000_000
+    p, rad, r0 = D.dam_break_cloud(n)
+    d_p, d_r = torch.from_numpy(p).cuda(), torch.from_numpy(rad).cuda()
+    ids = torch.arange(n, dtype=torch.int64, device="cuda")
+    ns = T.TreeNSearch()
+    ns.add_point_set(d_p, d_r)
+    ns.set_active_search(0, 0, True)
+    ns.set_symmetric_search(True)
+    ns.run()
+    a, b = _weights(n, 11), _weights(n, 12)
+    cnt, own, idx = _device_csr(ns, 0, 0)
+    _assert_lists_wellformed(own, idx, n, True, "c4")
+    m_ab = _moment(own, idx, a, b)
+    assert m_ab == _moment(own, idx, b, a), "symmetric search, yet the pair set is not symmetric"
+    total = int(cnt.sum().item())
+    deg = int((a * cnt).sum().item())                           # identity-weighted degree sum
+    del own, idx
+    ns.prepare_zsort()
+    ns.apply_zsort(0, d_p, 3)
+    ns.apply_zsort(0, d_r, 1)
+    ns.apply_zsort(0, ids, 1)
+    assert not torch.equal(ids, torch.arange(n, dtype=torch.int64, device="cuda"))
+    ns.run()
+    cnt2, own2, idx2 = _device_csr(ns, 0, 0)
+    assert int(cnt2.sum().item()) == total
+    assert int((a[ids] * cnt2).sum().item()) == deg, "neighbour counts changed under the z-sort"
+    assert _moment(own2, idx2, a[ids], b[ids]) == m_ab, "the pair set changed under the z-sort"
+
+
+def test_c4_step_loop_matches_oracle(oracle):
+    """configs[3], five steps at 100 k points: perturb (<= 0.1 r0), prepare_zsort, apply_zsort(xyz), apply_zsort(radii), run -- every step
+    against the oracle on the arrays as they are after the permutation; symmetric and asymmetric."""
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    n = 100_000
+    for symmetric in (True, False):
+        p, rad, r0 = D.dam_break_cloud(n, 21)
+        d_p, d_r = torch.from_numpy(p).cuda(), torch.from_numpy(rad).cuda()
+        ns = T.TreeNSearch()
+        ns.add_point_set(d_p, d_r)
+        ns.set_active_search(0, 0, True)
+        ns.set_symmetric_search(symmetric)
+        g = torch.Generator(device="cuda").manual_seed(7)
+        for step in range(5):
+            d_p.add_((torch.rand(d_p.shape, generator=g, device="cuda") - 0.5) * (2.0 * 0.1 * float(r0) / 3.0 ** 0.5))
+            ns.prepare_zsort()
+            ns.apply_zsort(0, d_p, 3)
+            ns.apply_zsort(0, d_r, 1)
+            ns.run()
+            hp, hr = d_p.cpu().numpy(), d_r.cpu().numpy()
+            ref = oracle.pair_search(hp, hp, ra=hr, rb=hr, symmetric=symmetric, same_set=True)
+            P.assert_same_csr(ns.neighbor_csr(0, 0), ref, f"c4 loop step {step} symmetric={symmetric}")
+            # the order handed out is a permutation and the points really are z-sorted on the reference grid afterwards
+            order = ns.get_zsort_order(0)
+            assert np.array_equal(np.sort(order), np.arange(n))

@@ -11,5 +11,5 @@ for f in tnsx_query tnsx_build; do
   /opt/rocm/bin/hipcc $FL "$@" -c treensearch_amd/csrc/$f.hip -o ab_libs/obj_$name/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab_libs/libtnsx_$name.so ab_libs/obj_$name/tnsx_query.o ab_libs/obj_$name/tnsx_build.o treensearch_amd/lib/tnsx_kernels.o treensearch_amd/lib/tnsx_engine.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab_libs/libtnsx_$name.so ab_libs/obj_$name/tnsx_query.o ab_libs/obj_$name/tnsx_build.o treensearch_amd/lib/tnsx_kernels.o treensearch_amd/lib/tnsx_engine.o treensearch_amd/lib/tnsx_multi.o
 echo built ab_libs/libtnsx_$name.so

@@ -35,7 +35,7 @@ class TnsxError(RuntimeError):
 class _Options(C.Structure):
     _fields_ = [("device_id", C.c_int), ("stream", C.c_void_p), ("arith", C.c_int), ("mirror_to_host", C.c_int),
                 ("collect_stage_times", C.c_int), ("exact_layout", C.c_int), ("max_dense_cells", C.c_uint64), ("temporal_reuse", C.c_int),
-                ("reserved", C.c_int * 6)]
+                ("sorted_lists", C.c_int), ("n_devices", C.c_int), ("device_ids", C.c_int * 8), ("reserved", C.c_int * 4)]
 
 
 class _CsrView(C.Structure):
@@ -51,9 +51,9 @@ class Stats(C.Structure):
                 ("bytes_build", C.c_uint64), ("bytes_query", C.c_uint64),
                 ("ms_total", C.c_float), ("ms_upload", C.c_float), ("ms_bounds", C.c_float), ("ms_table_clear", C.c_float),
                 ("ms_sort", C.c_float), ("ms_cells", C.c_float), ("ms_count", C.c_float),
-                ("ms_scan", C.c_float), ("ms_fill", C.c_float), ("ms_mirror", C.c_float),
+                ("ms_scan", C.c_float), ("ms_fill", C.c_float), ("ms_mirror", C.c_float), ("ms_sort_lists", C.c_float),
                 ("n_pool_pairs", C.c_int), ("pool_retries", C.c_int), ("cold_passes", C.c_int), ("speculated", C.c_int),
-                ("speculation_redos", C.c_int), ("n_cached_sets", C.c_int),
+                ("speculation_redos", C.c_int), ("n_cached_sets", C.c_int), ("n_devices_used", C.c_int),
                 ("world_bottom", C.c_float * 3), ("world_top", C.c_float * 3), ("world_cells_pow2", C.c_int)]
 
     def as_dict(self):
@@ -185,7 +185,8 @@ class NeighborList:
 class TreeNSearch:
     def __init__(self, *, arith: int = ARITH_STRICT, mirror_to_host: bool = False, device_id: int = -1,
                  stream: Optional[int] = None, collect_stage_times: bool = False, max_dense_cells: int = 0,
-                 exact_layout: bool = False, temporal_reuse: bool = True):
+                 exact_layout: bool = False, temporal_reuse: bool = True, sorted_lists: bool = False, devices=None):
+        """devices: a list of HIP device ordinals -> multi-device mode (host-resident inputs only, see include/tnsx.h)"""
         self._L = load_library()
         opt = _Options()
         self._L.tnsx_default_options(C.byref(opt))
@@ -197,6 +198,11 @@ class TreeNSearch:
         opt.max_dense_cells = max_dense_cells
         opt.exact_layout = int(exact_layout)
         opt.temporal_reuse = int(temporal_reuse)
+        opt.sorted_lists = int(sorted_lists)
+        if devices is not None and len(devices) > 1:
+            opt.n_devices = len(devices)
+            for k, d in enumerate(devices):
+                opt.device_ids[k] = int(d)
         h = C.c_void_p()
         st = self._L.tnsx_create(C.byref(opt), C.byref(h))
         if st != 0:

@@ -15,8 +15,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libtnsx.so")
-SOURCES = ["tnsx_kernels.hip", "tnsx_build.hip", "tnsx_query.hip", "tnsx_engine.cpp"]
-HEADERS = ["tnsx_kernels.h", "tnsx_device.h", os.path.join(ROOT, "include", "tnsx.h")]
+SOURCES = ["tnsx_kernels.hip", "tnsx_build.hip", "tnsx_query.hip", "tnsx_engine.cpp", "tnsx_multi.cpp"]
+HEADERS = ["tnsx_kernels.h", "tnsx_device.h", "tnsx_multi.h", os.path.join(ROOT, "include", "tnsx.h")]
 
 # -ffp-contract=off: the neighbour predicate must not be re-associated or fused behind our back
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

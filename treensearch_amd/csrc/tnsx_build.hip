@@ -93,12 +93,13 @@ __device__ __forceinline__ uint64_t sort_key(float x, float y, float z, const Gr
 //             not change keeps its sorted arrays and cell table (the static boundary of an SPH scene)
 __device__ __forceinline__ unsigned long long point_hash(uint32_t i, float x, float y, float z, float r)
 {
-	unsigned long long a = ((unsigned long long)__float_as_uint(y) << 32) | __float_as_uint(x);
-	unsigned long long b = ((unsigned long long)__float_as_uint(r) << 32) | __float_as_uint(z);
-	a = (a ^ (a >> 29)) * 0xBF58476D1CE4E5B9ull;
-	b = (b + 0x9E3779B97F4A7C15ull * (2ull * i + 1ull)) * 0x94D049BB133111EBull;
-	unsigned long long h = a ^ b ^ (a >> 31) ^ (b >> 27);
-	return h * (2ull * i + 1ull);
+	// two 32-bit mixes of the four words (odd multipliers, rotations), joined to 64 bits and weighted with the odd number 2 i + 1
+	// (a permutation of the points, or a change of one of them, changes the sum): ~14 integer instructions per point
+	const uint32_t ux = __float_as_uint(x), uy = __float_as_uint(y), uz = __float_as_uint(z), ur = __float_as_uint(r);
+	const uint32_t m1 = (ux * 0x9E3779B1u) ^ __funnelshift_l(uy, uy, 13) ^ (uz * 0x85EBCA77u) ^ __funnelshift_l(ur, ur, 7);
+	const uint32_t m2 = (uy * 0xC2B2AE3Du) ^ __funnelshift_l(uz, uz, 17) ^ (ur * 0x27D4EB2Fu) ^ __funnelshift_l(ux, ux, 5) ^ i;
+	const unsigned long long h = ((unsigned long long)m1 << 32) | m2;
+	return h * (unsigned long long)(2u * i + 1u) + (unsigned long long)m1 * m2;
 }
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 {
@@ -106,12 +107,6 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
 	return v;
 }
-__device__ __forceinline__ bool outside(const BuildGuard& gd, float x, float y, float z)
-{
-	// (NaN x = "no point": not outside; NaN in y or z fails the comparisons and is reported)
-	return x == x && !(x >= gd.lo[0] && x <= gd.hi[0] && y >= gd.lo[1] && y <= gd.hi[1] && z >= gd.lo[2] && z <= gd.hi[2]);
-}
-
 // ---- per-tile histogram of one digit -----------------------------------------------------------------------------
 template <int BITS, bool FIRST, bool MORTON>
 __global__ void __launch_bounds__(CS_THREADS) k_cs_hist(const float* __restrict__ xyz, const float4* __restrict__ xyzi, int n, GridParams g, int shift,
@@ -123,6 +118,7 @@ __global__ void __launch_bounds__(CS_THREADS) k_cs_hist(const float* __restrict_
 	__syncthreads();
 	const size_t base = (size_t)blockIdx.x * CS_TILE;
 	bool bad = false;
+	float mn[3] = { gd.hi[0], gd.hi[1], gd.hi[2] }, mx[3] = { gd.lo[0], gd.lo[1], gd.lo[2] };   // (guard: this thread's bounds, compared once at the end)
 	unsigned long long chk = 0;
 	#pragma unroll 8
 	for (int i = 0; i < CS_ITEMS; i++) {
@@ -133,7 +129,13 @@ __global__ void __launch_bounds__(CS_THREADS) k_cs_hist(const float* __restrict_
 				const F3 q = reinterpret_cast<const F3*>(xyz)[e];
 				key = sort_key<MORTON>(q.x, q.y, q.z, g);
 				if (!MORTON) {
-					if (gd.flag) bad |= outside(gd, q.x, q.y, q.z);
+					if (gd.flag) {
+						// v_min / v_max drop a NaN operand: a NaN x ("no point") never counts, NaN in y or z is caught below
+						mn[0] = fminf(mn[0], q.x); mx[0] = fmaxf(mx[0], q.x);
+						mn[1] = fminf(mn[1], q.y); mx[1] = fmaxf(mx[1], q.y);
+						mn[2] = fminf(mn[2], q.z); mx[2] = fmaxf(mx[2], q.z);
+						bad |= (q.y != q.y) | (q.z != q.z);
+					}
 					if (gd.checksum) chk += point_hash((uint32_t)e, q.x, q.y, q.z, radii ? radii[e] : 0.0f);
 				}
 			}
@@ -142,8 +144,11 @@ __global__ void __launch_bounds__(CS_THREADS) k_cs_hist(const float* __restrict_
 		}
 	}
 	if (FIRST && !MORTON) {
+		if (gd.flag) bad |= mn[0] < gd.lo[0] || mn[1] < gd.lo[1] || mn[2] < gd.lo[2] || mx[0] > gd.hi[0] || mx[1] > gd.hi[1] || mx[2] > gd.hi[2];
 		if (gd.flag && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane_id() == 0) atomicOr(gd.flag, 1u);
-		if (gd.checksum) { chk = wave_sum_u64(chk); if (lane_id() == 0 && chk) atomicAdd(gd.checksum, chk); }
+		// (partial sums spread over CHK_SLOTS cache lines: the L2 serialises atomics on one line, ~88 per microsecond, and ten thousand
+		//  waves adding to ONE word cost 0.12 ms at 10 M points)
+		if (gd.checksum) { chk = wave_sum_u64(chk); if (lane_id() == 0 && chk) atomicAdd(gd.checksum + (blockIdx.x % CHK_SLOTS) * CHK_STRIDE, chk); }
 	}
 	__syncthreads();
 	for (int b = threadIdx.x; b < RADIX; b += CS_THREADS) hist[(size_t)blockIdx.x * RADIX + b] = h[b];   // row = tile: coalesced
@@ -157,7 +162,7 @@ __global__ void __launch_bounds__(256) k_set_checksum(const float* __restrict__ 
 		chk += point_hash((uint32_t)e, q.x, q.y, q.z, radii ? radii[e] : 0.0f);
 	}
 	chk = wave_sum_u64(chk);
-	if (lane_id() == 0 && chk) atomicAdd(out, chk);
+	if (lane_id() == 0 && chk) atomicAdd(out + (blockIdx.x % CHK_SLOTS) * CHK_STRIDE, chk);
 }
 void launch_set_checksum(const float* xyz, const float* radii, int n, unsigned long long* out, hipStream_t s)
 {

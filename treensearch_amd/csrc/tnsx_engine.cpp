@@ -6,6 +6,7 @@
 // There is deliberately NO CPU fallback anywhere in this file.
 #include "../../include/tnsx.h"
 #include "tnsx_kernels.h"
+#include "tnsx_multi.h"
 
 #include <hip/hip_runtime.h>
 
@@ -18,6 +19,7 @@
 #include <limits>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -122,6 +124,7 @@ struct PairResult {
 }  // namespace
 
 struct tnsx_context {
+	tnsx_multi::State* multi = nullptr;   // multi-device mode (tnsx_options.n_devices > 1): everything is dispatched to tnsx_multi.cpp
 	tnsx_options opt{};
 	int device = 0;
 	hipStream_t stream = nullptr;
@@ -346,6 +349,8 @@ tnsx_status tnsx_default_options(tnsx_options* opt)
 	opt->exact_layout = 0;
 	opt->max_dense_cells = 0;
 	opt->temporal_reuse = 1;
+	opt->sorted_lists = 0;
+	opt->n_devices = 0;
 	return TNSX_OK;
 }
 
@@ -362,6 +367,12 @@ tnsx_status tnsx_create(const tnsx_options* opt, tnsx_context** out)
 	}
 	tnsx_context* c = new tnsx_context();
 	if (opt) c->opt = *opt; else tnsx_default_options(&c->opt);
+	if (c->opt.n_devices > 1) {
+		c->multi = tnsx_multi::create(c->opt, g_create_error);
+		if (!c->multi) { delete c; return g_create_error.find("no HIP device") != std::string::npos ? TNSX_ERR_NO_DEVICE : TNSX_ERR_HIP; }
+		*out = c;
+		return TNSX_OK;
+	}
 	c->auto_dense_cells = c->opt.max_dense_cells == 0;   // default: bounded by the number of points (see run_once)
 	if (c->opt.max_dense_cells == 0) c->opt.max_dense_cells = (uint64_t)1 << 30;
 	if (c->opt.max_dense_cells > ((uint64_t)1 << 30)) c->opt.max_dense_cells = (uint64_t)1 << 30;   // 32-bit keys, int cell arithmetic
@@ -391,6 +402,7 @@ tnsx_status tnsx_create(const tnsx_options* opt, tnsx_context** out)
 void tnsx_destroy(tnsx_context* c)
 {
 	if (!c) return;
+	if (c->multi) { tnsx_multi::destroy(c->multi); delete c; return; }
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
 	for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -399,9 +411,13 @@ void tnsx_destroy(tnsx_context* c)
 }
 
 // ------------------------------------------------------------------------------------------------ sets
+#define TNSX_MULTI(call) do { if (c->multi) return (call); } while (0)
+#define TNSX_NOT_MULTI(what) do { if (c->multi) TNSX_FAIL(c, TNSX_ERR_STATE, what ": not available on a multi-device context (host-resident inputs and host views only)"); } while (0)
+
 int tnsx_add_point_set(tnsx_context* c, const void* xyz, const void* radii, int n, unsigned flags)
 {
 	if (!c) return -TNSX_ERR_INVALID;
+	TNSX_MULTI(tnsx_multi::add_point_set(c->multi, xyz, radii, n, flags, c->last_error));
 	if (n < 0) { c->last_error = "add_point_set: n_points < 0"; return -TNSX_ERR_INVALID; }
 	new_point_set(c);
 	PointSet& s = c->sets.back();
@@ -419,6 +435,7 @@ int tnsx_add_point_set(tnsx_context* c, const void* xyz, const void* radii, int 
 tnsx_status tnsx_resize_point_set(tnsx_context* c, int set_id, const void* xyz, const void* radii, int n, unsigned flags)
 {
 	if (!c) return TNSX_ERR_INVALID;
+	TNSX_MULTI(tnsx_multi::resize_point_set(c->multi, set_id, xyz, radii, n, flags, c->last_error));
 	if (!set_ok(c, set_id)) TNSX_FAIL(c, TNSX_ERR_INVALID, "TreeNSearch::resize_point_set error: Cannot resize a set that was not previously added.");
 	if (n < 0) TNSX_FAIL(c, TNSX_ERR_INVALID, "resize_point_set: n_points < 0");
 	PointSet& s = c->sets[set_id];
@@ -444,6 +461,7 @@ tnsx_status tnsx_resize_point_set(tnsx_context* c, int set_id, const void* xyz, 
 tnsx_status tnsx_set_search_radius(tnsx_context* c, float r)
 {
 	if (!c) return TNSX_ERR_INVALID;
+	TNSX_MULTI(tnsx_multi::set_search_radius(c->multi, r, c->last_error));
 	if (c->n_sets_with_radii > 0) {
 		TNSX_FAIL(c, TNSX_ERR_INVALID, "tns::TreeNSearch::set_search_radius error: Cannot set a global search radius if a set with a radii array was already added.");
 	}
@@ -455,6 +473,7 @@ tnsx_status tnsx_set_search_radius(tnsx_context* c, float r)
 tnsx_status tnsx_set_cell_size(tnsx_context* c, float cell_size)
 {
 	if (!c) return TNSX_ERR_INVALID;
+	TNSX_MULTI(tnsx_multi::set_cell_size(c->multi, cell_size, c->last_error));
 	if (c->cell_size > 0.0f) {
 		TNSX_FAIL(c, TNSX_ERR_INVALID, "tns::TreeNSearch::set_cell_size error: Cell size already set. Create a new TreeNSearch instance if you need a different cell_size.");
 	}
@@ -462,17 +481,25 @@ tnsx_status tnsx_set_cell_size(tnsx_context* c, float cell_size)
 	c->cell_size_inv = 1.0f / cell_size;
 	return TNSX_OK;
 }
-tnsx_status tnsx_set_symmetric_search(tnsx_context* c, int active) { if (!c) return TNSX_ERR_INVALID; c->symmetric = active != 0; return TNSX_OK; }
+tnsx_status tnsx_set_symmetric_search(tnsx_context* c, int active)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	if (c->multi) { tnsx_multi::set_symmetric(c->multi, active != 0); return TNSX_OK; }
+	c->symmetric = active != 0;
+	return TNSX_OK;
+}
 tnsx_status tnsx_set_arithmetic(tnsx_context* c, int arith)
 {
 	if (!c) return TNSX_ERR_INVALID;
 	if (arith != TNSX_ARITH_STRICT && arith != TNSX_ARITH_CONTRACTED) TNSX_FAIL(c, TNSX_ERR_INVALID, "set_arithmetic: unknown mode %d", arith);
+	if (c->multi) tnsx_multi::set_arithmetic(c->multi, arith);
 	c->opt.arith = arith;
 	return TNSX_OK;
 }
 tnsx_status tnsx_set_active_search(tnsx_context* c, int i, int j, int active)
 {
 	if (!c) return TNSX_ERR_INVALID;
+	TNSX_MULTI(tnsx_multi::set_active(c->multi, i, j, active != 0, c->last_error));
 	if (!set_ok(c, i) || !set_ok(c, j)) TNSX_FAIL(c, TNSX_ERR_INVALID, "set_active_search: set does not exist (%d, %d)", i, j);
 	c->active[i][j] = active != 0;
 	return TNSX_OK;
@@ -480,6 +507,7 @@ tnsx_status tnsx_set_active_search(tnsx_context* c, int i, int j, int active)
 tnsx_status tnsx_set_active_search_all(tnsx_context* c, int i, int search_in_all, int be_found_by_all)
 {
 	if (!c) return TNSX_ERR_INVALID;
+	TNSX_MULTI(tnsx_multi::set_active_all(c->multi, i, search_in_all != 0, be_found_by_all != 0, c->last_error));
 	if (!set_ok(c, i)) TNSX_FAIL(c, TNSX_ERR_INVALID, "set_active_search: set does not exist (%d)", i);
 	// column first, then row (TreeNSearch.cpp:223-232)
 	for (size_t j = 0; j < c->sets.size(); j++) c->active[j][i] = be_found_by_all != 0;
@@ -489,30 +517,41 @@ tnsx_status tnsx_set_active_search_all(tnsx_context* c, int i, int search_in_all
 tnsx_status tnsx_set_all_searches(tnsx_context* c, int active)
 {
 	if (!c) return TNSX_ERR_INVALID;
+	if (c->multi) { tnsx_multi::set_all_searches(c->multi, active != 0); return TNSX_OK; }
 	for (auto& row : c->active) for (auto& v : row) v = active != 0;
 	return TNSX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ getters
-int tnsx_get_n_sets(const tnsx_context* c) { return c ? (int)c->sets.size() : 0; }
-int tnsx_get_n_points_in_set(const tnsx_context* c, int s) { return (c && set_ok(c, s)) ? c->sets[s].n : -1; }
+int tnsx_get_n_sets(const tnsx_context* c) { return !c ? 0 : (c->multi ? tnsx_multi::n_sets(c->multi) : (int)c->sets.size()); }
+int tnsx_get_n_points_in_set(const tnsx_context* c, int s)
+{
+	if (c && c->multi) return tnsx_multi::n_points_in_set(c->multi, s);
+	return (c && set_ok(c, s)) ? c->sets[s].n : -1;
+}
 int64_t tnsx_get_total_n_points(const tnsx_context* c)
 {
+	if (c && c->multi) return tnsx_multi::total_points(c->multi);
 	int64_t t = 0;
 	if (c) for (const PointSet& s : c->sets) t += s.n;
 	return t;
 }
-int tnsx_is_search_active(const tnsx_context* c, int i, int j) { return (c && set_ok(c, i) && set_ok(c, j)) ? (int)c->active[i][j] : 0; }
-int tnsx_does_set_exist(const tnsx_context* c, int s) { return (c && s < (int)c->sets.size()) ? 1 : 0; }   // TreeNSearch.cpp:215-218
+int tnsx_is_search_active(const tnsx_context* c, int i, int j)
+{
+	if (c && c->multi) return tnsx_multi::is_active(c->multi, i, j) ? 1 : 0;
+	return (c && set_ok(c, i) && set_ok(c, j)) ? (int)c->active[i][j] : 0;
+}
+int tnsx_does_set_exist(const tnsx_context* c, int s) { return (c && s < tnsx_get_n_sets(c)) ? 1 : 0; }   // TreeNSearch.cpp:215-218
 uint64_t tnsx_get_neighborlist_n_bytes(const tnsx_context* c)
 {
+	if (c && c->multi) return tnsx_multi::neighborlist_bytes(c->multi);
 	uint64_t b = 0;
 	if (c) for (const PairResult& p : c->pairs) if (p.valid) b += p.n_records * sizeof(int);
 	return b;
 }
 
 // ------------------------------------------------------------------------------------------------ run
-enum Stage { ST_UPLOAD, ST_BOUNDS, ST_KEYS, ST_SORT, ST_GATHER, ST_CELLS, ST_COUNT, ST_SCAN, ST_FILL, ST_MIRROR, ST_N };
+enum Stage { ST_UPLOAD, ST_BOUNDS, ST_KEYS, ST_SORT, ST_GATHER, ST_CELLS, ST_COUNT, ST_SCAN, ST_FILL, ST_MIRROR, ST_SORT_LISTS, ST_N };
 
 // One attempt of run().  `speculate`: the search grid of the previous run is laid over the points without looking at their
 // bounds first (no bounds kernel, no host round trip before the build), and sets that did not change between the last two runs
@@ -635,9 +674,10 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	S.radix_passes = tnsx::cell_sort_plan(key_bits).passes;
 	S.speculated = speculate ? 1 : 0;
 
-	// ---- device words of this attempt: [0] guard flag, [1 + si] checksum of set si (64-bit each)
-	HIPCHK(c, c->run_words.reserve(sizeof(uint64_t) * (size_t)(n_sets + 1)));
-	HIPCHK(c, hipMemsetAsync(c->run_words.p, 0, sizeof(uint64_t) * (size_t)(n_sets + 1), st));
+	// ---- device words of this attempt (64-bit each): block 0 = the guard flag, block 1 + si = the partial checksums of set si
+	constexpr size_t WB = (size_t)tnsx::CHK_SLOTS * tnsx::CHK_STRIDE;   // words per block
+	HIPCHK(c, c->run_words.reserve(sizeof(uint64_t) * WB * (size_t)(n_sets + 1)));
+	HIPCHK(c, hipMemsetAsync(c->run_words.p, 0, sizeof(uint64_t) * WB * (size_t)(n_sets + 1), st));
 	unsigned long long* const d_words = c->run_words.as<unsigned long long>();
 
 	// ---- per set: cell sort -> cell table (or nothing: a set that did not change keeps what it has)
@@ -653,7 +693,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		const bool cacheable = !s.user_ids && s.n > 0;
 		if (speculate && cacheable && s.predicted_static && same_input && s.built_gen == c->grid_gen && s.table_state == 1) {
 			// taken to be unchanged: only its checksum is computed (and compared after the run)
-			tnsx::launch_set_checksum(s.d_xyz, variable ? s.d_radii : nullptr, s.n, d_words + 1 + si, st);
+			tnsx::launch_set_checksum(s.d_xyz, variable ? s.d_radii : nullptr, s.n, d_words + WB * (size_t)(1 + si), st);
 			skipped[(size_t)si] = 1;
 			S.n_cached_sets++;
 			continue;
@@ -685,7 +725,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			gd.r_max = c->grid_r_max;
 			gd.flag = reinterpret_cast<uint32_t*>(d_words);
 		}
-		if (cacheable) gd.checksum = d_words + 1 + si;
+		if (cacheable) gd.checksum = d_words + WB * (size_t)(1 + si);
 		const int t1 = tm.mark();
 		if (s.user_ids) HIPCHK(c, s.orig_sorted.reserve((size_t)s.n * sizeof(uint32_t)));
 		s.sorted_buf = tnsx::launch_cell_sort(s.d_xyz, variable ? s.d_radii : nullptr, s.n, g, key_bits, cb, c->sort_temp.p, s.user_ids,
@@ -702,10 +742,10 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	struct Job { int i, j; bool pool; };
 	std::vector<Job> jobs;
 	for (int i = 0; i < n_sets; i++) for (int j = 0; j < n_sets; j++) if (c->active[i][j]) jobs.push_back({ i, j, false });
-	HIPCHK(c, c->h_small.reserve(sizeof(uint64_t) * (2 * jobs.size() + 2 + (size_t)n_sets + 1) + sizeof(uint32_t) * (size_t)(n_sets + 1) + 64));
+	HIPCHK(c, c->h_small.reserve(sizeof(uint64_t) * (2 * jobs.size() + 2 + WB * ((size_t)n_sets + 1)) + sizeof(uint32_t) * (size_t)(n_sets + 1) + 64));
 	uint64_t* h_ctrl = c->h_small.as<uint64_t>();                       // per job: {cursor | total, hit_total}
-	uint64_t* h_words = h_ctrl + 2 * jobs.size() + 2;                   // guard flag, checksums
-	uint32_t* h_nocc = reinterpret_cast<uint32_t*>(h_words + n_sets + 1);
+	uint64_t* h_words = h_ctrl + 2 * jobs.size() + 2;                   // guard flag, partial checksums
+	uint32_t* h_nocc = reinterpret_cast<uint32_t*>(h_words + WB * ((size_t)n_sets + 1));
 	HIPCHK(c, c->pool_ctrl.reserve(tnsx::CTRL_BYTES * (jobs.size() + 1)));   // per job: cursor, hit_total, 2 x (8 tickets, n_heavy), spread out
 	auto ctrl_slot = [&](size_t k, int slot) { return c->pool_ctrl.as<uint32_t>() + (k * tnsx::CTRL_SLOTS + (size_t)slot) * tnsx::CTRL_STRIDE_U32; };
 	const int query_waves = c->n_cus * 8 * 4;
@@ -806,7 +846,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		}
 	}
 	HIPCHK(c, hipMemcpyAsync(h_nocc, c->n_occ.p, sizeof(uint32_t) * (size_t)std::max(n_sets, 1), hipMemcpyDeviceToHost, st));
-	HIPCHK(c, hipMemcpyAsync(h_words, c->run_words.p, sizeof(uint64_t) * (size_t)(n_sets + 1), hipMemcpyDeviceToHost, st));
+	HIPCHK(c, hipMemcpyAsync(h_words, c->run_words.p, sizeof(uint64_t) * WB * (size_t)(n_sets + 1), hipMemcpyDeviceToHost, st));
 	HIPCHK(c, hipStreamSynchronize(st));   // record totals / pool cursors / what was speculated on are needed on the host
 
 	// ---- were the assumptions of this attempt right?
@@ -820,11 +860,13 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		PointSet& s = c->sets[si];
 		const bool cacheable = !s.user_ids && s.n > 0;
 		const bool same_input = s.chk_valid && s.chk_xyz == s.user_xyz && s.chk_radii == s.user_radii && s.chk_n == s.n && s.chk_double == s.is_double;
-		const bool unchanged = cacheable && same_input && s.chk_value == h_words[1 + si];
+		uint64_t chk_now = 0;
+		for (int k = 0; k < tnsx::CHK_SLOTS; k++) chk_now += h_words[WB * (size_t)(1 + si) + (size_t)k * tnsx::CHK_STRIDE];
+		const bool unchanged = cacheable && same_input && s.chk_value == chk_now;
 		if (skipped[(size_t)si] && !unchanged) { wrong = true; s.predicted_static = false; s.chk_valid = false; continue; }
 		if (wrong) continue;                      // (an attempt that is thrown away teaches nothing)
 		s.predicted_static = unchanged;           // two equal checksums in a row: the next run keeps the structures
-		s.chk_valid = cacheable; s.chk_value = h_words[1 + si];
+		s.chk_valid = cacheable; s.chk_value = chk_now;
 		s.chk_xyz = s.user_xyz; s.chk_radii = s.user_radii; s.chk_n = s.n; s.chk_double = s.is_double;
 		if (!skipped[(size_t)si] && s.n > 0) s.built_gen = c->grid_gen;
 	}
@@ -879,6 +921,17 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	}
 	for (int si = 0; si < n_sets; si++) S.n_occupied_cells += h_nocc[si];
 
+	// ---- optional: ascending order inside every record
+	if (c->opt.sorted_lists) {
+		const int t0 = tm.mark();
+		for (const Job& jb : jobs) {
+			PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
+			tnsx::launch_sort_records(pr.records.as<int>(), pr.offs_orig.as<uint64_t>(), pr.n_query, c->n_cus, st);
+		}
+		const int t1 = tm.mark();
+		span(ST_SORT_LISTS, t0, t1);
+	}
+
 	// ---- optional pinned host mirror (what get_neighborlist needs on the CPU side)
 	const int e_m0 = tm.mark();
 	if (c->opt.mirror_to_host) {
@@ -910,7 +963,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		for (const Span& sp : spans) acc[sp.stage] += tm.ms(sp.a, sp.b);
 		S.ms_upload = acc[ST_UPLOAD]; S.ms_bounds = acc[ST_BOUNDS]; S.ms_table_clear = acc[ST_KEYS]; S.ms_sort = acc[ST_SORT];
 		S.ms_cells = acc[ST_CELLS]; S.ms_count = acc[ST_COUNT]; S.ms_scan = acc[ST_SCAN];
-		S.ms_fill = acc[ST_FILL]; S.ms_mirror = acc[ST_MIRROR];
+		S.ms_fill = acc[ST_FILL]; S.ms_mirror = acc[ST_MIRROR]; S.ms_sort_lists = acc[ST_SORT_LISTS];
 		S.ms_total = tm.ms(e_begin, e_end);
 	}
 	c->ran = true;
@@ -920,6 +973,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 tnsx_status tnsx_run(tnsx_context* c)
 {
 	if (!c) return TNSX_ERR_INVALID;
+	TNSX_MULTI(tnsx_multi::run(c->multi, c->last_error));
 	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
 	c->stats.speculation_redos = 0;
 	// the previous run's grid can be laid over this run's points unseen if nothing it was derived from has changed on the host side
@@ -953,6 +1007,7 @@ static tnsx_status find_pair(tnsx_context* c, int i, int j, PairResult** out)
 tnsx_status tnsx_mirror_pair_to_host(tnsx_context* c, int i, int j)
 {
 	if (!c) return TNSX_ERR_INVALID;
+	if (c->multi) { tnsx_csr_view v; return tnsx_multi::pair_view(c->multi, i, j, &v, c->last_error); }   // (always mirrored)
 	PairResult* pr = nullptr;
 	{ const tnsx_status r = find_pair(c, i, j, &pr); if (r != TNSX_OK) return r; }
 	std::lock_guard<std::mutex> lock(c->mirror_mutex);
@@ -972,6 +1027,7 @@ tnsx_status tnsx_mirror_pair_to_host(tnsx_context* c, int i, int j)
 tnsx_status tnsx_get_pair_view(tnsx_context* c, int i, int j, tnsx_csr_view* out)
 {
 	if (!c || !out) return TNSX_ERR_INVALID;
+	TNSX_MULTI(tnsx_multi::pair_view(c->multi, i, j, out, c->last_error));
 	PairResult* pr = nullptr;
 	{ const tnsx_status r = find_pair(c, i, j, &pr); if (r != TNSX_OK) return r; }
 	out->n_points = pr->n_query;
@@ -987,6 +1043,15 @@ tnsx_status tnsx_get_pair_view(tnsx_context* c, int i, int j, tnsx_csr_view* out
 tnsx_status tnsx_copy_pair(tnsx_context* c, int i, int j, uint64_t* offsets_dst, int* records_dst, int dst_on_device)
 {
 	if (!c) return TNSX_ERR_INVALID;
+	if (c->multi) {
+		if (dst_on_device) TNSX_FAIL(c, TNSX_ERR_STATE, "tnsx_copy_pair to device memory: not available on a multi-device context");
+		tnsx_csr_view v;
+		const tnsx_status r = tnsx_multi::pair_view(c->multi, i, j, &v, c->last_error);
+		if (r != TNSX_OK) return r;
+		if (offsets_dst && v.n_points > 0) std::memcpy(offsets_dst, v.offsets_host, (size_t)v.n_points * sizeof(uint64_t));
+		if (records_dst && v.n_records > 0) std::memcpy(records_dst, v.records_host, v.n_records * sizeof(int));
+		return TNSX_OK;
+	}
 	PairResult* pr = nullptr;
 	{ const tnsx_status r = find_pair(c, i, j, &pr); if (r != TNSX_OK) return r; }
 	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
@@ -1000,6 +1065,7 @@ tnsx_status tnsx_copy_pair(tnsx_context* c, int i, int j, uint64_t* offsets_dst,
 tnsx_status tnsx_translate_neighbors(tnsx_context* c, int i, int j, const int* id_map_dev)
 {
 	if (!c) return TNSX_ERR_INVALID;
+	TNSX_NOT_MULTI("tnsx_translate_neighbors");
 	PairResult* pr = nullptr;
 	{ const tnsx_status r = find_pair(c, i, j, &pr); if (r != TNSX_OK) return r; }
 	if (!id_map_dev) TNSX_FAIL(c, TNSX_ERR_INVALID, "tnsx_translate_neighbors: null id map");
@@ -1015,6 +1081,7 @@ tnsx_status tnsx_translate_neighbors(tnsx_context* c, int i, int j, const int* i
 tnsx_status tnsx_prepare_zsort(tnsx_context* c)
 {
 	if (!c) return TNSX_ERR_INVALID;
+	TNSX_MULTI(tnsx_multi::prepare_zsort(c->multi, c->last_error));
 	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
 	hipStream_t st = c->stream;
 	// _set_up (TreeNSearch.cpp:2584) + world box (TreeNSearch.cpp:2666)
@@ -1078,6 +1145,7 @@ static tnsx_status zsort_host_order(tnsx_context* c, PointSet& s)
 tnsx_status tnsx_get_zsort_order(tnsx_context* c, int set_i, const int** host, const int** dev, int* n)
 {
 	if (!c) return TNSX_ERR_INVALID;
+	if (c->multi) { if (dev) *dev = nullptr; return tnsx_multi::zsort_order(c->multi, set_i, host, n, c->last_error); }
 	if (!set_ok(c, set_i)) TNSX_FAIL(c, TNSX_ERR_INVALID, "tns::TreeNSearch::apply_zsort error: set to z_sort does not exit.");
 	PointSet& s = c->sets[set_i];
 	if (!s.zsort_ready) TNSX_FAIL(c, TNSX_ERR_STATE, "tns::TreeNSearch::apply_zsort error: no zsort order ready for set_i (%d).", set_i);
@@ -1090,6 +1158,10 @@ tnsx_status tnsx_get_zsort_order(tnsx_context* c, int set_i, const int** host, c
 tnsx_status tnsx_apply_zsort(tnsx_context* c, int set_i, void* data, size_t elem_bytes, int stride, int on_device)
 {
 	if (!c) return TNSX_ERR_INVALID;
+	if (c->multi) {
+		if (on_device) TNSX_FAIL(c, TNSX_ERR_STATE, "tnsx_apply_zsort on device memory: not available on a multi-device context");
+		return tnsx_multi::apply_zsort(c->multi, set_i, data, elem_bytes, stride, c->last_error);
+	}
 	if (!set_ok(c, set_i)) TNSX_FAIL(c, TNSX_ERR_INVALID, "tns::TreeNSearch::apply_zsort error: set to z_sort does not exit.");
 	PointSet& s = c->sets[set_i];
 	if (!s.zsort_ready) TNSX_FAIL(c, TNSX_ERR_STATE, "tns::TreeNSearch::apply_zsort error: no zsort order ready for set_i (%d).", set_i);
@@ -1105,12 +1177,19 @@ tnsx_status tnsx_apply_zsort(tnsx_context* c, int set_i, void* data, size_t elem
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 	}
 	else {
-		// user memory on the host: plain gather through a swap buffer, as TreeNSearch.h:456-480 does
+		// user memory on the host: gather through a swap buffer on the host cores, as TreeNSearch.h:456-480 does with OpenMP
 		std::vector<unsigned char> swap((const unsigned char*)data, (const unsigned char*)data + rec * (size_t)n);
 		unsigned char* dst = (unsigned char*)data;
 		{ const tnsx_status r = zsort_host_order(c, s); if (r != TNSX_OK) return r; }
 		const int* map = s.zsort_host.data();
-		for (int i = 0; i < n; i++) std::memcpy(dst + rec * (size_t)i, swap.data() + rec * (size_t)map[i], rec);
+		const unsigned char* src = swap.data();
+		auto gather = [=](int lo, int hi) { for (int i = lo; i < hi; i++) std::memcpy(dst + rec * (size_t)i, src + rec * (size_t)map[i], rec); };
+		unsigned n_thr = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+		if ((size_t)n * rec < ((size_t)1 << 20)) n_thr = 1;
+		std::vector<std::thread> pool;
+		for (unsigned t = 1; t < n_thr; t++) pool.emplace_back(gather, (int)((long long)n * t / n_thr), (int)((long long)n * (t + 1) / n_thr));
+		gather(0, (int)((long long)n / n_thr));
+		for (std::thread& th : pool) th.join();
 	}
 	return TNSX_OK;
 }
@@ -1120,6 +1199,7 @@ tnsx_status tnsx_halo_pack(tnsx_context* c, const float* xyz, const float* radii
                            unsigned int* counts_dev, unsigned int* counts_host)
 {
 	if (!c) return TNSX_ERR_INVALID;
+	TNSX_NOT_MULTI("tnsx_halo_pack");
 	if (n_points < 0 || !counts_dev || (n_points > 0 && (!xyz || !global_ids))) TNSX_FAIL(c, TNSX_ERR_INVALID, "tnsx_halo_pack: null pointer or negative size");
 	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
 	HIPCHK(c, hipMemsetAsync(counts_dev, 0, 2 * sizeof(unsigned int), c->stream));
@@ -1138,6 +1218,7 @@ tnsx_status tnsx_halo_pack(tnsx_context* c, const float* xyz, const float* radii
 tnsx_status tnsx_x_histogram(tnsx_context* c, const float* xyz, int n_points, float x0, float inv_dx, int n_bins, unsigned int* hist_dev)
 {
 	if (!c) return TNSX_ERR_INVALID;
+	TNSX_NOT_MULTI("tnsx_x_histogram");
 	if (n_points < 0 || n_bins <= 0 || !hist_dev || (n_points > 0 && !xyz)) TNSX_FAIL(c, TNSX_ERR_INVALID, "tnsx_x_histogram: null pointer or bad size");
 	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
 	tnsx::launch_x_histogram(xyz, n_points, x0, inv_dx, n_bins, hist_dev, c->stream);
@@ -1148,6 +1229,7 @@ tnsx_status tnsx_x_histogram(tnsx_context* c, const float* xyz, int n_points, fl
 tnsx_status tnsx_set_point_ids(tnsx_context* c, int set_i, const int* ids_dev)
 {
 	if (!c) return TNSX_ERR_INVALID;
+	TNSX_NOT_MULTI("tnsx_set_point_ids");
 	if (!set_ok(c, set_i)) TNSX_FAIL(c, TNSX_ERR_INVALID, "tnsx_set_point_ids: set does not exist (%d)", set_i);
 	c->sets[set_i].user_ids = ids_dev;
 	return TNSX_OK;
@@ -1156,6 +1238,7 @@ tnsx_status tnsx_set_point_ids(tnsx_context* c, int set_i, const int* ids_dev)
 tnsx_status tnsx_synchronize(tnsx_context* c)
 {
 	if (!c) return TNSX_ERR_INVALID;
+	if (c->multi) return TNSX_OK;
 	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	return TNSX_OK;
@@ -1164,6 +1247,7 @@ tnsx_status tnsx_synchronize(tnsx_context* c)
 tnsx_status tnsx_set_query_count(tnsx_context* c, int set_i, int n_query)
 {
 	if (!c) return TNSX_ERR_INVALID;
+	TNSX_NOT_MULTI("tnsx_set_query_count");
 	if (!set_ok(c, set_i)) TNSX_FAIL(c, TNSX_ERR_INVALID, "tnsx_set_query_count: set does not exist (%d)", set_i);
 	c->sets[set_i].n_query = n_query < 0 ? -1 : n_query;
 	return TNSX_OK;
@@ -1172,6 +1256,7 @@ tnsx_status tnsx_set_query_count(tnsx_context* c, int set_i, int n_query)
 tnsx_status tnsx_get_stats(const tnsx_context* c, tnsx_stats* out)
 {
 	if (!c || !out) return TNSX_ERR_INVALID;
+	if (c->multi) { tnsx_multi::stats(c->multi, out); return TNSX_OK; }
 	*out = c->stats;
 	return TNSX_OK;
 }

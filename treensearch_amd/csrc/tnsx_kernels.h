@@ -38,7 +38,9 @@ struct CellSortBuffers { float4* xyzi[2]; float* r2[2]; };
 size_t cell_sort_temp_bytes(int n);
 // What a run of the engine speculates on, validated by the first pass of the sort (see tnsx_build.hip): flag (or nullptr) is
 // raised when a point lies outside [lo, hi] or a radius exceeds r_max; checksum (or nullptr, must be zeroed) receives the
-// order-sensitive 64-bit checksum of the set's points (+ radii).
+// order-sensitive 64-bit checksum of the set's points (+ radii), as CHK_SLOTS partial sums (see above).
+// the checksum of a set is the sum of CHK_SLOTS partial sums that live CHK_STRIDE 64-bit words (one 128-byte line) apart
+static constexpr int CHK_SLOTS = 64, CHK_STRIDE = 16;
 struct BuildGuard {
 	float lo[3] = { 0.f, 0.f, 0.f }, hi[3] = { 0.f, 0.f, 0.f };
 	float r_max = 3.402823466e+38f;
@@ -114,6 +116,9 @@ void launch_halo_pack(const float* xyz, const float* radii, const long long* gid
 void launch_x_histogram(const float* xyz, int n, float x0, float inv_dx, int n_bins, unsigned int* hist, hipStream_t s);
 // list entries j of the records of the first n_query points -> id_map[j], in place
 void launch_translate_records(int* records, const uint64_t* offs_by_orig, int n_query, const int* id_map, int n_cus, hipStream_t s);
+
+// ---- ascending order inside every record of the first n_query points (tnsx_options.sorted_lists), in place
+void launch_sort_records(int* records, const uint64_t* offs_by_orig, int n_query, int n_cus, hipStream_t s);
 
 // ---- permutation of byte records: out[new] = in[perm[new]] ------------------------------------------
 void launch_permute_bytes(const void* in, void* out, const int* new_to_old, int n, size_t rec_bytes, hipStream_t s);

@@ -372,4 +372,87 @@ void launch_translate_records(int* records, const uint64_t* offs_by_orig, int n_
 	hipLaunchKernelGGL(k_translate_records, dim3((unsigned)blocks), dim3(256), 0, s, records, offs_by_orig, n_query, id_map);
 }
 
+// =====================================================================================================
+// ascending neighbour lists (tnsx_options.sorted_lists).  The reference's lists are ascending by construction
+// (TreeNSearch.cpp:2474-2500 emits in cell order over z-sorted input; BruteforceNSearch.cpp:135-137 sorts before comparing); the
+// single-pass query writes them in lane order.  One wave per record, in place:
+//   <= 64 entries    one entry per lane, bitonic network over the lanes (shuffles)
+//   <= 2048 entries  bitonic network in the wave's LDS slice
+//   longer           the same network directly on the record in global memory (rare: thousands of neighbours)
+// Entries past the end act as +infinity and are never written.
+// =====================================================================================================
+static constexpr int SL_LDS = 2048;
+__device__ __forceinline__ void bitonic_mem(int* a, uint32_t cnt, int lane)
+{
+	// `a` (LDS or global), any length.  The network form in which EVERY compare-exchange is ascending (the first stage of a merge
+	// pairs i with its mirror image inside the block, i ^ (k - 1), the later ones with i ^ j): the absent elements past the end
+	// then behave like +infinity that already sits in place, and a pair whose upper index is past the end is simply skipped.
+	uint32_t n2 = 1;
+	while (n2 < cnt) n2 <<= 1;
+	auto stage = [&](uint32_t mask) {
+		for (uint32_t i = (uint32_t)lane; i < cnt; i += WAVE) {
+			const uint32_t l = i ^ mask;
+			if (l > i && l < cnt) {
+				const int x = a[i], y = a[l];
+				if (x > y) { a[i] = y; a[l] = x; }
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	};
+	for (uint32_t k = 2; k <= n2; k <<= 1) {
+		stage(k - 1u);
+		for (uint32_t j = k >> 2; j > 0; j >>= 1) stage(j);
+	}
+}
+__global__ void __launch_bounds__(256) k_sort_records(int* __restrict__ records, const uint64_t* __restrict__ offs_by_orig, int n_query)
+{
+	__shared__ int lds[(256 / WAVE) * SL_LDS];
+	const int lane = lane_id();
+	int* const my = lds + (threadIdx.x / WAVE) * SL_LDS;
+	const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) / WAVE, n_waves = (size_t)gridDim.x * (256 / WAVE);
+	for (size_t p = wave; p < (size_t)n_query; p += n_waves) {
+		int* rec = records + offs_by_orig[p];
+		const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane(rec[0]);
+		rec += 1;
+		if (cnt <= 1u) continue;
+		if (cnt <= (uint32_t)WAVE) {
+			int v = (uint32_t)lane < cnt ? rec[lane] : 0x7fffffff;
+			#pragma unroll
+			for (int k = 2; k <= WAVE; k <<= 1) {
+				#pragma unroll
+				for (int j = k >> 1; j > 0; j >>= 1) {
+					const int o = __shfl_xor(v, j, WAVE);
+					const bool up = (lane & k) == 0, low = (lane & j) == 0;
+					const int mn = v < o ? v : o, mx = v < o ? o : v;
+					v = (low == up) ? mn : mx;
+				}
+			}
+			if ((uint32_t)lane < cnt) rec[lane] = v;
+		}
+		else if (cnt <= (uint32_t)SL_LDS) {
+			for (uint32_t i = (uint32_t)lane; i < cnt; i += WAVE) my[i] = rec[i];
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			bitonic_mem(my, cnt, lane);
+			for (uint32_t i = (uint32_t)lane; i < cnt; i += WAVE) rec[i] = my[i];
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+		}
+		else {
+			bitonic_mem(rec, cnt, lane);
+		}
+	}
+}
+void launch_sort_records(int* records, const uint64_t* offs_by_orig, int n_query, int n_cus, hipStream_t s)
+{
+	if (n_query <= 0) return;
+	long long blocks = ((long long)n_query + 3) / 4;
+	const long long cap = (long long)n_cus * 32;
+	if (blocks > cap) blocks = cap;
+	hipLaunchKernelGGL(k_sort_records, dim3((unsigned)blocks), dim3(256), 0, s, records, offs_by_orig, n_query);
+}
+
 }  // namespace tnsx
