@@ -526,7 +526,9 @@ class SlabSearch:
                 s.buf[n:n + m].copy_(ghost_pts)
             if s.ids is None or s.ids.shape[0] < cap or s.ids.device != dev:
                 s.ids = torch.empty(cap, dtype=torch.int32, device=dev)
-            s.ids[:n].copy_(gids)
+            if getattr(s, "_ids_of", None) != (gids.data_ptr(), n, s.ids.data_ptr()):   # the owned ids rarely change: converted once
+                s.ids[:n].copy_(gids)
+                s._ids_of = (gids.data_ptr(), n, s.ids.data_ptr())
             if m:
                 s.ids[n:n + m].copy_(ghost_gid)
             r_view = None
