@@ -130,10 +130,14 @@ typedef struct tnsx_stats {
 	int speculated;               /* 1: the last run reused the previous run's grid (no bounds pass, no host round trip before the build) */
 	int speculation_redos;        /* attempts of the last run that were thrown away because an assumption was wrong (0 or 1) */
 	int n_cached_sets;            /* point sets whose build was skipped in the last run (input unchanged) */
+	uint32_t n_filtered_cells;    /* pairs of two different sets: query cells that have any candidate (the others share ONE empty record and
+	                                 are never visited), summed over those pairs */
 	int n_devices_used;           /* multi-device mode: slabs the last run was cut into (0 on a single-device context) */
 	/* world box of the reference semantics (TreeNSearch.cpp:415-522) */
 	float world_bottom[3], world_top[3];
 	int world_cells_pow2;
+	float zsort_cell_size_inv;    /* 1 / quantisation step of the last tnsx_prepare_zsort: 1 / cell size after a run() (cell-level order, the
+	                                 reference's tree path), the cell size halved down to < 2^21 steps per axis otherwise (its no-tree path) */
 } tnsx_stats;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */

@@ -406,3 +406,40 @@ def test_cpp_dropin_scenarios_on_two_engines(built_library, tmp_path):
     print(out.stdout[-3000:])
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "FAILED" not in out.stdout and "ALL PASSED" in out.stdout
+
+
+def test_zsort_resolution_follows_the_reference(oracle):
+    """prepare_zsort before any run(): the reference sorts the POINTS on the cell grid refined to just under 2^21 steps per axis
+    (_compute_zsort_order_notree, TreeNSearch.cpp:2678-2699); after a run() it orders whole cells (:2603-2660).  Both orders are
+    checked on the grid the engine reports, and the fine one must really be finer than the cell grid."""
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    pts = D.uniform_cloud(50000, 17)
+    r = D.radius_for_neighbors(50000, 30.0)
+    cell = np.float32(1.5) * np.float32(r)
+    ns = T.TreeNSearch()
+    ns.set_search_radius(r)
+    ns.add_point_set(pts)
+    ns.set_active_search(0, 0, True)
+    ns.prepare_zsort()                                   # no run() yet: point-level order
+    st = ns.get_stats()
+    inv_fine = np.float32(st["zsort_cell_size_inv"])
+    world = np.float32(st["world_top"][0]) - np.float32(st["world_bottom"][0])
+    steps = float(world) * float(inv_fine)
+    assert 0.999 * 2.0 ** 20 <= steps < 2.0 ** 21 and float(inv_fine) > 1000.0 / float(cell)
+    order = ns.get_zsort_order(0)
+    assert np.array_equal(np.sort(order), np.arange(len(pts)))
+    keys = oracle.zsort_keys(pts, np.array(st["world_bottom"], np.float32), inv_fine)
+    assert oracle.check_zsort(keys, order) == 0
+    assert len(np.unique(keys)) > 0.99 * len(pts)        # (at this resolution nearly every point has a key of its own)
+    ns.run()
+    ns.prepare_zsort()                                   # after a run(): cell-level order, in-cell order kept
+    st = ns.get_stats()
+    assert np.float32(st["zsort_cell_size_inv"]) == np.float32(1.0) / cell
+    order = ns.get_zsort_order(0)
+    keys = oracle.zsort_keys(pts, np.array(st["world_bottom"], np.float32), np.float32(1.0) / cell)
+    assert oracle.check_zsort(keys, order) == 0
+    same = keys[order][1:] == keys[order][:-1]
+    assert np.all(np.diff(order)[same] > 0), "points of one cell must keep their order"
+    ns.prepare_zsort()                                   # twice in a row: the cells are gone again (TreeNSearch.cpp:2659-2660)
+    assert np.float32(ns.get_stats()["zsort_cell_size_inv"]) == inv_fine

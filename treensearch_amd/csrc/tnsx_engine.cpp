@@ -116,7 +116,7 @@ struct PairResult {
 	uint64_t need_hint = 0;      // neighbours + points of the previous run: sizes the pool of the next one
 	uint32_t pool_slab = 16384;
 	bool dry = false;            // this pass only counts (first run of a pair: nothing is known about its size yet)
-	DevBuf counts, offs_sorted, offs_orig, records, heavy, heavy2;
+	DevBuf counts, offs_sorted, offs_orig, records, heavy, heavy2, filtered;
 	PinnedBuf h_offs, h_records;
 	bool mirrored = false;
 };
@@ -146,11 +146,13 @@ struct tnsx_context {
 	float world[6] = { FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX };   // bottom, top (octree_internals.h:29-30)
 	int world_cells_pow2 = 0;
 	bool ran = false;
+	bool cells_valid = false;   // the reference's are_cells_valid: a run() has happened since the sets last changed (selects the z-sort resolution)
 	// the search grid of the last run and what it was laid out for (temporal reuse, see run_once)
 	tnsx::GridParams grid{};
 	float grid_h = 0.0f, grid_lo[3] = { 0, 0, 0 }, grid_hi[3] = { 0, 0, 0 }, grid_r_max = 0.0f;
 	bool grid_valid = false, grid_variable = false;
 	uint32_t grid_gen = 0;
+	float zsort_inv_h = 0.0f;   // 1 / quantisation step of the last prepare_zsort (tnsx_stats.zsort_cell_size_inv)
 	bool auto_dense_cells = true;
 	bool debug_nostore = std::getenv("TNSX_DEBUG_NOSTORE") != nullptr;   // timing experiments only: pool pass without its stores
 
@@ -420,6 +422,7 @@ int tnsx_add_point_set(tnsx_context* c, const void* xyz, const void* radii, int 
 	TNSX_MULTI(tnsx_multi::add_point_set(c->multi, xyz, radii, n, flags, c->last_error));
 	if (n < 0) { c->last_error = "add_point_set: n_points < 0"; return -TNSX_ERR_INVALID; }
 	new_point_set(c);
+	c->cells_valid = false;   // TreeNSearch.cpp:364
 	PointSet& s = c->sets.back();
 	s.user_xyz = xyz; s.user_radii = radii; s.n = n;
 	s.is_double = s.radii_double = (flags & TNSX_F64) != 0;
@@ -454,6 +457,7 @@ tnsx_status tnsx_resize_point_set(tnsx_context* c, int set_id, const void* xyz, 
 		s.radii_on_device = s.on_device;
 	}
 	s.zsort_ready = false;
+	c->cells_valid = false;   // TreeNSearch.cpp:117-118
 	return TNSX_OK;
 }
 
@@ -479,6 +483,7 @@ tnsx_status tnsx_set_cell_size(tnsx_context* c, float cell_size)
 	}
 	c->cell_size = cell_size;
 	c->cell_size_inv = 1.0f / cell_size;
+	c->cells_valid = false;   // TreeNSearch.cpp:181
 	return TNSX_OK;
 }
 tnsx_status tnsx_set_symmetric_search(tnsx_context* c, int active)
@@ -742,10 +747,12 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	struct Job { int i, j; bool pool; };
 	std::vector<Job> jobs;
 	for (int i = 0; i < n_sets; i++) for (int j = 0; j < n_sets; j++) if (c->active[i][j]) jobs.push_back({ i, j, false });
-	HIPCHK(c, c->h_small.reserve(sizeof(uint64_t) * (2 * jobs.size() + 2 + WB * ((size_t)n_sets + 1)) + sizeof(uint32_t) * (size_t)(n_sets + 1) + 64));
+	HIPCHK(c, c->h_small.reserve(sizeof(uint64_t) * (2 * jobs.size() + 2 + WB * ((size_t)n_sets + 1)) + sizeof(uint32_t) * (size_t)(n_sets + 1 + jobs.size() + 1) + 64));
 	uint64_t* h_ctrl = c->h_small.as<uint64_t>();                       // per job: {cursor | total, hit_total}
 	uint64_t* h_words = h_ctrl + 2 * jobs.size() + 2;                   // guard flag, partial checksums
 	uint32_t* h_nocc = reinterpret_cast<uint32_t*>(h_words + WB * ((size_t)n_sets + 1));
+	uint32_t* h_filt = h_nocc + n_sets + 1;                             // per job: cells that passed the candidate-presence filter
+	for (size_t k = 0; k < jobs.size(); k++) h_filt[k] = 0;
 	HIPCHK(c, c->pool_ctrl.reserve(tnsx::CTRL_BYTES * (jobs.size() + 1)));   // per job: cursor, hit_total, 2 x (8 tickets, n_heavy), spread out
 	auto ctrl_slot = [&](size_t k, int slot) { return c->pool_ctrl.as<uint32_t>() + (k * tnsx::CTRL_SLOTS + (size_t)slot) * tnsx::CTRL_STRIDE_U32; };
 	const int query_waves = c->n_cus * 8 * 4;
@@ -776,6 +783,12 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		a.heavy2 = pr.heavy2.as<uint2>();
 		a.pool_capacity = (c->debug_nostore || pr.dry) ? 0 : pr.records.cap / sizeof(int);
 		a.pool_slab = pr.pool_slab;
+		a.shared_empty = jb.pool && jb.i != jb.j ? 1u : 0u;
+		if (a.shared_empty && pr.n_query > 0) {
+			// the query walks the cells that have candidates at all (launch_filter_cells, enqueued by launch_pool)
+			a.occ_i = pr.filtered.as<uint2>();
+			a.n_occ_i = ctrl_slot(k, tnsx::CTRL_NFILTERED);
+		}
 		return a;
 	};
 	tnsx::QueryConfig qc{};
@@ -787,6 +800,18 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		const Job& jb = jobs[k];
 		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
 		HIPCHK(c, hipMemsetAsync(ctrl_slot(k, 0), 0, tnsx::CTRL_BYTES, st));
+		if (jb.i != jb.j && pr.n_query > 0) {
+			// a pair of two different sets: most query cells may have no candidate at all (a fluid searched in its boundary).  Int 0 of
+			// the pool is THE empty record, every offset starts out pointing at it and the pool hands out ints from 1 on: cells without
+			// candidates then cost no allocation, no record and no scattered 8-byte offset store.
+			tnsx::launch_shared_empty_begin(pr.offs_orig.as<uint64_t>(), (size_t)pr.n_query, pr.records.as<int>(),
+			                                reinterpret_cast<unsigned long long*>(ctrl_slot(k, tnsx::CTRL_CURSOR)), st);
+			const PointSet& A = c->sets[jb.i];
+			const size_t max_cells = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pr.n_i, n_cells));
+			HIPCHK(c, pr.filtered.reserve(max_cells * sizeof(uint2)));
+			tnsx::launch_filter_cells(A.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.i, c->sets[jb.j].table.as<uint2>(), g, pr.filtered.as<uint2>(),
+			                          ctrl_slot(k, tnsx::CTRL_NFILTERED), max_cells, st);
+		}
 		const int t0 = tm.mark();
 		if (pr.n_i > 0) {
 			qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_POOL;
@@ -795,6 +820,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		const int t1 = tm.mark();
 		span(ST_FILL, t0, t1);
 		HIPCHK(c, hipMemcpyAsync(h_ctrl + 2 * k, ctrl_slot(k, tnsx::CTRL_CURSOR), 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+		if (jb.i != jb.j && pr.n_query > 0) HIPCHK(c, hipMemcpyAsync(h_filt + k, ctrl_slot(k, tnsx::CTRL_NFILTERED), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 		return TNSX_OK;
 	};
 
@@ -918,6 +944,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		S.n_queries += (uint64_t)pr.n_query;
 		S.n_neighbors += n_neighbors;
 		if (jb.pool) S.n_pool_pairs++;
+		S.n_filtered_cells += h_filt[k];
 	}
 	for (int si = 0; si < n_sets; si++) S.n_occupied_cells += h_nocc[si];
 
@@ -967,6 +994,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		S.ms_total = tm.ms(e_begin, e_end);
 	}
 	c->ran = true;
+	c->cells_valid = true;
 	return TNSX_OK;
 }
 
@@ -1099,13 +1127,27 @@ tnsx_status tnsx_prepare_zsort(tnsx_context* c)
 	int64_t n_total = 0;
 	for (const PointSet& s : c->sets) n_total += s.n;
 	if (n_total > 0) { const tnsx_status r = update_world_box(c, b8); if (r != TNSX_OK) return r; }
-	const int n_pow2 = std::max(c->world_cells_pow2, 1);
+	int n_pow2 = std::max(c->world_cells_pow2, 1);
+	float zs_inv_h = c->cell_size_inv;
+	if (!c->cells_valid && n_total > 0) {
+		// No run() since the sets last changed: the reference cannot reuse its tree and sorts the POINTS on the cell grid refined by
+		// the largest power of two that keeps it below 2^21 cells per axis (_compute_zsort_order_notree, TreeNSearch.cpp:2678-2699).
+		// After a run() it orders whole CELLS and keeps the order inside a cell -- the branch above, and what a stable sort on the
+		// cell's Morton code gives.
+		const float world_size = c->world[3] - c->world[0];
+		float cs = c->cell_size;
+		int refine = 1;
+		while (world_size / (cs / 2.0f) < 2097151.0f && refine < (1 << 20)) { cs /= 2.0f; refine *= 2; }
+		zs_inv_h = 1.0f / cs;
+		n_pow2 = (int)std::min<long long>((long long)n_pow2 * refine, 2097152ll);
+	}
+	c->zsort_inv_h = zs_inv_h;
 	const int bits_per_axis = std::max(1, ceil_log2_u64((uint64_t)n_pow2));
 	const int key_bits = 3 * bits_per_axis;
 
 	tnsx::GridParams mg{};
 	mg.ox = c->world[0]; mg.oy = c->world[1]; mg.oz = c->world[2];
-	mg.inv_h = c->cell_size_inv;
+	mg.inv_h = zs_inv_h;
 	mg.nx = mg.ny = mg.nz = n_pow2;
 	for (PointSet& s : c->sets) {
 		s.zsort_n = s.n;
@@ -1124,6 +1166,7 @@ tnsx_status tnsx_prepare_zsort(tnsx_context* c)
 		HIPCHK(c, hipGetLastError());
 	}
 	HIPCHK(c, hipStreamSynchronize(st));
+	c->cells_valid = false;   // TreeNSearch.cpp:2659-2660: the cells are no longer in index order
 	// xyzi[] of the search structures was reused as scratch: results of the previous run() stay valid (they do not
 	// depend on it), and the next run() rebuilds everything anyway.
 	return TNSX_OK;
@@ -1258,6 +1301,9 @@ tnsx_status tnsx_get_stats(const tnsx_context* c, tnsx_stats* out)
 	if (!c || !out) return TNSX_ERR_INVALID;
 	if (c->multi) { tnsx_multi::stats(c->multi, out); return TNSX_OK; }
 	*out = c->stats;
+	out->zsort_cell_size_inv = c->zsort_inv_h;
+	for (int d = 0; d < 3; d++) { out->world_bottom[d] = c->world[d]; out->world_top[d] = c->world[3 + d]; }   // (prepare_zsort may have moved the box)
+	out->world_cells_pow2 = c->world_cells_pow2;
 	return TNSX_OK;
 }
 

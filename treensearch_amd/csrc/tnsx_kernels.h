@@ -72,6 +72,7 @@ struct QueryArgs {
 	// candidate set j
 	const uint2* table_j; const float4* xyzi_j; const float* r2_j;
 	float r2_fixed;
+	uint32_t shared_empty;  // pool pass: offs_by_orig was pre-set to 0 and records[0] == 0 is THE empty record (cells without candidates write nothing)
 	uint32_t query_limit;   // only query points with original index < query_limit get lists (the rest of set i are candidates only)
 	GridParams g;
 	// count pass: counts[p] = n_neighbours + 1 (record length), by sorted position of set i
@@ -96,7 +97,8 @@ struct QueryArgs {
 static constexpr size_t CTRL_STRIDE_U32 = 1088;
 static constexpr uint32_t CTRL_SUBRANGES = 8;   // ticket counters per XCD and tier (each hands out one contiguous piece of the XCD's cells)
 enum { CTRL_CURSOR = 0 /* u64 cursor, u64 hit_total */, CTRL_TICKETS = 1 /* 8 x CTRL_SUBRANGES slots */, CTRL_NHEAVY = CTRL_TICKETS + 8 * CTRL_SUBRANGES,
-       CTRL_TICKETS2 = CTRL_NHEAVY + 1 /* 8 x CTRL_SUBRANGES slots */, CTRL_NHEAVY2 = CTRL_TICKETS2 + 8 * CTRL_SUBRANGES, CTRL_SLOTS = CTRL_NHEAVY2 + 1 };
+       CTRL_TICKETS2 = CTRL_NHEAVY + 1 /* 8 x CTRL_SUBRANGES slots */, CTRL_NHEAVY2 = CTRL_TICKETS2 + 8 * CTRL_SUBRANGES,
+       CTRL_NFILTERED = CTRL_NHEAVY2 + 1 /* length of the candidate-presence worklist */, CTRL_SLOTS = CTRL_NFILTERED + 1 };
 static constexpr size_t CTRL_BYTES = CTRL_SLOTS * CTRL_STRIDE_U32 * sizeof(uint32_t);
 enum { QUERY_COUNT = 0, QUERY_FILL = 1, QUERY_POOL = 2 };
 struct QueryConfig {
@@ -107,6 +109,10 @@ struct QueryConfig {
 	int mode;        // QUERY_COUNT / QUERY_FILL (exact two-pass layout) / QUERY_POOL (single pass)
 };
 void launch_query(const QueryArgs& a, const QueryConfig& c, int n_compute_units, hipStream_t s);
+// pool pass over two different sets: out / *n_out (zeroed before) = the occupied cells of set i that have at least one candidate of
+// set j in their 27 cells (max_cells: upper bound of *n_occ_i, sizes the launch)
+void launch_filter_cells(const uint2* occ_i, const uint32_t* n_occ_i, const uint2* table_j, GridParams g, uint2* out, uint32_t* n_out, size_t max_cells,
+                         hipStream_t s);
 
 // ---- multi-GPU slab support (tnsx_kernels.hip) ----------------------------------------------------------------------
 // ghost-halo selection of a slab decomposition along x; counts[2] must be zeroed before
@@ -116,6 +122,9 @@ void launch_halo_pack(const float* xyz, const float* radii, const long long* gid
 void launch_x_histogram(const float* xyz, int n, float x0, float inv_dx, int n_bins, unsigned int* hist, hipStream_t s);
 // list entries j of the records of the first n_query points -> id_map[j], in place
 void launch_translate_records(int* records, const uint64_t* offs_by_orig, int n_query, const int* id_map, int n_cus, hipStream_t s);
+
+// ---- pool pass over two different sets: offs[0..n) = 0 (the shared empty record at int 0 of the pool), records[0] = 0, *cursor = 1
+void launch_shared_empty_begin(uint64_t* offs, size_t n, int* records, unsigned long long* cursor, hipStream_t s);
 
 // ---- ascending order inside every record of the first n_query points (tnsx_options.sorted_lists), in place
 void launch_sort_records(int* records, const uint64_t* offs_by_orig, int n_query, int n_cus, hipStream_t s);

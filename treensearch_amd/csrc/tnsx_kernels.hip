@@ -373,6 +373,25 @@ void launch_translate_records(int* records, const uint64_t* offs_by_orig, int n_
 }
 
 // =====================================================================================================
+// start of a pool pass over two DIFFERENT sets: every offset points at the shared empty record (int 0 of the pool, count 0) and
+// the pool hands out ints from 1 on -- one launch instead of three memsets
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_shared_empty_begin(uint64_t* __restrict__ offs, size_t n, int* __restrict__ records, unsigned long long* __restrict__ cursor)
+{
+	if (blockIdx.x == 0 && threadIdx.x == 0) { records[0] = 0; *cursor = 1ull; }
+	ulonglong2* o2 = reinterpret_cast<ulonglong2*>(offs);
+	const size_t n2 = n / 2;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) o2[i] = make_ulonglong2(0ull, 0ull);
+	if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) offs[n - 1] = 0ull;
+}
+void launch_shared_empty_begin(uint64_t* offs, size_t n, int* records, unsigned long long* cursor, hipStream_t s)
+{
+	size_t blocks = (n / 2 + 256 * 8 - 1) / (256 * 8);
+	blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+	hipLaunchKernelGGL(k_shared_empty_begin, dim3((unsigned)blocks), dim3(256), 0, s, offs, n, records, cursor);
+}
+
+// =====================================================================================================
 // ascending neighbour lists (tnsx_options.sorted_lists).  The reference's lists are ascending by construction
 // (TreeNSearch.cpp:2474-2500 emits in cell order over z-sorted input; BruteforceNSearch.cpp:135-137 sorts before comparing); the
 // single-pass query writes them in lane order.  One wave per record, in place:

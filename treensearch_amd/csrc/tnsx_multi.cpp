@@ -65,8 +65,8 @@ struct HostSet {
 };
 
 struct SlabSet {   // one user set as one slab sees it: [owned | ghosts]
-	Pinned xyz, radii;
-	std::vector<int> gid;
+	Pinned xyz, radii, gid_buf;          // pinned: uploaded by DMA every run
+	int* gid = nullptr;                  // global ids of [owned | ghosts] (= gid_buf)
 	int n_owned = 0, n_ghost = 0;
 	int* d_ids = nullptr;
 	size_t d_ids_cap = 0;
@@ -110,6 +110,12 @@ struct State {
 	int zctx_sets = 0;
 	tnsx_stats stats{};
 	int n_slabs_last = 0;
+	// the cuts of the previous run are kept while nothing they depend on has changed (any cuts at least one halo apart are
+	// CORRECT; only the balance drifts with the points) and are re-balanced from a fresh histogram every CUT_PERIOD runs
+	std::vector<float> cuts;
+	float cuts_halo = 0.0f;
+	int64_t cuts_n_total = -1;
+	int cuts_age = 0;
 };
 
 namespace {
@@ -311,7 +317,13 @@ tnsx_status run(State* m, std::string& error)
 	const float halo = r_max * 1.001f;
 	int K = 1;                             // slabs in use
 	std::vector<float> cuts(2, 0.0f);      // cuts[k] <= x < cuts[k+1]; cuts[0] = -inf, cuts[K] = +inf
-	if (n_total > 0) {
+	constexpr int CUT_PERIOD = 16;
+	if (n_total > 0 && m->cuts_n_total == n_total && m->cuts_halo == halo && m->cuts_age < CUT_PERIOD && !m->cuts.empty()) {
+		cuts = m->cuts;
+		K = (int)cuts.size() - 1;
+		m->cuts_age++;
+	}
+	else if (n_total > 0) {
 		double w = (double)halo * 1.001;
 		const double ext = (double)x1 - (double)x0;
 		if (ext / w > 1048576.0) w = ext / 1048576.0;
@@ -353,6 +365,7 @@ tnsx_status run(State* m, std::string& error)
 			cuts[(size_t)k] = x0 + (float)b * wf;
 			prev = b;
 		}
+		m->cuts = cuts; m->cuts_halo = halo; m->cuts_n_total = n_total; m->cuts_age = 0;
 	}
 	else { cuts[0] = -INFINITY; cuts[1] = INFINITY; }
 	m->n_slabs_last = K;
@@ -393,9 +406,10 @@ tnsx_status run(State* m, std::string& error)
 			SlabSet& ss = m->dev[(size_t)k].sets[(size_t)s];
 			ss.n_owned = (int)n_owned[(size_t)k]; ss.n_ghost = (int)n_ghost[(size_t)k];
 			const size_t tot = (size_t)ss.n_owned + ss.n_ghost;
-			ss.gid.resize(tot);
-			if (!ss.xyz.reserve(std::max<size_t>(tot, 1) * 3 * sizeof(float)) || (h.has_radii && !ss.radii.reserve(std::max<size_t>(tot, 1) * sizeof(float))))
+			if (!ss.xyz.reserve(std::max<size_t>(tot, 1) * 3 * sizeof(float)) || !ss.gid_buf.reserve(std::max<size_t>(tot, 1) * sizeof(int)) ||
+			    (h.has_radii && !ss.radii.reserve(std::max<size_t>(tot, 1) * sizeof(float))))
 				MFAIL(TNSX_ERR_HIP, "multi-device mode: pinned host memory exhausted");
+			ss.gid = ss.gid_buf.as<int>();
 		}
 		if (h.n > 0) {
 			parallel_chunks((size_t)h.n, NC, [&](size_t c, size_t b, size_t e) {
@@ -449,7 +463,7 @@ tnsx_status run(State* m, std::string& error)
 					if (hipMalloc((void**)&ss.d_ids, want * sizeof(int)) != hipSuccess) { d.status = TNSX_ERR_HIP; d.error = "hipMalloc of the id array failed"; return; }
 					ss.d_ids_cap = want;
 				}
-				if (hipMemcpy(ss.d_ids, ss.gid.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { d.status = TNSX_ERR_HIP; d.error = "upload of the id array failed"; return; }
+				if (hipMemcpy(ss.d_ids, ss.gid, (size_t)n * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { d.status = TNSX_ERR_HIP; d.error = "upload of the id array failed"; return; }
 			}
 			(void)tnsx_set_point_ids(c, s, n > 0 ? ss.d_ids : nullptr);
 		}
@@ -508,7 +522,8 @@ tnsx_status run(State* m, std::string& error)
 			const uint64_t* lo = d.local_offsets.as<uint64_t>();
 			uint64_t* go = po.offsets.as<uint64_t>();
 			const uint64_t b0 = base[q][(size_t)k];
-			for (int p = 0; p < pl.n_points; p++) go[(size_t)ss.gid[(size_t)p]] = b0 + lo[p];
+			const int* gid = ss.gid;
+			parallel_chunks((size_t)pl.n_points, 8, [&](size_t, size_t b, size_t e) { for (size_t p = b; p < e; p++) go[(size_t)gid[p]] = b0 + lo[p]; });
 		}
 	};
 	{

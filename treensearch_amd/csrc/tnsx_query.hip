@@ -492,6 +492,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 				if (RR.total > 0) {
 					process_batch_nc<ARITH, VARIABLE, SYM, SELF, MODE, true>(a, RR, 0u, RR.total, lane, qv, qr2, qb, nq, my_off, run_cnt, ps, wave_hits);
 				}
+				else if (MODE == MODE_POOL && a.shared_empty != 0u) { my_off = ~0ull; }   // (offsets pre-set to the shared empty record: nothing to write)
 				else if (MODE == MODE_POOL) {
 					// no candidates at all: every query still gets its (empty) record
 					for (uint32_t t = 0; t < nq; t++) {
@@ -1013,6 +1014,10 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 			if (++rej_n == (uint32_t)WAVE) { flush_rejects(); rej_n = 0; }
 		}
 		else if (!FAT && RR.total > (uint32_t)TNSX_CULL_FROM) { /* done by the culled path above */ }
+		else if (RR.total == 0u && a.shared_empty != 0u) {
+			// no candidate at all, and the offsets of this pair were pre-set to the shared empty record: nothing to do.  (The fluid of an
+			// SPH scene searched in its boundary: most fluid cells are nowhere near it -- C3's 0->1 pair dropped from 1.0 to <..> ms.)
+		}
 		else if (RR.total == 0u) {
 			// no candidate at all (set_j is another, sparser or empty set): nq empty records, one int each
 			const uint32_t qs0 = cur_q.x + ((uint32_t)lane < nq ? (uint32_t)lane : 0u);
@@ -1033,6 +1038,58 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 	}
 	if (rej_n) flush_rejects();
 	if (lane == 0 && wave_hits) atomicAdd(a.hit_total, (unsigned long long)wave_hits);
+}
+
+// =====================================================================================================
+// Candidate-presence filter of a pool pass over two DIFFERENT sets.  A fluid searched in its boundary: most fluid cells are nowhere
+// near a boundary point, their lists are the shared empty record (see launch_shared_empty_begin), and walking them through the
+// query pipeline -- a wave, a ticket, 27 lookups per cell -- is all the pass would do there (C3: 0.85 ms for the 0->1 pair).  One
+// THREAD per occupied cell of the query set sums the 27 table entries of the candidate set and the cells that have any candidate
+// are compacted into the worklist the query kernels then walk instead of the whole occupied-cell list.
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_filter_cells(const uint2* __restrict__ occ, const uint32_t* __restrict__ n_occ_p, const uint2* __restrict__ table_j, GridParams g,
+                                                     uint2* __restrict__ out, uint32_t* __restrict__ n_out)
+{
+	__shared__ uint32_t wbase[256 / WAVE];
+	const uint32_t n_occ = *n_occ_p;
+	const int nx = g.nx, ny = g.ny, nz = g.nz;
+	for (uint32_t base = blockIdx.x * 256u; base < n_occ; base += gridDim.x * 256u) {
+		const uint32_t i = base + threadIdx.x;
+		uint2 oc = make_uint2(0u, 0u);
+		bool any = false;
+		if (i < n_occ) {
+			oc = occ[i];
+			const int cx = (int)(oc.y % (uint32_t)nx), cy = (int)((oc.y / (uint32_t)nx) % (uint32_t)ny), cz = (int)(oc.y / ((uint32_t)nx * (uint32_t)ny));
+			uint32_t total = 0;
+			for (int dz = -1; dz <= 1; dz++) {
+				const int z = cz + dz;
+				if (z < 0 || z >= nz) continue;
+				for (int dy = -1; dy <= 1; dy++) {
+					const int y = cy + dy;
+					if (y < 0 || y >= ny) continue;
+					const size_t row = ((size_t)z * ny + y) * nx;
+					#pragma unroll
+					for (int dx = -1; dx <= 1; dx++) {
+						const int x = cx + dx;
+						if (x >= 0 && x < nx) { const uint2 t = table_j[row + x]; total += t.y - t.x; }
+					}
+				}
+			}
+			any = total != 0u;
+		}
+		const uint64_t m = __builtin_amdgcn_ballot_w64(any);
+		uint32_t wb = 0;
+		if (lane_id() == 0 && m) wb = atomicAdd(n_out, (uint32_t)__popcll(m));
+		wb = readfirstlane_u32(wb);
+		if (any) out[wb + mbcnt64(m)] = oc;
+	}
+	(void)wbase;
+}
+void launch_filter_cells(const uint2* occ_i, const uint32_t* n_occ_i, const uint2* table_j, GridParams g, uint2* out, uint32_t* n_out, size_t max_cells, hipStream_t s)
+{
+	size_t blocks = (max_cells + 255) / 256;
+	blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+	hipLaunchKernelGGL(k_filter_cells, dim3((unsigned)blocks), dim3(256), 0, s, occ_i, n_occ_i, table_j, g, out, n_out);
 }
 
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int MODE>
