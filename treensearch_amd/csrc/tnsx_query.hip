@@ -57,6 +57,15 @@ __device__ __forceinline__ v2f dist_sq2(float qx, float qy, float qz, v2f cx, v2
 	}
 }
 
+// max of a wave-uniform and a per-lane value as ONE v_max_f32 (fmaxf() comes with a canonicalising v_max x, x per operand in IEEE
+// mode; neither operand is ever a NaN here: squared radii, or -1 in padding lanes)
+__device__ __forceinline__ float max_raw(float uniform, float v)
+{
+	float r;
+	asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(uniform), "v"(v));
+	return r;
+}
+
 // Wave-uniform description of the 9 merged candidate runs of one cell.  Deliberately NINE NAMED SCALARS per field and
 // not arrays: with arrays the compiler turns the select chain below into a table lookup and parks the table in LDS.
 struct Runs {
@@ -372,8 +381,9 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 			for (int u = 0; u < 2; u++) {
 				const int k = 2 * h + u;
 				if (k < NC) {
-					m[k] = __builtin_amdgcn_ballot_w64(d2[u] <= r2);
-					if (SYM) m[k] |= __builtin_amdgcn_ballot_w64(d2[u] <= cr2[k]);
+					// symmetric search: d2 <= r_i^2 || d2 <= r_j^2 is d2 <= max(r_i^2, r_j^2) -- one v_max instead of a second compare
+					// and a scalar or (padding lanes carry r_j^2 = -1 and d2 = +inf)
+					m[k] = __builtin_amdgcn_ballot_w64(d2[u] <= (SYM ? max_raw(r2, cr2[k]) : r2));
 					// self exclusion by index: one VALU compare + one s_and per chunk.  (Clearing the one self bit with
 					// scalar ops costs 4-5 SALU per chunk, and the CU's single scalar unit is as scarce as its 4 SIMDs.)
 					if (SELF == 1) m[k] &= __builtin_amdgcn_ballot_w64(cid[k] != qi);
@@ -615,8 +625,7 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 			for (int u = 0; u < 2; u++) {
 				const int k = 2 * h + u;
 				if (k < NC) {
-					m[k] = __builtin_amdgcn_ballot_w64(d2[u] <= r2q);
-					if (SYM) m[k] |= __builtin_amdgcn_ballot_w64(d2[u] <= cr2[k]);
+					m[k] = __builtin_amdgcn_ballot_w64(d2[u] <= (SYM ? max_raw(r2q, cr2[k]) : r2q));   // (SYM: see process_batch)
 				}
 			}
 		}
@@ -1016,7 +1025,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 		else if (!FAT && RR.total > (uint32_t)TNSX_CULL_FROM) { /* done by the culled path above */ }
 		else if (RR.total == 0u && a.shared_empty != 0u) {
 			// no candidate at all, and the offsets of this pair were pre-set to the shared empty record: nothing to do.  (The fluid of an
-			// SPH scene searched in its boundary: most fluid cells are nowhere near it -- C3's 0->1 pair dropped from 1.0 to <..> ms.)
+			// SPH scene searched in its boundary: most fluid cells are nowhere near it.)
 		}
 		else if (RR.total == 0u) {
 			// no candidate at all (set_j is another, sparser or empty set): nq empty records, one int each
