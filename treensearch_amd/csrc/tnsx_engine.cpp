@@ -157,7 +157,7 @@ struct tnsx_context {
 	bool debug_nostore = std::getenv("TNSX_DEBUG_NOSTORE") != nullptr;   // timing experiments only: pool pass without its stores
 
 	// scratch
-	DevBuf bounds_partials, bounds_out, sort_temp, scan_temp, n_occ, permute_tmp, pool_ctrl, run_words;
+	DevBuf bounds_partials, bounds_out, sort_temp, scan_temp, n_occ, permute_tmp, pool_ctrl, run_words, cell_map;
 	PinnedBuf h_small;
 	tnsx_stats stats{};
 	std::vector<hipEvent_t> events;
@@ -785,7 +785,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		a.pool_slab = pr.pool_slab;
 		a.shared_empty = jb.pool && jb.i != jb.j ? 1u : 0u;
 		if (a.shared_empty && pr.n_query > 0) {
-			// the query walks the cells that have candidates at all (launch_filter_cells, enqueued by launch_pool)
+			// the query walks the cells that have candidates at all (launch_mark_cells + launch_filter_marked, enqueued by launch_pool)
 			a.occ_i = pr.filtered.as<uint2>();
 			a.n_occ_i = ctrl_slot(k, tnsx::CTRL_NFILTERED);
 		}
@@ -809,8 +809,17 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			const PointSet& A = c->sets[jb.i];
 			const size_t max_cells = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pr.n_i, n_cells));
 			HIPCHK(c, pr.filtered.reserve(max_cells * sizeof(uint2)));
-			tnsx::launch_filter_cells(A.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.i, c->sets[jb.j].table.as<uint2>(), g, pr.filtered.as<uint2>(),
-			                          ctrl_slot(k, tnsx::CTRL_NFILTERED), max_cells, st);
+			{
+				const PointSet& B = c->sets[jb.j];
+				const void* old_map = c->cell_map.p;
+				HIPCHK(c, c->cell_map.reserve(n_cells));
+				if (c->cell_map.p != old_map) HIPCHK(c, hipMemsetAsync(c->cell_map.p, 0, c->cell_map.cap, st));   // (all zero between uses)
+				const size_t max_cells_j = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(B.n, 1), n_cells));
+				unsigned char* map = c->cell_map.as<unsigned char>();
+				tnsx::launch_mark_cells(B.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.j, g, map, 1, max_cells_j, st);
+				tnsx::launch_filter_marked(A.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.i, map, pr.filtered.as<uint2>(), ctrl_slot(k, tnsx::CTRL_NFILTERED), max_cells, st);
+				tnsx::launch_mark_cells(B.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.j, g, map, 0, max_cells_j, st);
+			}
 		}
 		const int t0 = tm.mark();
 		if (pr.n_i > 0) {

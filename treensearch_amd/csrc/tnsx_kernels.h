@@ -109,10 +109,11 @@ struct QueryConfig {
 	int mode;        // QUERY_COUNT / QUERY_FILL (exact two-pass layout) / QUERY_POOL (single pass)
 };
 void launch_query(const QueryArgs& a, const QueryConfig& c, int n_compute_units, hipStream_t s);
-// pool pass over two different sets: out / *n_out (zeroed before) = the occupied cells of set i that have at least one candidate of
-// set j in their 27 cells (max_cells: upper bound of *n_occ_i, sizes the launch)
-void launch_filter_cells(const uint2* occ_i, const uint32_t* n_occ_i, const uint2* table_j, GridParams g, uint2* out, uint32_t* n_out, size_t max_cells,
-                         hipStream_t s);
+// pool pass over two different sets, candidate-presence filter: launch_mark_cells writes `value` into the byte of every grid cell
+// that has an occupied cell of set j among its 27 (value 1 before the filter, 0 afterwards: the map is all zero between uses);
+// launch_filter_marked compacts the occupied cells of set i whose byte is set into out / *n_out (zeroed before)
+void launch_mark_cells(const uint2* occ_j, const uint32_t* n_occ_j, GridParams g, unsigned char* map, unsigned char value, size_t max_cells_j, hipStream_t s);
+void launch_filter_marked(const uint2* occ_i, const uint32_t* n_occ_i, const unsigned char* map, uint2* out, uint32_t* n_out, size_t max_cells, hipStream_t s);
 
 // ---- multi-GPU slab support (tnsx_kernels.hip) ----------------------------------------------------------------------
 // ghost-halo selection of a slab decomposition along x; counts[2] must be zeroed before

@@ -1052,53 +1052,58 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 // =====================================================================================================
 // Candidate-presence filter of a pool pass over two DIFFERENT sets.  A fluid searched in its boundary: most fluid cells are nowhere
 // near a boundary point, their lists are the shared empty record (see launch_shared_empty_begin), and walking them through the
-// query pipeline -- a wave, a ticket, 27 lookups per cell -- is all the pass would do there (C3: 0.85 ms for the 0->1 pair).  One
-// THREAD per occupied cell of the query set sums the 27 table entries of the candidate set and the cells that have any candidate
-// are compacted into the worklist the query kernels then walk instead of the whole occupied-cell list.
+// query pipeline -- a wave, a ticket, 27 lookups per cell -- is all the pass would do there (C3: 0.85 ms for the 0->1 pair).  The
+// query cells that have any candidate are compacted into the worklist the query kernels then walk instead of the whole
+// occupied-cell list.
 // =====================================================================================================
-__global__ void __launch_bounds__(256) k_filter_cells(const uint2* __restrict__ occ, const uint32_t* __restrict__ n_occ_p, const uint2* __restrict__ table_j, GridParams g,
-                                                     uint2* __restrict__ out, uint32_t* __restrict__ n_out)
+// Two steps, both cheap because they start from the SPARSER side: (1) every occupied cell of the candidate set marks its 27
+// neighbour cells in a byte map of the grid (k_mark_cells; the map is all zero between runs: the same kernel un-marks after the
+// pass); (2) every occupied query cell looks at ONE byte and the marked ones are compacted (k_filter_marked).  (A first version let
+// every query cell sum its 27 table entries itself: 90 us at C3 for 15 M scattered 8-byte loads.)
+__global__ void __launch_bounds__(256) k_mark_cells(const uint2* __restrict__ occ_j, const uint32_t* __restrict__ n_occ_p, GridParams g, unsigned char* __restrict__ map,
+                                                   unsigned char value)
 {
-	__shared__ uint32_t wbase[256 / WAVE];
 	const uint32_t n_occ = *n_occ_p;
 	const int nx = g.nx, ny = g.ny, nz = g.nz;
+	// 32 threads per cell: 27 of them write one neighbour each (x fastest: three consecutive bytes per row)
+	const uint32_t per_block = 256u / 32u;
+	const uint32_t sub = threadIdx.x & 31u;
+	for (uint32_t c = blockIdx.x * per_block + (threadIdx.x >> 5); c < n_occ; c += gridDim.x * per_block) {
+		if (sub >= 27u) continue;
+		const uint32_t key = occ_j[c].y;
+		const int x = (int)(key % (uint32_t)nx) + (int)(sub % 3u) - 1;
+		const int y = (int)((key / (uint32_t)nx) % (uint32_t)ny) + (int)((sub / 3u) % 3u) - 1;
+		const int z = (int)(key / ((uint32_t)nx * (uint32_t)ny)) + (int)(sub / 9u) - 1;
+		if (x >= 0 && x < nx && y >= 0 && y < ny && z >= 0 && z < nz) map[((size_t)z * ny + y) * nx + x] = value;
+	}
+}
+__global__ void __launch_bounds__(256) k_filter_marked(const uint2* __restrict__ occ, const uint32_t* __restrict__ n_occ_p, const unsigned char* __restrict__ map,
+                                                      uint2* __restrict__ out, uint32_t* __restrict__ n_out)
+{
+	const uint32_t n_occ = *n_occ_p;
 	for (uint32_t base = blockIdx.x * 256u; base < n_occ; base += gridDim.x * 256u) {
 		const uint32_t i = base + threadIdx.x;
 		uint2 oc = make_uint2(0u, 0u);
 		bool any = false;
-		if (i < n_occ) {
-			oc = occ[i];
-			const int cx = (int)(oc.y % (uint32_t)nx), cy = (int)((oc.y / (uint32_t)nx) % (uint32_t)ny), cz = (int)(oc.y / ((uint32_t)nx * (uint32_t)ny));
-			uint32_t total = 0;
-			for (int dz = -1; dz <= 1; dz++) {
-				const int z = cz + dz;
-				if (z < 0 || z >= nz) continue;
-				for (int dy = -1; dy <= 1; dy++) {
-					const int y = cy + dy;
-					if (y < 0 || y >= ny) continue;
-					const size_t row = ((size_t)z * ny + y) * nx;
-					#pragma unroll
-					for (int dx = -1; dx <= 1; dx++) {
-						const int x = cx + dx;
-						if (x >= 0 && x < nx) { const uint2 t = table_j[row + x]; total += t.y - t.x; }
-					}
-				}
-			}
-			any = total != 0u;
-		}
+		if (i < n_occ) { oc = occ[i]; any = map[oc.y] != 0; }
 		const uint64_t m = __builtin_amdgcn_ballot_w64(any);
 		uint32_t wb = 0;
 		if (lane_id() == 0 && m) wb = atomicAdd(n_out, (uint32_t)__popcll(m));
 		wb = readfirstlane_u32(wb);
 		if (any) out[wb + mbcnt64(m)] = oc;
 	}
-	(void)wbase;
 }
-void launch_filter_cells(const uint2* occ_i, const uint32_t* n_occ_i, const uint2* table_j, GridParams g, uint2* out, uint32_t* n_out, size_t max_cells, hipStream_t s)
+void launch_mark_cells(const uint2* occ_j, const uint32_t* n_occ_j, GridParams g, unsigned char* map, unsigned char value, size_t max_cells_j, hipStream_t s)
+{
+	size_t blocks = (max_cells_j + 7) / 8;
+	blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
+	hipLaunchKernelGGL(k_mark_cells, dim3((unsigned)blocks), dim3(256), 0, s, occ_j, n_occ_j, g, map, value);
+}
+void launch_filter_marked(const uint2* occ_i, const uint32_t* n_occ_i, const unsigned char* map, uint2* out, uint32_t* n_out, size_t max_cells, hipStream_t s)
 {
 	size_t blocks = (max_cells + 255) / 256;
 	blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-	hipLaunchKernelGGL(k_filter_cells, dim3((unsigned)blocks), dim3(256), 0, s, occ_i, n_occ_i, table_j, g, out, n_out);
+	hipLaunchKernelGGL(k_filter_marked, dim3((unsigned)blocks), dim3(256), 0, s, occ_i, n_occ_i, map, out, n_out);
 }
 
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int MODE>
