@@ -3,9 +3,10 @@
  * neighbour search path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
  * may load this library; the product path (treensearch_amd/, include/) never does.
  *
- * Parity pinning: this restatement is checked in tests/test_oracle_vs_reference.py against the
- * real reference built from /root/reference (oracle/_ref/libtns_ref*.so, see oracle/Makefile) and
- * against the committed golden fixtures in tests/golden/ that were generated from that build.
+ * Parity pinning: tests/golden/make_golden.py runs the REAL reference built from /root/reference
+ * (oracle/_ref/libtns_ref*.so, see oracle/Makefile) on every seeded case, asserts that this
+ * restatement agrees with it list by list, and writes the fixtures in tests/golden/;
+ * tests/test_oracle_golden.py checks the restatement against those fixtures wherever the tests run.
  *
  * What is restated (reference file:line, relative to /root/reference):
  *   - the neighbour predicate of the AVX2 path and of tests/BruteforceNSearch:
