@@ -124,6 +124,32 @@ def test_pool_overflow_is_detected_and_repaired(oracle):
     P.assert_matches_golden({(0, 0): ns.neighbor_csr(0, 0)}, load_golden(case.name), 0, oracle, "after overflow")
 
 
+def test_pool_regions_follow_a_moving_cluster():
+    """The pool is cut into one region per XCD, each sized by what that XCD's share of the cell list produced in the previous run
+    (plus a common region that takes what does not fit).  A dense cluster that jumps from one end of the domain to the other
+    shifts the load from the first regions to the last ones: the lists must stay exact (common region, or a repeated pass)."""
+    import treensearch_amd as T
+    rng = np.random.default_rng(77)
+    n_bg, n_cl = 150_000, 150_000
+    bg = rng.random((n_bg, 3), dtype=np.float32) * np.array([8.0, 1.0, 1.0], np.float32)
+    blob = (rng.random((n_cl, 3), dtype=np.float32) * 0.35).astype(np.float32)
+    radius = 0.03
+    ns = T.TreeNSearch(); ns.set_search_radius(radius)
+    ref = T.TreeNSearch(exact_layout=True); ref.set_search_radius(radius)
+    pts = np.ascontiguousarray(np.concatenate([bg, blob]))
+    ns.add_point_set(pts); ns.set_active_search(0, 0, True)
+    ref.add_point_set(pts); ref.set_active_search(0, 0, True)
+    retries = 0
+    for step, x0 in enumerate([0.0, 0.0, 7.6, 7.6, 3.9, 0.1]):
+        pts[n_bg:] = blob + np.array([x0, 0.3, 0.3], np.float32)
+        ns.run(); ref.run()
+        st = ns.get_stats()
+        retries += st["pool_retries"]
+        P.assert_same_csr(ns.neighbor_csr(0, 0), ref.neighbor_csr(0, 0), f"moving cluster, step {step} (x0 = {x0})")
+        assert st["n_neighbors"] == ref.get_stats()["n_neighbors"]
+    assert retries <= 3     # (a repeated pass is allowed when the cluster jumps, never in the steps where it stays)
+
+
 def test_exact_layout_option_is_sorted_and_gapless(oracle):
     case = CS.by_name("uniform_fixed_100000")
     ns = P.make_engine(case, 0, exact_layout=True)

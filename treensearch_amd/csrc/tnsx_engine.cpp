@@ -111,10 +111,15 @@ struct PairResult {
 	bool valid = false;
 	int n_i = 0;
 	int n_query = 0;             // points of set i that have a list: min(n_i, tnsx_set_query_count)
-	uint64_t n_records = 0;      // ints of `records` in use (pool mode: including slab holes)
+	uint64_t n_records = 0;      // extent of `records` in ints (pool mode: including slab holes and the unused ends of the regions)
 	uint64_t n_neighbors = 0;
-	uint64_t need_hint = 0;      // neighbours + points of the previous run: sizes the pool of the next one
+	uint64_t need_hint = 0;      // 1 + ints of records the previous run produced: sizes the pool of the next one (0: nothing known, dry pass first)
 	uint32_t pool_slab = 16384;
+	// pool mode: `records` is cut into one region per XCD + the common overflow region (tnsx_query.hip, PoolState)
+	static constexpr int NR = tnsx::POOL_REGIONS + 1;
+	uint64_t region_payload[NR] = { 0 };   // ints of records the waves of XCD r produced in the previous run
+	uint64_t region_base[NR] = { 0 }, region_cap[NR] = { 0 }, region_used[NR] = { 0 };
+	bool shared_empty = false;   // int 0 of `records` is the empty record every list without a candidate points at
 	bool dry = false;            // this pass only counts (first run of a pair: nothing is known about its size yet)
 	DevBuf counts, offs_sorted, offs_orig, records, heavy, heavy2, filtered;
 	PinnedBuf h_offs, h_records;
@@ -564,6 +569,18 @@ enum Stage { ST_UPLOAD, ST_BOUNDS, ST_KEYS, ST_SORT, ST_GATHER, ST_CELLS, ST_COU
 // read back with the record totals at the one synchronisation every run has anyway; *redo tells the caller that one of them
 // was wrong -- the run is then repeated without speculation.  This is the reference's own temporal reuse (the world box
 // persists while it contains the points, TreeNSearch.cpp:474-482; unchanged sets, :77-79) moved off the critical path.
+// the used parts of a pair's records (the shared empty record + what every pool region handed out) -> dst, same layout
+static tnsx_status copy_records(tnsx_context* c, const PairResult& pr, int* dst, hipMemcpyKind kind, hipStream_t st)
+{
+	const int* src = pr.records.as<int>();
+	if (pr.shared_empty) HIPCHK(c, hipMemcpyAsync(dst, src, sizeof(int), kind, st));
+	for (int r = 0; r < PairResult::NR; r++) {
+		if (pr.region_used[r] == 0) continue;
+		HIPCHK(c, hipMemcpyAsync(dst + pr.region_base[r], src + pr.region_base[r], pr.region_used[r] * sizeof(int), kind, st));
+	}
+	return TNSX_OK;
+}
+
 static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 {
 	*redo = false;
@@ -744,12 +761,16 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	// ---- per active pair: the query.
 	//      pool mode (default): ONE pass, records bump-allocated from a device cursor (first run of a pair: a dry pass first);
 	//      exact mode (opt.exact_layout): count -> scan -> fill, gap-free CSR in sorted order.
+	#ifndef TNSX_SLAB_WAVE_DIV
+#define TNSX_SLAB_WAVE_DIV 8
+#endif
 	struct Job { int i, j; bool pool; };
 	std::vector<Job> jobs;
 	for (int i = 0; i < n_sets; i++) for (int j = 0; j < n_sets; j++) if (c->active[i][j]) jobs.push_back({ i, j, false });
-	HIPCHK(c, c->h_small.reserve(sizeof(uint64_t) * (2 * jobs.size() + 2 + WB * ((size_t)n_sets + 1)) + sizeof(uint32_t) * (size_t)(n_sets + 1 + jobs.size() + 1) + 64));
-	uint64_t* h_ctrl = c->h_small.as<uint64_t>();                       // per job: {cursor | total, hit_total}
-	uint64_t* h_words = h_ctrl + 2 * jobs.size() + 2;                   // guard flag, partial checksums
+	constexpr size_t HC = (size_t)PairResult::NR * tnsx::POOL_CTRL_WORDS;   // per job: cursor / neighbours / unused ints of every pool region (exact layout: word 0 = total)
+	HIPCHK(c, c->h_small.reserve(sizeof(uint64_t) * (HC * jobs.size() + 2 + WB * ((size_t)n_sets + 1)) + sizeof(uint32_t) * (size_t)(n_sets + 1 + jobs.size() + 1) + 64));
+	uint64_t* h_ctrl = c->h_small.as<uint64_t>();
+	uint64_t* h_words = h_ctrl + HC * jobs.size() + 2;                  // guard flag, partial checksums
 	uint32_t* h_nocc = reinterpret_cast<uint32_t*>(h_words + WB * ((size_t)n_sets + 1));
 	uint32_t* h_filt = h_nocc + n_sets + 1;                             // per job: cells that passed the candidate-presence filter
 	for (size_t k = 0; k < jobs.size(); k++) h_filt[k] = 0;
@@ -774,14 +795,13 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		a.records = pr.records.as<int>();
 		a.offs_by_orig = pr.offs_orig.as<uint64_t>();
 		a.pool_cursor = reinterpret_cast<unsigned long long*>(ctrl_slot(k, tnsx::CTRL_CURSOR));
-		a.hit_total = a.pool_cursor + 1;
+		a.pool_regions = reinterpret_cast<const unsigned long long*>(ctrl_slot(k, tnsx::CTRL_REGIONS));
 		a.tickets = ctrl_slot(k, tnsx::CTRL_TICKETS);
 		a.n_heavy = ctrl_slot(k, tnsx::CTRL_NHEAVY);
 		a.tickets2 = ctrl_slot(k, tnsx::CTRL_TICKETS2);
 		a.n_heavy2 = ctrl_slot(k, tnsx::CTRL_NHEAVY2);
 		a.heavy = pr.heavy.as<uint2>();
 		a.heavy2 = pr.heavy2.as<uint2>();
-		a.pool_capacity = (c->debug_nostore || pr.dry) ? 0 : pr.records.cap / sizeof(int);
 		a.pool_slab = pr.pool_slab;
 		a.shared_empty = jb.pool && jb.i != jb.j ? 1u : 0u;
 		if (a.shared_empty && pr.n_query > 0) {
@@ -800,12 +820,18 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		const Job& jb = jobs[k];
 		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
 		HIPCHK(c, hipMemsetAsync(ctrl_slot(k, 0), 0, tnsx::CTRL_BYTES, st));
-		if (jb.i != jb.j && pr.n_query > 0) {
-			// a pair of two different sets: most query cells may have no candidate at all (a fluid searched in its boundary).  Int 0 of
-			// the pool is THE empty record, every offset starts out pointing at it and the pool hands out ints from 1 on: cells without
-			// candidates then cost no allocation, no record and no scattered 8-byte offset store.
-			tnsx::launch_shared_empty_begin(pr.offs_orig.as<uint64_t>(), (size_t)pr.n_query, pr.records.as<int>(),
-			                                reinterpret_cast<unsigned long long*>(ctrl_slot(k, tnsx::CTRL_CURSOR)), st);
+		{
+			// the region table of this pass (all capacities 0: nothing is written, everything is counted).
+			// A pair of two different sets: most query cells may have no candidate at all (a fluid searched in its boundary).  Int 0 of
+			// the pool is THE empty record and every offset starts out pointing at it: cells without candidates then cost no
+			// allocation, no record and no scattered 8-byte offset store.
+			unsigned long long regions[2 * PairResult::NR];
+			const bool count_only = c->debug_nostore || pr.dry;
+			for (int r = 0; r < PairResult::NR; r++) { regions[2 * r] = pr.region_base[r]; regions[2 * r + 1] = count_only ? 0ull : pr.region_cap[r]; }
+			tnsx::launch_pool_begin(regions, reinterpret_cast<unsigned long long*>(ctrl_slot(k, tnsx::CTRL_REGIONS)), pr.offs_orig.as<uint64_t>(),
+			                        pr.shared_empty ? (size_t)pr.n_query : 0, pr.records.as<int>(), st);
+		}
+		if (pr.shared_empty) {
 			const PointSet& A = c->sets[jb.i];
 			const size_t max_cells = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pr.n_i, n_cells));
 			HIPCHK(c, pr.filtered.reserve(max_cells * sizeof(uint2)));
@@ -828,19 +854,38 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		}
 		const int t1 = tm.mark();
 		span(ST_FILL, t0, t1);
-		HIPCHK(c, hipMemcpyAsync(h_ctrl + 2 * k, ctrl_slot(k, tnsx::CTRL_CURSOR), 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-		if (jb.i != jb.j && pr.n_query > 0) HIPCHK(c, hipMemcpyAsync(h_filt + k, ctrl_slot(k, tnsx::CTRL_NFILTERED), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+		HIPCHK(c, hipMemcpy2DAsync(h_ctrl + HC * k, tnsx::POOL_CTRL_WORDS * sizeof(uint64_t), ctrl_slot(k, tnsx::CTRL_CURSOR), tnsx::CTRL_STRIDE_U32 * sizeof(uint32_t),
+		                           tnsx::POOL_CTRL_WORDS * sizeof(uint64_t), PairResult::NR, hipMemcpyDeviceToHost, st));
+		if (pr.shared_empty) HIPCHK(c, hipMemcpyAsync(h_filt + k, ctrl_slot(k, tnsx::CTRL_NFILTERED), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 		return TNSX_OK;
 	};
 
-	// slab size and record storage of a pool pass that is expected to need `need` ints (0: dry pass)
-	auto size_pool = [&](PairResult& pr, uint64_t need) -> tnsx_status {
-		const uint64_t expect = need + need / 8 + 1024;
-		uint64_t slab = expect / ((uint64_t)query_waves * 8);
-		slab = std::min<uint64_t>(16384, std::max<uint64_t>(256, slab));
-		if (need == 0) slab = 16384;   // dry pass: nothing is written, big slabs keep the cursor atomics rare (256-int slabs: 32 ms at 10 M points)
+	// slab size, regions and record storage of a pool pass whose regions are expected to receive payload[r] ints of records (nullptr: dry
+	// pass).  generous: the common region can take EVERYTHING (the redo of a pass that overflowed must not overflow again).
+	auto size_pool = [&](PairResult& pr, const uint64_t* payload, bool generous) -> tnsx_status {
+		for (int r = 0; r < PairResult::NR; r++) { pr.region_base[r] = 0; pr.region_cap[r] = 0; pr.region_used[r] = 0; }
+		if (!payload) {
+			pr.pool_slab = 16384;   // nothing is written, big slabs keep the cursor atomics rare (256-int slabs: 32 ms at 10 M points)
+			HIPCHK(c, pr.records.reserve(1024 * sizeof(int)));
+			return TNSX_OK;
+		}
+		uint64_t total = 0;
+		for (int r = 0; r < PairResult::NR; r++) total += payload[r];
+		const uint64_t expect = total + total / 8 + 1024;
+		// a wave's last slab stays half empty on average: slabs of 1/8 of a wave's share keep the holes at ~6 % of the pool
+		const uint64_t slab = std::min<uint64_t>(16384, std::max<uint64_t>(256, expect / ((uint64_t)query_waves * TNSX_SLAB_WAVE_DIV)));
 		pr.pool_slab = (uint32_t)slab;
-		HIPCHK(c, pr.records.reserve(need == 0 ? 1024 : (expect + (uint64_t)query_waves * slab * 2) * sizeof(int)));
+		const uint64_t waves_x = (uint64_t)query_waves / tnsx::POOL_REGIONS;
+		uint64_t first = pr.shared_empty ? 64 : 0;
+		for (int r = 0; r < PairResult::NR; r++) {
+			// a region of the fast tier: what its XCD produced last time + 6 % + a slab per wave;
+			// the common region: what the heavy tiers produced + 6 % + a slab per wave of a launch + 6 % of everything (fast-tier overflow)
+			uint64_t cap = payload[r] + payload[r] / 16 + 1024 + (r < tnsx::POOL_REGIONS ? waves_x * slab : expect / 16 + (uint64_t)query_waves * slab);
+			if (generous && r == tnsx::POOL_OVERFLOW) cap += expect;
+			pr.region_base[r] = first; pr.region_cap[r] = cap;
+			first = (first + cap + 63) & ~(uint64_t)63;
+		}
+		HIPCHK(c, pr.records.reserve(first * sizeof(int)));
 		return TNSX_OK;
 	};
 	for (size_t k = 0; k < jobs.size(); k++) {
@@ -856,7 +901,8 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			// makes a DRY pass first (same kernels, capacity 0: everything is counted, nothing is written), which the overflow
 			// handling below turns into a real pass of the right size.
 			pr.dry = pr.need_hint == 0;
-			{ const tnsx_status r = size_pool(pr, pr.need_hint); if (r != TNSX_OK) return r; }
+			pr.shared_empty = jb.i != jb.j && pr.n_query > 0;
+			{ const tnsx_status r = size_pool(pr, pr.dry ? nullptr : pr.region_payload, false); if (r != TNSX_OK) return r; }
 			// worklists of the cells the fast / fat kernels pass on (at most one entry per occupied cell)
 			const size_t max_cells = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_i, n_cells));
 			HIPCHK(c, pr.heavy.reserve(max_cells * sizeof(uint2)));
@@ -875,7 +921,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			}
 			const int t1 = tm.mark();
 			tnsx::exclusive_scan_u32_to_u64(pr.counts.as<uint32_t>(), pr.offs_sorted.as<uint64_t>(), (size_t)n_i, c->scan_temp.p, st);
-			HIPCHK(c, hipMemcpyAsync(h_ctrl + 2 * k, pr.offs_sorted.as<uint64_t>() + n_i, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+			HIPCHK(c, hipMemcpyAsync(h_ctrl + HC * k, pr.offs_sorted.as<uint64_t>() + n_i, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
 			const int t2 = tm.mark();
 			span(ST_COUNT, t0, t1); span(ST_SCAN, t1, t2);
 		}
@@ -912,32 +958,52 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
 		uint64_t n_neighbors = 0;
 		if (jb.pool) {
-			// pool overflow: the cursor says how much was needed; grow and redo this pair's pass
-			for (int attempt = 0; !c->debug_nostore && (pr.dry || h_ctrl[2 * k] > pr.records.cap / sizeof(int)); attempt++) {
-				if (attempt >= 5) TNSX_FAIL(c, TNSX_ERR_HIP, "neighbour pool kept overflowing (needed %llu ints)", (unsigned long long)h_ctrl[2 * k]);
-				if (pr.dry) {
-					// the dry pass counted every neighbour: size the real pass exactly
-					pr.dry = false;
-					S.cold_passes++;
-					const tnsx_status r = size_pool(pr, h_ctrl[2 * k + 1] + (uint64_t)pr.n_query);
-					if (r != TNSX_OK) return r;
+			// what every XCD produced: ints it asked for - ints it left unused.  The pass failed if a wave found both its own region and the
+			// overflow region full (or if it was a dry pass): size the pool by what was counted and redo this pair's pass.
+			const uint64_t* hc = h_ctrl + HC * k;
+			uint64_t payload[PairResult::NR];
+			auto read_counters = [&]() {
+				n_neighbors = 0;
+				for (int r = 0; r < PairResult::NR; r++) {
+					const uint64_t asked = hc[(size_t)r * tnsx::POOL_CTRL_WORDS];
+					// (the common region: what the heavy tiers asked for + what fast-tier waves were diverted to it, the latter counted in their
+					//  own region as well -- a harmless overestimate in the rare run where a region was full)
+					payload[r] = asked - std::min(asked, hc[(size_t)r * tnsx::POOL_CTRL_WORDS + tnsx::POOL_WASTE_WORD]);
+					n_neighbors += hc[(size_t)r * tnsx::POOL_CTRL_WORDS + tnsx::POOL_HITS_WORD];
 				}
+			};
+			read_counters();
+			for (int attempt = 0; !c->debug_nostore && (pr.dry || hc[(size_t)tnsx::POOL_OVERFLOW * tnsx::POOL_CTRL_WORDS] > pr.region_cap[tnsx::POOL_OVERFLOW]); attempt++) {
+				if (attempt >= 5) TNSX_FAIL(c, TNSX_ERR_HIP, "neighbour pool kept overflowing (%llu neighbours)", (unsigned long long)n_neighbors);
+				const bool was_dry = pr.dry;
+				if (pr.dry) { pr.dry = false; S.cold_passes++; }   // the dry pass counted everything: the real pass is sized exactly
 				else {
-					const uint64_t need = h_ctrl[2 * k];
-					if (std::getenv("TNSX_DEBUG_POOL")) fprintf(stderr, "[tnsx] pool overflow pair %zu: cursor %llu hits %llu cap %zu slab %u n_i %d\n", k, (unsigned long long)need, (unsigned long long)h_ctrl[2 * k + 1], pr.records.cap / sizeof(int), pr.pool_slab, pr.n_i);
-					HIPCHK(c, pr.records.reserve((need + need / 8 + (uint64_t)query_waves * pr.pool_slab * 2) * sizeof(int)));
+					if (std::getenv("TNSX_DEBUG_POOL")) fprintf(stderr, "[tnsx] pool overflow pair %zu: overflow region asked %llu of %llu, slab %u n_i %d\n", k,
+					                                            (unsigned long long)hc[(size_t)tnsx::POOL_OVERFLOW * tnsx::POOL_CTRL_WORDS], (unsigned long long)pr.region_cap[tnsx::POOL_OVERFLOW], pr.pool_slab, pr.n_i);
 					S.pool_retries++;
 				}
+				{ const tnsx_status r = size_pool(pr, payload, !was_dry); if (r != TNSX_OK) return r; }
 				const tnsx_status r = launch_pool(k);
 				if (r != TNSX_OK) return r;
 				HIPCHK(c, hipStreamSynchronize(st));
+				read_counters();
 			}
-			pr.n_records = h_ctrl[2 * k];
-			n_neighbors = h_ctrl[2 * k + 1];
+			pr.n_records = pr.shared_empty ? 1 : 0;
+			uint64_t sum = 0;
+			for (int r = 0; r < PairResult::NR; r++) {
+				pr.region_payload[r] = payload[r];
+				sum += payload[r];
+				pr.region_used[r] = c->debug_nostore ? 0 : std::min<uint64_t>(hc[(size_t)r * tnsx::POOL_CTRL_WORDS], pr.region_cap[r]);
+				if (pr.region_used[r]) pr.n_records = std::max(pr.n_records, pr.region_base[r] + pr.region_used[r]);
+			}
+			pr.need_hint = sum + 1;
 		}
 		else {
-			pr.n_records = h_ctrl[2 * k];
+			pr.n_records = h_ctrl[HC * k];
 			n_neighbors = pr.n_records - (uint64_t)pr.n_query;
+			pr.shared_empty = false;
+			for (int r = 0; r < PairResult::NR; r++) { pr.region_base[r] = 0; pr.region_used[r] = 0; }
+			pr.region_used[0] = pr.n_records;
 			HIPCHK(c, pr.records.reserve(std::max<uint64_t>(pr.n_records, 1) * sizeof(int)));
 			const int t0 = tm.mark();
 			if (pr.n_i > 0) {
@@ -948,7 +1014,6 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			span(ST_FILL, t0, t1);
 		}
 		pr.n_neighbors = n_neighbors;
-		pr.need_hint = n_neighbors + (uint64_t)pr.n_query;
 		pr.valid = true;
 		S.n_queries += (uint64_t)pr.n_query;
 		S.n_neighbors += n_neighbors;
@@ -977,7 +1042,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			HIPCHK(c, pr.h_records.reserve(std::max<uint64_t>(pr.n_records, 1) * sizeof(int)));
 			if (pr.n_query > 0) {
 				HIPCHK(c, hipMemcpyAsync(pr.h_offs.p, pr.offs_orig.p, (size_t)pr.n_query * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-				HIPCHK(c, hipMemcpyAsync(pr.h_records.p, pr.records.p, pr.n_records * sizeof(int), hipMemcpyDeviceToHost, st));
+				{ const tnsx_status r = copy_records(c, pr, pr.h_records.as<int>(), hipMemcpyDeviceToHost, st); if (r != TNSX_OK) return r; }
 			}
 			pr.mirrored = true;
 		}
@@ -1054,7 +1119,7 @@ tnsx_status tnsx_mirror_pair_to_host(tnsx_context* c, int i, int j)
 	HIPCHK(c, pr->h_records.reserve(std::max<uint64_t>(pr->n_records, 1) * sizeof(int)));
 	if (pr->n_query > 0) {
 		HIPCHK(c, hipMemcpyAsync(pr->h_offs.p, pr->offs_orig.p, (size_t)pr->n_query * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-		HIPCHK(c, hipMemcpyAsync(pr->h_records.p, pr->records.p, pr->n_records * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+		{ const tnsx_status r = copy_records(c, *pr, pr->h_records.as<int>(), hipMemcpyDeviceToHost, c->stream); if (r != TNSX_OK) return r; }
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 	}
 	pr->mirrored = true;
@@ -1094,7 +1159,7 @@ tnsx_status tnsx_copy_pair(tnsx_context* c, int i, int j, uint64_t* offsets_dst,
 	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
 	const hipMemcpyKind kind = dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
 	if (offsets_dst && pr->n_query > 0) HIPCHK(c, hipMemcpyAsync(offsets_dst, pr->offs_orig.p, (size_t)pr->n_query * sizeof(uint64_t), kind, c->stream));
-	if (records_dst && pr->n_records > 0) HIPCHK(c, hipMemcpyAsync(records_dst, pr->records.p, pr->n_records * sizeof(int), kind, c->stream));
+	if (records_dst && pr->n_records > 0) { const tnsx_status r = copy_records(c, *pr, records_dst, kind, c->stream); if (r != TNSX_OK) return r; }
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	return TNSX_OK;
 }

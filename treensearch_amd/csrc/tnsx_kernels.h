@@ -81,11 +81,11 @@ struct QueryArgs {
 	const uint64_t* offs_sorted;   // exclusive scan of counts
 	int* records;                  // [count, j...] records
 	uint64_t* offs_by_orig;        // offsets by original index of set i
-	// pool pass (single pass, no count/scan): records are bump-allocated from *pool_cursor in per-wave slabs
-	unsigned long long* pool_cursor;   // ints handed out so far (may exceed pool_capacity: then the pass must be redone)
-	uint64_t pool_capacity;            // ints available in `records`
-	uint32_t pool_slab;                // ints a wave takes from the cursor per atomic
-	unsigned long long* hit_total;     // += number of neighbour indices emitted
+	// pool pass (single pass, no count/scan): records are bump-allocated in per-wave slabs from POOL_REGIONS + 1 regions of `records`
+	unsigned long long* pool_cursor;         // cursor of region r at pool_cursor[r * POOL_CURSOR_STRIDE]: ints ASKED FOR so far by the waves of XCD r (r == POOL_OVERFLOW: by
+	                                         // waves whose own region was full); [+ POOL_HITS_WORD] neighbour indices emitted, [+ POOL_WASTE_WORD] slab ints left unused
+	const unsigned long long* pool_regions;  // device table: {first int, capacity in ints} of region 0..POOL_OVERFLOW (all capacities 0: a dry pass that only counts)
+	uint32_t pool_slab;                      // ints a wave takes from a cursor per atomic (fast tier: its XCD's region; fat and general tier: region POOL_OVERFLOW)
 	uint32_t* tickets;                 // ticket counters of the fast kernel: tickets[(xcd * CTRL_SUBRANGES + piece) * CTRL_STRIDE_U32] (zeroed before the launch)
 	uint2* heavy;                      // worklist {first sorted position, key} of the cells the fast kernel skipped
 	uint32_t* n_heavy;                 // its length (zeroed before the launch)
@@ -96,7 +96,12 @@ struct QueryArgs {
 // the counters over different L2 channels whether these interleave at 256 B or at 4 KiB.
 static constexpr size_t CTRL_STRIDE_U32 = 1088;
 static constexpr uint32_t CTRL_SUBRANGES = 8;   // ticket counters per XCD and tier (each hands out one contiguous piece of the XCD's cells)
-enum { CTRL_CURSOR = 0 /* u64 cursor, u64 hit_total */, CTRL_TICKETS = 1 /* 8 x CTRL_SUBRANGES slots */, CTRL_NHEAVY = CTRL_TICKETS + 8 * CTRL_SUBRANGES,
+static constexpr int POOL_REGIONS = 8, POOL_OVERFLOW = POOL_REGIONS;   // one region per XCD (fast tier) + the common region (heavy tiers, overflow)
+static constexpr size_t POOL_CURSOR_STRIDE = CTRL_STRIDE_U32 / 2;      // in 64-bit words
+static constexpr int POOL_HITS_WORD = 16, POOL_WASTE_WORD = 17;        // 64-bit words of a cursor's slot, on the line after the cursor's
+static constexpr int POOL_CTRL_WORDS = 18;                             // what the host reads back per region
+enum { CTRL_CURSOR = 0 /* POOL_REGIONS + 1 slots: u64 cursor | u64 hits, u64 waste */, CTRL_REGIONS = CTRL_CURSOR + POOL_REGIONS + 1 /* the region table */,
+       CTRL_TICKETS = CTRL_REGIONS + 1 /* 8 x CTRL_SUBRANGES slots */, CTRL_NHEAVY = CTRL_TICKETS + 8 * CTRL_SUBRANGES,
        CTRL_TICKETS2 = CTRL_NHEAVY + 1 /* 8 x CTRL_SUBRANGES slots */, CTRL_NHEAVY2 = CTRL_TICKETS2 + 8 * CTRL_SUBRANGES,
        CTRL_NFILTERED = CTRL_NHEAVY2 + 1 /* length of the candidate-presence worklist */, CTRL_SLOTS = CTRL_NFILTERED + 1 };
 static constexpr size_t CTRL_BYTES = CTRL_SLOTS * CTRL_STRIDE_U32 * sizeof(uint32_t);
@@ -124,8 +129,9 @@ void launch_x_histogram(const float* xyz, int n, float x0, float inv_dx, int n_b
 // list entries j of the records of the first n_query points -> id_map[j], in place
 void launch_translate_records(int* records, const uint64_t* offs_by_orig, int n_query, const int* id_map, int n_cus, hipStream_t s);
 
-// ---- pool pass over two different sets: offs[0..n) = 0 (the shared empty record at int 0 of the pool), records[0] = 0, *cursor = 1
-void launch_shared_empty_begin(uint64_t* offs, size_t n, int* records, unsigned long long* cursor, hipStream_t s);
+// ---- start of a pool pass: regions[2 * (POOL_REGIONS + 1)] = {first int, capacity} of every region -> the device table the query reads;
+//      n_shared_empty > 0 (a pair of two different sets): offs[0..n) = 0 and records[0] = 0, the shared empty record at int 0 of the pool
+void launch_pool_begin(const unsigned long long* regions, unsigned long long* table, uint64_t* offs, size_t n_shared_empty, int* records, hipStream_t s);
 
 // ---- ascending order inside every record of the first n_query points (tnsx_options.sorted_lists), in place
 void launch_sort_records(int* records, const uint64_t* offs_by_orig, int n_query, int n_cus, hipStream_t s);

@@ -376,19 +376,24 @@ void launch_translate_records(int* records, const uint64_t* offs_by_orig, int n_
 // start of a pool pass over two DIFFERENT sets: every offset points at the shared empty record (int 0 of the pool, count 0) and
 // the pool hands out ints from 1 on -- one launch instead of three memsets
 // =====================================================================================================
-__global__ void __launch_bounds__(256) k_shared_empty_begin(uint64_t* __restrict__ offs, size_t n, int* __restrict__ records, unsigned long long* __restrict__ cursor)
+struct PoolRegionTable { unsigned long long v[2 * (POOL_REGIONS + 1)]; };
+__global__ void __launch_bounds__(256) k_pool_begin(PoolRegionTable t, unsigned long long* __restrict__ table, uint64_t* __restrict__ offs, size_t n, int* __restrict__ records)
 {
-	if (blockIdx.x == 0 && threadIdx.x == 0) { records[0] = 0; *cursor = 1ull; }
+	if (blockIdx.x == 0 && threadIdx.x < 2 * (POOL_REGIONS + 1)) table[threadIdx.x] = t.v[threadIdx.x];
+	if (n == 0) return;
+	if (blockIdx.x == 0 && threadIdx.x == 0) records[0] = 0;
 	ulonglong2* o2 = reinterpret_cast<ulonglong2*>(offs);
 	const size_t n2 = n / 2;
 	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) o2[i] = make_ulonglong2(0ull, 0ull);
 	if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) offs[n - 1] = 0ull;
 }
-void launch_shared_empty_begin(uint64_t* offs, size_t n, int* records, unsigned long long* cursor, hipStream_t s)
+void launch_pool_begin(const unsigned long long* regions, unsigned long long* table, uint64_t* offs, size_t n_shared_empty, int* records, hipStream_t s)
 {
-	size_t blocks = (n / 2 + 256 * 8 - 1) / (256 * 8);
+	PoolRegionTable t;
+	for (int k = 0; k < 2 * (POOL_REGIONS + 1); k++) t.v[k] = regions[k];
+	size_t blocks = (n_shared_empty / 2 + 256 * 8 - 1) / (256 * 8);
 	blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
-	hipLaunchKernelGGL(k_shared_empty_begin, dim3((unsigned)blocks), dim3(256), 0, s, offs, n, records, cursor);
+	hipLaunchKernelGGL(k_pool_begin, dim3((unsigned)blocks), dim3(256), 0, s, t, table, offs, n_shared_empty, records);
 }
 
 // =====================================================================================================

@@ -178,35 +178,76 @@ __device__ __forceinline__ void lookup_cell(const QueryArgs& a, uint32_t key, bo
 enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_POOL = 2 };
 
 // Per-wave bump allocator over the record pool (MODE_POOL): a wave owns a slab of POOL_SLAB ints at a time and takes a
-// new one from the global cursor with ONE atomic when the next record does not fit.  Slab remainders stay unused, so
-// the pool has holes; every record is still contiguous and exact.
+// new one with ONE atomic when the next record does not fit.  Slab remainders stay unused, so the pool has holes; every
+// record is still contiguous and exact.
+// The pool is cut into POOL_REGIONS regions, one per XCD, each with its own cursor on its own cache line, for the fast tier (whose
+// cells are split among the XCDs by position in the cell list: what an XCD produces changes slowly from run to run), plus one
+// common region for the two heavy tiers (their worklists are appended to in any order) that a fast-tier wave also falls back to
+// when its XCD's region is full.  One cursor for everybody was the bottleneck of
+// every launch that is not huge: the L2 serialises the atomics of a line (~88 per microsecond), 8192 waves that each take
+// ~8 slabs are 65 k atomics = 0.74 ms whatever the problem size (C3's fluid->boundary pair: 0.66 ms for 69 k cells; a
+// 1 M point query: 0.84 ms instead of 0.28).  Region capacities follow the payload every XCD produced in the previous run.
 // All fast-path bookkeeping is 32-bit scalar work: gfx9 has no 64-bit scalar magnitude compare, so a `cur + len > end`
 // test on 64-bit values would be done on the VALU (with copies back and forth) for every single query.
 struct PoolState {
 	uint32_t cur_lo, cur_hi;   // next free int of the wave's slab
 	uint32_t left;             // ints left in the slab
 	uint32_t ok;               // 1 when the whole slab lies inside the pool (else: count, but do not write)
+	uint32_t waste;            // ints of abandoned slab remainders so far (payload of an XCD = what it asked for - what it wasted)
 };
 
-// rare path, deliberately out of line so that the per-query fast path stays a handful of scalar instructions
-__device__ __attribute__((noinline)) unsigned long long pool_take_slab(unsigned long long* cursor, uint32_t sz)
+// rare path, deliberately out of line so that the per-query fast path stays a handful of scalar instructions.
+// Returns the first int of the new slab, or POOL_NONE when it may not be written (valid in lane 0).
+static constexpr unsigned long long POOL_NONE = ~0ull;
+__device__ __attribute__((noinline)) unsigned long long pool_take_slab(unsigned long long* cursors, const unsigned long long* regions, uint32_t sz, uint32_t heavy_tier)
 {
-	unsigned long long old = 0;
-	if (lane_id() == 0) old = atomicAdd(cursor, (unsigned long long)sz);
-	return old;   // valid in lane 0
+	unsigned long long first = POOL_NONE;
+	if (lane_id() == 0) {
+		const uint32_t r = heavy_tier ? (uint32_t)POOL_OVERFLOW : (blockIdx.x & 7u);
+		const unsigned long long old = atomicAdd(cursors + (size_t)r * POOL_CURSOR_STRIDE, (unsigned long long)sz);
+		if (old + sz <= regions[2 * r + 1]) first = regions[2 * r] + old;
+		else if (r != (uint32_t)POOL_OVERFLOW) {
+			const unsigned long long cap_o = regions[2 * POOL_OVERFLOW + 1];
+			if (cap_o != 0ull) {   // (0: dry pass, nothing is written anywhere)
+				const unsigned long long old_o = atomicAdd(cursors + (size_t)POOL_OVERFLOW * POOL_CURSOR_STRIDE, (unsigned long long)sz);
+				if (old_o + sz <= cap_o) first = regions[2 * POOL_OVERFLOW] + old_o;
+			}
+		}
+	}
+	return first;
 }
 
+// end of a wave's work: its neighbour count and its unused ints -> the counters of its region
+template <bool HEAVY>
+__device__ __forceinline__ void pool_wave_done(const QueryArgs& a, const PoolState& ps, uint32_t wave_hits, int lane)
+{
+	if (lane == 0) {
+		const uint32_t r = HEAVY ? (uint32_t)POOL_OVERFLOW : (blockIdx.x & 7u);
+		unsigned long long* line = a.pool_cursor + (size_t)r * POOL_CURSOR_STRIDE;
+		const unsigned long long waste = (unsigned long long)ps.waste + ps.left;
+		if (wave_hits) atomicAdd(line + POOL_HITS_WORD, (unsigned long long)wave_hits);
+		if (waste) atomicAdd(line + POOL_WASTE_WORD, waste);
+	}
+}
+
+__device__ __forceinline__ void pool_waste(PoolState& ps, uint32_t left)
+{
+	ps.waste += left;
+}
+
+template <bool HEAVY>
 __device__ __forceinline__ uint64_t pool_alloc(const QueryArgs& a, PoolState& ps, uint32_t len, int lane, bool& ok)
 {
 	(void)lane;
 	if (len > ps.left) {
+		pool_waste(ps, ps.left);
 		const uint32_t sz = len > a.pool_slab ? len : a.pool_slab;
-		const unsigned long long old = pool_take_slab(a.pool_cursor, sz);
-		ps.cur_lo = readfirstlane_u32((uint32_t)old);
-		ps.cur_hi = readfirstlane_u32((uint32_t)(old >> 32));
+		const unsigned long long first = pool_take_slab(a.pool_cursor, a.pool_regions, sz, HEAVY ? 1u : 0u);
+		ps.cur_lo = readfirstlane_u32((uint32_t)first);
+		ps.cur_hi = readfirstlane_u32((uint32_t)(first >> 32));
 		ps.left = sz;
-		const uint64_t slab_end = (((uint64_t)ps.cur_hi << 32) | ps.cur_lo) + sz;
-		ps.ok = readfirstlane_u32(slab_end <= a.pool_capacity ? 1u : 0u);
+		ps.ok = (ps.cur_lo & ps.cur_hi) != 0xffffffffu ? 1u : 0u;
+		if (ps.ok == 0u) { ps.cur_lo = 0u; ps.cur_hi = 0u; }
 	}
 	const uint64_t off = ((uint64_t)ps.cur_hi << 32) | ps.cur_lo;
 	const uint64_t nxt = off + len;
@@ -398,7 +439,7 @@ __device__ __forceinline__ void process_batch(const QueryArgs& a, const RunRef R
 			uint64_t off;
 			bool ok = true;
 			if (MODE == MODE_POOL) {
-				off = pool_alloc(a, ps, cnt + 1u, lane, ok);
+				off = pool_alloc<true>(a, ps, cnt + 1u, lane, ok);
 				if ((uint32_t)lane == t) my_off = ok ? off : ~0ull;
 			}
 			else {
@@ -449,7 +490,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 	const uint32_t lo = (uint32_t)(((uint64_t)n_occ * xcd) >> 3), hi = (uint32_t)(((uint64_t)n_occ * (xcd + 1u)) >> 3);
 	const uint32_t stride = (gridDim.x >> 3) * Q_WAVES;
 	uint32_t ci = lo + (blockIdx.x >> 3) * Q_WAVES + w;
-	PoolState ps = { 0u, 0u, 0u, 0u };
+	PoolState ps = { 0u, 0u, 0u, 0u, 0u };
 	uint32_t wave_hits = 0;
 
 	// software pipeline: occ entry two cells ahead, 27 lookups one cell ahead
@@ -507,7 +548,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 					// no candidates at all: every query still gets its (empty) record
 					for (uint32_t t = 0; t < nq; t++) {
 						bool ok1;
-						const uint64_t off = pool_alloc(a, ps, 1u, lane, ok1);
+						const uint64_t off = pool_alloc<true>(a, ps, 1u, lane, ok1);
 						if ((uint32_t)lane == t) my_off = ok1 ? off : ~0ull;
 					}
 				}
@@ -532,7 +573,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 				for (int o = 1; o < WAVE; o <<= 1) { const uint32_t tv = __shfl_up(inc, o, WAVE); if (lane >= o) inc += tv; }
 				const uint32_t total_len = readlane_u32(inc, WAVE - 1);
 				bool okm;
-				const uint64_t base = pool_alloc(a, ps, total_len, lane, okm);
+				const uint64_t base = pool_alloc<true>(a, ps, total_len, lane, okm);
 				my_off = okm ? base + (inc - len) : ~0ull;
 				run_cnt = 0;
 				if (okm) {
@@ -553,9 +594,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 		}
 		ci = ci_n; oc = oc_n; oc_n = oc_nn;
 	}
-	if (MODE == MODE_POOL) {
-		if (lane == 0 && wave_hits) atomicAdd(a.hit_total, (unsigned long long)wave_hits);
-	}
+	if (MODE == MODE_POOL) pool_wave_done<true>(a, ps, wave_hits, lane);   // (pool mode: this kernel is the general tier)
 }
 
 // =====================================================================================================
@@ -651,12 +690,14 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 		if (len > left) {
 			// rare: new slab (one atomic on the global cursor).  The queries so far refer to the old base: write them out first.
 			flush(t);
+			pool_waste(ps, left);
 			const uint32_t sz = len > a.pool_slab ? len : a.pool_slab;
-			const unsigned long long old = pool_take_slab(a.pool_cursor, sz);
-			base = ((uint64_t)readfirstlane_u32((uint32_t)(old >> 32)) << 32) | readfirstlane_u32((uint32_t)old);
+			const unsigned long long first = pool_take_slab(a.pool_cursor, a.pool_regions, sz, NC > 8 ? 1u : 0u);   // (more than 8 chunks: the fat tier)
+			base = ((uint64_t)readfirstlane_u32((uint32_t)(first >> 32)) << 32) | readfirstlane_u32((uint32_t)first);
+			ok = base != POOL_NONE ? 1u : 0u;
+			if (ok == 0u) base = 0;
 			rsrc = record_rsrc(a.records + base);
 			left = sz;
-			ok = readfirstlane_u32(base + sz <= a.pool_capacity ? 1u : 0u);
 			pos0 = 0;
 		}
 		if (ok != 0u) {
@@ -937,7 +978,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 	const uint32_t lo = (uint32_t)(((uint64_t)n_occ * xcd) >> 3), hi = (uint32_t)(((uint64_t)n_occ * (xcd + 1u)) >> 3);
 	// more waves than cells (short worklists of the later tiers): the surplus leaves without touching the counter
 	if ((blockIdx.x >> 3) * Q_WAVES + threadIdx.x / WAVE >= hi - lo) return;
-	PoolState ps = { 0u, 0u, 0u, 0u };
+	PoolState ps = { 0u, 0u, 0u, 0u, 0u };
 	uint32_t wave_hits = 0;
 
 	// One cell per ticket (measured: 1.79 ms against 1.99 ms with tickets of 8 cells), fetched through a three-deep software
@@ -1033,7 +1074,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 			const uint32_t qi0 = a.orig_i ? a.orig_i[qs0] : __float_as_uint(a.xyzi_i[qs0].w);
 			const uint32_t nqv = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((uint32_t)lane < nq && qi0 < a.query_limit));   // (a prefix, see fast_query_loop)
 			bool okz;
-			const uint64_t off = pool_alloc(a, ps, nqv, lane, okz);
+			const uint64_t off = pool_alloc<FAT>(a, ps, nqv, lane, okz);
 			if ((uint32_t)lane < nqv && okz) {
 				a.records[off + lane] = 0;
 				a.offs_by_orig[qi0] = off + lane;
@@ -1046,7 +1087,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 		first_next = first_next2;
 	}
 	if (rej_n) flush_rejects();
-	if (lane == 0 && wave_hits) atomicAdd(a.hit_total, (unsigned long long)wave_hits);
+	pool_wave_done<FAT>(a, ps, wave_hits, lane);
 }
 
 // =====================================================================================================
