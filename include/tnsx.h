@@ -138,6 +138,8 @@ typedef struct tnsx_stats {
 	int world_cells_pow2;
 	float zsort_cell_size_inv;    /* 1 / quantisation step of the last tnsx_prepare_zsort: 1 / cell size after a run() (cell-level order, the
 	                                 reference's tree path), the cell size halved down to < 2^21 steps per axis otherwise (its no-tree path) */
+	int grid_trimmed;             /* 1: cells of one search radius over the bounding box of all points would not fit (far outliers): the grid of the last
+	                                 run covers the bulk of the points, the rest sits in its border cells (exact all the same) */
 } tnsx_stats;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */

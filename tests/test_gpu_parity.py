@@ -150,6 +150,40 @@ def test_pool_regions_follow_a_moving_cluster():
     assert retries <= 3     # (a repeated pass is allowed when the cluster jumps, never in the steps where it stays)
 
 
+def test_far_outliers_do_not_coarsen_the_grid(oracle):
+    """A few stray points far away from a dense cloud: cells of one search radius over the bounding box do not fit any table, and
+    coarser cells would make every query test thousands of candidates.  The grid is laid over the bulk of the points instead; the
+    outliers are binned into its border cells, which is exact (clamping never increases a coordinate difference).  Checked against
+    the CPU restatement, including outliers that are neighbours of each other and an outlier next to the cloud."""
+    import treensearch_amd as T
+    rng = np.random.default_rng(5)
+    n = 30_000
+    cloud = rng.random((n, 3), dtype=np.float32)
+    radius = 0.04
+    far = np.array([[400.0, 0.5, 0.5], [400.0 + 0.5 * radius, 0.5, 0.5],      # two outliers that ARE neighbours of each other
+                    [-250.0, -250.0, 300.0], [0.5, 0.5, 380.0],
+                    [1.0 + 0.9 * radius, 0.5, 0.5],                               # just outside the cloud: neighbour of cloud points
+                    [399.0, 0.5, 0.5]], np.float32)
+    pts = np.ascontiguousarray(np.concatenate([cloud, far]))
+    ns = T.TreeNSearch(); ns.set_search_radius(radius)
+    ns.add_point_set(pts); ns.set_active_search(0, 0, True)
+    for step in range(3):
+        ns.run()
+        st = ns.get_stats()
+        assert st["grid_trimmed"] == 1 and st["speculated"] == 0
+        assert abs(st["grid_cell_size"] / radius - 1.0) < 1e-3, "the cells must stay one search radius wide"
+        assert st["n_grid_cells"] < 2_000_000
+        ref = oracle.pair_search(pts, pts, radius=radius, same_set=True, mode=0, use_grid=False)    # (all pairs)
+        P.assert_same_csr(ns.neighbor_csr(0, 0), ref, f"cloud + far outliers, run {step}")
+        pts[:n] += (rng.random((n, 3), dtype=np.float32) - 0.5) * np.float32(0.2 * radius)
+    off, idx = ns.neighbor_csr(0, 0)
+    assert list(idx[off[n]:off[n + 1]]) == [n + 1] and list(idx[off[n + 1]:off[n + 2]]) == [n]
+    # the outliers go away: the next run is an ordinary one again
+    ns.resize_point_set(0, pts, n_points=n)
+    ns.run()
+    assert ns.get_stats()["grid_trimmed"] == 0
+
+
 def test_exact_layout_option_is_sorted_and_gapless(oracle):
     case = CS.by_name("uniform_fixed_100000")
     ns = P.make_engine(case, 0, exact_layout=True)

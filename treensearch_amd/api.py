@@ -54,7 +54,8 @@ class Stats(C.Structure):
                 ("ms_scan", C.c_float), ("ms_fill", C.c_float), ("ms_mirror", C.c_float), ("ms_sort_lists", C.c_float),
                 ("n_pool_pairs", C.c_int), ("pool_retries", C.c_int), ("cold_passes", C.c_int), ("speculated", C.c_int),
                 ("speculation_redos", C.c_int), ("n_cached_sets", C.c_int), ("n_filtered_cells", C.c_uint32), ("n_devices_used", C.c_int),
-                ("world_bottom", C.c_float * 3), ("world_top", C.c_float * 3), ("world_cells_pow2", C.c_int), ("zsort_cell_size_inv", C.c_float)]
+                ("world_bottom", C.c_float * 3), ("world_top", C.c_float * 3), ("world_cells_pow2", C.c_int), ("zsort_cell_size_inv", C.c_float),
+                ("grid_trimmed", C.c_int)]
 
     def as_dict(self):
         d = {}

@@ -156,14 +156,15 @@ struct tnsx_context {
 	tnsx::GridParams grid{};
 	float grid_h = 0.0f, grid_lo[3] = { 0, 0, 0 }, grid_hi[3] = { 0, 0, 0 }, grid_r_max = 0.0f;
 	bool grid_valid = false, grid_variable = false;
+	bool grid_trimmed = false;      // the grid covers the bulk of the points only (trim_box)
 	uint32_t grid_gen = 0;
 	float zsort_inv_h = 0.0f;   // 1 / quantisation step of the last prepare_zsort (tnsx_stats.zsort_cell_size_inv)
 	bool auto_dense_cells = true;
 	bool debug_nostore = std::getenv("TNSX_DEBUG_NOSTORE") != nullptr;   // timing experiments only: pool pass without its stores
 
 	// scratch
-	DevBuf bounds_partials, bounds_out, sort_temp, scan_temp, n_occ, permute_tmp, pool_ctrl, run_words, cell_map;
-	PinnedBuf h_small;
+	DevBuf bounds_partials, bounds_out, sort_temp, scan_temp, n_occ, permute_tmp, pool_ctrl, run_words, cell_map, trim_hist;
+	PinnedBuf h_small, h_trim;
 	tnsx_stats stats{};
 	std::vector<hipEvent_t> events;
 	std::mutex mirror_mutex;
@@ -287,6 +288,57 @@ tnsx_status compute_bounds(tnsx_context* c, float out8[8])
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	std::memcpy(out8, c->h_small.p, 8 * sizeof(float));
 	return TNSX_OK;
+}
+
+// A few points far away from all the others (a stray particle of an SPH scene) blow the bounding box up until no table of cells of
+// one search radius fits any more; coarser cells would make EVERY query test thousands of candidates.  The grid does not have to
+// cover every point, though: the binning clamps cell coordinates to the grid (bin_coord), clamping is monotone and never increases a
+// coordinate difference, so two points at most one cell edge apart along an axis still land in the same or in adjacent cells and
+// the distance test does the rest -- a grid over the BULK of the points is exact, the outliers just sit in its border cells.
+// This finds that bulk: per-axis histograms of all points over the current box, tails of at most n/4096 points cut off on either
+// side, repeated on the cut box (every round zooms in by up to the number of bins) until a table of cells of edge h0 fits.
+// lo/hi: in = the tight bounds, out = the trimmed box.  Returns true if a box that fits was found.
+static bool trim_box(tnsx_context* c, int64_t n_total, double h0, double margin, uint64_t cell_cap, float lo[3], float hi[3], tnsx_status* status)
+{
+	constexpr int NB = 2048;
+	*status = TNSX_OK;
+	auto fits = [&](const float* a, const float* b) {
+		double cells = 1.0;
+		for (int d = 0; d < 3; d++) cells *= std::floor(((double)b[d] - a[d] + 2.0 * margin) / h0) + 1.0;
+		return cells <= (double)cell_cap;
+	};
+	if (c->trim_hist.reserve(3 * NB * sizeof(unsigned int)) != hipSuccess || c->h_trim.reserve(3 * NB * sizeof(unsigned int)) != hipSuccess) { *status = TNSX_ERR_HIP; return false; }
+	const uint64_t budget = std::max<uint64_t>(1, (uint64_t)n_total >> 12);
+	for (int round = 0; round < 6; round++) {
+		if (fits(lo, hi)) return true;
+		float inv[3];
+		for (int d = 0; d < 3; d++) inv[d] = hi[d] > lo[d] ? (float)((double)NB / ((double)hi[d] - lo[d])) : 0.0f;
+		if (hipMemsetAsync(c->trim_hist.p, 0, 3 * NB * sizeof(unsigned int), c->stream) != hipSuccess) { *status = TNSX_ERR_HIP; return false; }
+		for (const PointSet& s : c->sets) {
+			if (s.n == 0) continue;
+			for (int d = 0; d < 3; d++) tnsx::launch_x_histogram(s.d_xyz + d, s.n, lo[d], inv[d], NB, c->trim_hist.as<unsigned int>() + d * NB, c->stream);
+		}
+		if (hipMemcpyAsync(c->h_trim.p, c->trim_hist.p, 3 * NB * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+		    hipStreamSynchronize(c->stream) != hipSuccess) { *status = TNSX_ERR_HIP; return false; }
+		const unsigned int* h = c->h_trim.as<unsigned int>();
+		bool progress = false;
+		for (int d = 0; d < 3; d++) {
+			if (!(hi[d] > lo[d])) continue;
+			const unsigned int* hd = h + d * NB;
+			int b0 = 0, b1 = NB - 1;
+			uint64_t acc = 0;
+			while (b0 < NB - 1 && acc + hd[b0] <= budget) acc += hd[b0++];
+			acc = 0;
+			while (b1 > b0 && acc + hd[b1] <= budget) acc += hd[b1--];
+			const double dx = ((double)hi[d] - lo[d]) / NB;
+			// one bin of slack on either side for the rounding of the binning
+			const double nlo = std::max((double)lo[d], (double)lo[d] + (b0 - 1) * dx), nhi = std::min((double)hi[d], (double)lo[d] + (b1 + 2) * dx);
+			if (nhi - nlo < 0.75 * ((double)hi[d] - lo[d])) progress = true;
+			lo[d] = (float)nlo; hi[d] = (float)nhi;
+		}
+		if (!progress) break;
+	}
+	return fits(lo, hi);
 }
 
 // _set_up default cell size (TreeNSearch.cpp:300-316) and _check (TreeNSearch.cpp:366-392)
@@ -642,22 +694,39 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		//      pair the fp32 predicate can accept lies in adjacent cells.  Coarsened until the dense table fits.
 		c->grid_valid = false;
 		if (n_total > 0) {
+			// the dense table costs 8 bytes per cell and set: bounded by the number of points (a sparse scene trims the grid to the
+			// bulk of its points or coarsens its cells instead of allocating gigabytes), and by the option
+			const uint64_t cell_cap = c->auto_dense_cells ? std::min<uint64_t>(c->opt.max_dense_cells, std::max<uint64_t>((uint64_t)1 << 22, 64ull * (uint64_t)n_total))
+			                                              : c->opt.max_dense_cells;
+			float blo[3] = { b8[0], b8[1], b8[2] }, bhi[3] = { b8[3], b8[4], b8[5] };
+			bool trimmed = false;
+			{
+				double cells = 1.0;
+				const double h0 = (double)r_max * 1.001;
+				for (int d = 0; d < 3; d++) cells *= std::floor(((double)bhi[d] - blo[d] + 4.0 * r_max) / h0) + 1.0;
+				if (cells > (double)cell_cap) {
+					// cells of one search radius over the bounding box do not fit: far outliers?  (trim_box)
+					float tlo[3] = { blo[0], blo[1], blo[2] }, thi[3] = { bhi[0], bhi[1], bhi[2] };
+					tnsx_status ts = TNSX_OK;
+					if (trim_box(c, n_total, h0, 2.0 * r_max, cell_cap, tlo, thi, &ts)) {
+						for (int d = 0; d < 3; d++) { blo[d] = tlo[d]; bhi[d] = thi[d]; }
+						trimmed = true;
+					}
+					if (ts != TNSX_OK) TNSX_FAIL(c, ts, "HIP error while trimming the search grid to the bulk of the points");
+				}
+			}
 			float lo[3], hi[3];
 			for (int d = 0; d < 3; d++) {
 				const float m = 2.0f * r_max;
-				lo[d] = std::max(b8[d] - m, c->world[d]);
-				hi[d] = std::min(b8[3 + d] + m, c->world[3 + d]);
-				if (!(lo[d] <= b8[d])) lo[d] = b8[d];            // (a world box that does not contain the points: a failed update)
-				if (!(hi[d] >= b8[3 + d])) hi[d] = b8[3 + d];
+				lo[d] = std::max(blo[d] - m, c->world[d]);
+				hi[d] = std::min(bhi[d] + m, c->world[3 + d]);
+				if (!(lo[d] <= blo[d])) lo[d] = blo[d];            // (a world box that does not contain the points: a failed update)
+				if (!(hi[d] >= bhi[d])) hi[d] = bhi[d];
 			}
 			const double ext[3] = { (double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2] };
 			const double max_ext = std::max(ext[0], std::max(ext[1], ext[2]));
 			const double n0 = std::floor(max_ext / (double)r_max) + 2.0;
 			double h = (double)r_max * (1.0 + 8.0 * 5.9604644775390625e-08 * (n0 + 2.0)) * (1.0 + 1e-6);
-			// the dense table costs 8 bytes per cell and set: bounded by the number of points (a sparse scene coarsens its cells
-			// instead of allocating gigabytes), and by the option
-			const uint64_t cell_cap = c->auto_dense_cells ? std::min<uint64_t>(c->opt.max_dense_cells, std::max<uint64_t>((uint64_t)1 << 22, 64ull * (uint64_t)n_total))
-			                                              : c->opt.max_dense_cells;
 			bool fits = false;
 			for (int it = 0; it < 400 && !fits; it++) {
 				const double nx = std::floor(ext[0] / h) + 1.0, ny = std::floor(ext[1] / h) + 1.0, nz = std::floor(ext[2] / h) + 1.0;
@@ -678,10 +747,11 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			for (int d = 0; d < 3; d++) { c->grid_lo[d] = lo[d]; c->grid_hi[d] = hi[d]; }
 			c->grid_r_max = r_max;
 			c->grid_variable = variable;
-			c->grid_valid = true;
+			c->grid_valid = !trimmed;   // (a trimmed grid is laid out afresh every run: the outliers are outside its box by design)
+			c->grid_trimmed = trimmed;
 			c->grid_gen++;
 		}
-		else { g.nx = g.ny = g.nz = 1; g.inv_h = 1.0f; c->grid = g; c->grid_h = 0.0f; }
+		else { g.nx = g.ny = g.nz = 1; g.inv_h = 1.0f; c->grid = g; c->grid_h = 0.0f; c->grid_trimmed = false; }
 	}
 	g = c->grid;
 	n_cells = (uint64_t)g.nx * g.ny * g.nz;
@@ -691,6 +761,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	S.grid_dims[0] = g.nx; S.grid_dims[1] = g.ny; S.grid_dims[2] = g.nz;
 	S.grid_origin[0] = g.ox; S.grid_origin[1] = g.oy; S.grid_origin[2] = g.oz;
 	S.n_grid_cells = n_cells;
+	S.grid_trimmed = c->grid_trimmed ? 1 : 0;
 	const int key_bits = std::max(1, ceil_log2_u64(n_cells + 1));   // + 1: the key behind the last cell, where NaN points ("no point") go
 	S.key_bits = key_bits;
 	S.radix_passes = tnsx::cell_sort_plan(key_bits).passes;
