@@ -184,6 +184,38 @@ def test_far_outliers_do_not_coarsen_the_grid(oracle):
     assert ns.get_stats()["grid_trimmed"] == 0
 
 
+@pytest.mark.parametrize("devices", [None, [0, 0]], ids=["one_engine", "two_engines"])
+def test_far_outliers_two_sets_per_point_radii(devices, oracle):
+    """the same with two sets, per-point radii (symmetric), double-precision input and all four searches -- on one engine and through
+    the multi-device mode of the ABI (every slab engine trims its own grid)"""
+    import treensearch_amd as T
+    rng = np.random.default_rng(9)
+    na, nb = 12_000, 5_000
+    r0 = 0.035
+    a = rng.random((na, 3))                                                   # float64 on purpose
+    b = rng.random((nb, 3)).astype(np.float32) * np.float32(0.5)
+    a[-3:] = [[300.0, 0.2, 0.2], [300.0 + 0.5 * r0, 0.2, 0.2], [-200.0, 250.0, 0.5]]     # (the reference allows 2^15 cells of 1.5 r_min per axis)
+    b[-2:] = [[300.0, 0.2 + 0.4 * r0, 0.2], [0.25, 0.25, -250.0]]
+    ra = (r0 * (1.0 + rng.random(na))).astype(np.float32)
+    rb = (r0 * (1.0 + rng.random(nb))).astype(np.float32)
+    ns = T.TreeNSearch(devices=devices) if devices else T.TreeNSearch()
+    ns.add_point_set(a, ra.astype(np.float64)); ns.add_point_set(b, rb)      # (set 0: doubles, cast to float by the engine like TreeNSearch.cpp:277-296)
+    ns.set_symmetric_search(True)
+    pairs = [(0, 0), (0, 1), (1, 0), (1, 1)]
+    for pr in pairs:
+        ns.set_active_search(*pr, True)
+    for step in range(2):
+        ns.run()
+        if not devices:
+            assert ns.get_stats()["grid_trimmed"] == 1
+        sets = [(a.astype(np.float32), ra), (b, rb)]
+        for (i, j) in pairs:
+            ref = oracle.pair_search(sets[i][0], sets[j][0], ra=sets[i][1], rb=sets[j][1], symmetric=True, same_set=(i == j), mode=0, use_grid=False)
+            P.assert_same_csr(ns.neighbor_csr(i, j), ref, f"two sets + outliers, pair {i}->{j}, run {step}")
+    off, idx = ns.neighbor_csr(0, 1)
+    assert nb - 2 in idx[off[na - 3]:off[na - 2]]          # the outlier of set 0 at x = 300 sees the outlier of set 1 next to it
+
+
 def test_exact_layout_option_is_sorted_and_gapless(oracle):
     case = CS.by_name("uniform_fixed_100000")
     ns = P.make_engine(case, 0, exact_layout=True)

@@ -832,9 +832,6 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	// ---- per active pair: the query.
 	//      pool mode (default): ONE pass, records bump-allocated from a device cursor (first run of a pair: a dry pass first);
 	//      exact mode (opt.exact_layout): count -> scan -> fill, gap-free CSR in sorted order.
-	#ifndef TNSX_SLAB_WAVE_DIV
-#define TNSX_SLAB_WAVE_DIV 8
-#endif
 	struct Job { int i, j; bool pool; };
 	std::vector<Job> jobs;
 	for (int i = 0; i < n_sets; i++) for (int j = 0; j < n_sets; j++) if (c->active[i][j]) jobs.push_back({ i, j, false });
@@ -944,7 +941,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		for (int r = 0; r < PairResult::NR; r++) total += payload[r];
 		const uint64_t expect = total + total / 8 + 1024;
 		// a wave's last slab stays half empty on average: slabs of 1/8 of a wave's share keep the holes at ~6 % of the pool
-		const uint64_t slab = std::min<uint64_t>(16384, std::max<uint64_t>(256, expect / ((uint64_t)query_waves * TNSX_SLAB_WAVE_DIV)));
+		const uint64_t slab = std::min<uint64_t>(16384, std::max<uint64_t>(256, expect / ((uint64_t)query_waves * 8)));
 		pr.pool_slab = (uint32_t)slab;
 		const uint64_t waves_x = (uint64_t)query_waves / tnsx::POOL_REGIONS;
 		uint64_t first = pr.shared_empty ? 64 : 0;
