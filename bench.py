@@ -171,6 +171,11 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
     ap.add_argument("--exact-layout", action="store_true", help="two-pass count/scan/fill result layout instead of the single pass")
     ap.add_argument("--static-input", action="store_true", help="do not move the points between steps (the engine then reuses everything it may)")
+    ap.add_argument("--zsort-input", dest="zsort_input", action="store_true", default=None,
+                    help="c2 / c5: the points are put into z-order once before the run (prepare_zsort + apply_zsort: what the reference's users do every "
+                         "so many steps, and what the cpu_baseline leg is given).  Default: c5 yes (the slab decomposition hands every rank its points "
+                         "in z-order), c2 no (the z-ordered figure is reported next to the main one)")
+    ap.add_argument("--no-zsort-input", dest="zsort_input", action="store_false")
     args = ap.parse_args()
 
     import torch
@@ -182,6 +187,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     workload = args.workload or ("c5" if args.gpus > 1 else "c2")
+    if args.zsort_input is None:
+        args.zsort_input = workload == "c5"
     # TNSX_BENCH_FORCE_SLAB=1: exercise the process-group path with a single rank (a 1-GPU box can check it)
     distributed = world > 1 or (os.environ.get("TNSX_BENCH_FORCE_SLAB") == "1" and "RANK" in os.environ)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU path)"
@@ -210,11 +217,27 @@ def main():
 
     points_total = args.points
     extra = {}
+
+    def zsorted(base, radius, *more, force=False):
+        """base (and the arrays in more) permuted into the z-order of base, in place -- outside the timed region"""
+        if not (args.zsort_input or force):
+            return
+        tmp = make_engine()
+        tmp.set_search_radius(radius)
+        tmp.add_point_set(base)
+        tmp.prepare_zsort()
+        tmp.apply_zsort(0, base, 3)
+        for arr in more:
+            tmp.apply_zsort(0, arr, 1)
+        torch.cuda.synchronize()
+        del tmp
     # ------------------------------------------------------------------------------------------------ workloads
     if workload == "c2":
         n = points_total or 10_000_000
         radius = D.radius_for_neighbors(n)
-        copies = osc(torch.from_numpy(D.uniform_cloud(n, args.seed)).cuda(), 0.1 * float(radius), 1)
+        base = torch.from_numpy(D.uniform_cloud(n, args.seed)).cuda()
+        zsorted(base, radius)
+        copies = osc(base, 0.1 * float(radius), 1)
         ns = make_engine()
         ns.set_search_radius(radius)
         ns.add_point_set(copies[0])
@@ -224,6 +247,22 @@ def main():
         def step(k):
             ns.resize_point_set(0, copies[k % 2])
             ns.run()
+
+        def zsorted_variant():
+            """the same cloud handed over in z-order (how an SPH code that calls zsort every so many steps holds it)"""
+            zb = base.clone()
+            zsorted(zb, radius, force=True)
+            zc = osc(zb, 0.1 * float(radius), 1)
+            for k in range(3):
+                ns.resize_point_set(0, zc[k % 2]); ns.run()
+            torch.cuda.synchronize()
+            t_z = time.perf_counter()
+            for k in range(10):
+                ns.resize_point_set(0, zc[k % 2]); ns.run()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_z) / 10 * 1e3
+        if not args.zsort_input:
+            extra["_zsorted_variant"] = zsorted_variant
         desc = (f"{n} uniform-random points in a unit cube, single set, fixed radius r={float(radius):.6f}, BASELINE.json configs[1]")
     elif workload == "c3":
         n = points_total or 10_000_000
@@ -287,11 +326,14 @@ def main():
         torch.cuda.synchronize()
         extra["decomposition_s"] = round(time.perf_counter() - t_dec, 3)
         del mine, gids, dec
+        owned, owned_gids = owned.contiguous(), owned_gids.contiguous()
+        zsorted(owned, radius, owned_gids)
         n_owned = int(owned.shape[0])
         # the points oscillate by <= 0.1 r around the positions the slabs were cut for: the halo is 0.11 r wider than the radius
         slab = SlabSearch(float(cuts[rank]), float(cuts[rank + 1]), float(radius), make_engine, halo_margin=0.11)
         copies = osc(owned, amp, 100 + rank)
         ns = slab.engine
+        extra["owned_points_order"] = "z-order (sorted once after the redistribution)" if args.zsort_input else "as redistributed"
 
         def step(k):
             slab.step(copies[k % 2], owned_gids)
@@ -359,8 +401,9 @@ def main():
         "higher_is_better": True, "scaling": "strong" if workload == "c5" else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": desc, "name": workload, "points_total": int(n_total), "arith": args.arith,
                    "input": "static" if args.static_input else "every coordinate moves by up to 0.058 r between steps (|d| <= 0.1 r)",
+                   "input_order": "z-order (sorted once before the run)" if args.zsort_input and workload in ("c2", "c5") else "as generated (random)",
                    "neighbors_rank0": int(E), "neighbors_per_query": round(E / max(Q, 1), 2), "queries_rank0": int(Q),
-                   "grid": st["grid_dims"], "parallelism": f"slab{world}", **{k: v for k, v in extra.items() if k != "zsort_ms_per_step"}},
+                   "grid": st["grid_dims"], "parallelism": f"slab{world}", **{k: v for k, v in extra.items() if k != "zsort_ms_per_step" and not k.startswith("_")}},
         "roofline": {"bound": "hbm", "kernel": QUERY_KERNEL if pooled else "k_query<fill>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_detail": None,
                      "bytes_per_launch": int(fill_bytes // n_launches), "avg_launch_ms": round(fill_ms / n_launches, 4), "launches_per_step": n_launches,
@@ -377,6 +420,11 @@ def main():
     if "zsort_ms_per_step" in extra and extra["zsort_ms_per_step"]:
         out["stage_ms"]["zsort_prepare_and_apply"] = round(float(np.mean(extra["zsort_ms_per_step"])), 4)
     if rank == 0:
+        if os.environ.get("TNSX_BENCH_INNER") != "1" and "_zsorted_variant" in extra:
+            z_ms = extra.pop("_zsorted_variant")()
+            out["zsorted_input"] = {"ms_per_step": round(z_ms, 4), "value": round(n_total / z_ms / 1e3, 1), "unit": "Mpoints/s",
+                                    "note": "same cloud, handed over in z-order (prepare_zsort + apply_zsort once, outside the timing): the order the "
+                                            "reference's users keep their particles in and the order the cpu_baseline leg is given; 10 steps after the main timing"}
         if os.environ.get("TNSX_BENCH_INNER") != "1":
             peak = measured_copy_peak(torch)
             out["roofline"]["peak_measured"] = peak
