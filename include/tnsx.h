@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TNSX_VERSION 200
+#define TNSX_VERSION 201
 
 typedef struct tnsx_context tnsx_context;
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(built_library):
 def test_version(built_library):
     from treensearch_amd import api
     L = api.load_library()
-    assert L.tnsx_version() == 200   # TNSX_VERSION of include/tnsx.h (round 2: slab support entry points)
+    assert L.tnsx_version() == 201   # TNSX_VERSION of include/tnsx.h (round 2: slab support entry points; 201: tnsx_stats.grid_trimmed)
 
 
 def test_no_cpu_fallback(built_library):
