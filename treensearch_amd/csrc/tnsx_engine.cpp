@@ -830,7 +830,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	}
 
 	// ---- per active pair: the query.
-	//      pool mode (default): ONE pass, records bump-allocated from a device cursor (first run of a pair: a dry pass first);
+	//      pool mode (default): ONE pass, records bump-allocated from the regions of the pair's pool (first run of a pair: a dry pass first);
 	//      exact mode (opt.exact_layout): count -> scan -> fill, gap-free CSR in sorted order.
 	struct Job { int i, j; bool pool; };
 	std::vector<Job> jobs;

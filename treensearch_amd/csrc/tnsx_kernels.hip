@@ -373,8 +373,9 @@ void launch_translate_records(int* records, const uint64_t* offs_by_orig, int n_
 }
 
 // =====================================================================================================
-// start of a pool pass over two DIFFERENT sets: every offset points at the shared empty record (int 0 of the pool, count 0) and
-// the pool hands out ints from 1 on -- one launch instead of three memsets
+// start of a pool pass: the region table of the pass (first int and capacity of every pool region, tnsx_query.hip PoolState) goes to
+// the device words the query kernels read; for a pair of two DIFFERENT sets every offset is also pointed at the shared empty record
+// (int 0 of the pool, count 0) -- one launch instead of a copy and three memsets
 // =====================================================================================================
 struct PoolRegionTable { unsigned long long v[2 * (POOL_REGIONS + 1)]; };
 __global__ void __launch_bounds__(256) k_pool_begin(PoolRegionTable t, unsigned long long* __restrict__ table, uint64_t* __restrict__ offs, size_t n, int* __restrict__ records)
