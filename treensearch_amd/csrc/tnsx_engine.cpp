@@ -943,12 +943,14 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		// a wave's last slab stays half empty on average: slabs of 1/8 of a wave's share keep the holes at ~6 % of the pool
 		const uint64_t slab = std::min<uint64_t>(16384, std::max<uint64_t>(256, expect / ((uint64_t)query_waves * 8)));
 		pr.pool_slab = (uint32_t)slab;
-		const uint64_t waves_x = (uint64_t)query_waves / tnsx::POOL_REGIONS;
+		// (a wave takes a slab only if it gets a cell: small sets keep small pools)
+		const uint64_t waves_all = std::min<uint64_t>((uint64_t)query_waves, (uint64_t)pr.n_i + 8);
+		const uint64_t waves_x = std::min<uint64_t>((uint64_t)query_waves / tnsx::POOL_REGIONS, (uint64_t)pr.n_i / tnsx::POOL_REGIONS + 2);
 		uint64_t first = pr.shared_empty ? 64 : 0;
 		for (int r = 0; r < PairResult::NR; r++) {
 			// a region of the fast tier: what its XCD produced last time + 6 % + a slab per wave;
 			// the common region: what the heavy tiers produced + 6 % + a slab per wave of a launch + 6 % of everything (fast-tier overflow)
-			uint64_t cap = payload[r] + payload[r] / 16 + 1024 + (r < tnsx::POOL_REGIONS ? waves_x * slab : expect / 16 + (uint64_t)query_waves * slab);
+			uint64_t cap = payload[r] + payload[r] / 16 + 1024 + (r < tnsx::POOL_REGIONS ? waves_x * slab : expect / 16 + waves_all * slab);
 			if (generous && r == tnsx::POOL_OVERFLOW) cap += expect;
 			pr.region_base[r] = first; pr.region_cap[r] = cap;
 			first = (first + cap + 63) & ~(uint64_t)63;
