@@ -9,7 +9,7 @@ Scenes: 1-3 point sets of random sizes (0 .. ~30 k, now and then up to 200 k, lo
 outliers, fixed radius or per-point radii (r_max / r_min up to 6), symmetric or not, random active pairs, strict or contracted
 arithmetic, float or double input, a few steps each with perturbation and occasional resizes.
 
-usage: python tools/fuzz_gpu.py [--minutes 5] [--seed 1]        (needs a GPU; test infrastructure, not part of the product)"""
+usage: python tools/fuzz_gpu.py [--minutes 5] [--seed 1] [--devices 3]        (needs a GPU; test infrastructure, not part of the product)"""
 import argparse
 import os
 import sys
@@ -26,6 +26,7 @@ from oracle import oracle as O   # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--minutes", type=float, default=5.0)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--devices", type=int, default=0, help="> 1: A is a multi-device context of that many engines on GPU 0 (tnsx_options.n_devices)")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 orc = O.Oracle()
@@ -79,7 +80,7 @@ while time.time() < t_end:
     ratio = float(rng.choice([1.5, 2.5, 6.0]))
     pairs = [(i, j) for i in range(n_sets) for j in range(n_sets) if rng.random() < 0.6] or [(0, 0)]
     opts_a = dict(arith=arith, sorted_lists=bool(rng.random() < 0.3), temporal_reuse=bool(rng.random() < 0.8))
-    A = T.TreeNSearch(**opts_a)
+    A = T.TreeNSearch(**opts_a, devices=[0] * args.devices) if args.devices > 1 else T.TreeNSearch(**opts_a)
     B = T.TreeNSearch(arith=arith, exact_layout=True, temporal_reuse=False)
     pts, rad = [], []
     for s in range(n_sets):
