@@ -120,6 +120,7 @@ __global__ void __launch_bounds__(CS_THREADS) k_cs_hist(const float* __restrict_
 	bool bad = false;
 	float mn[3] = { gd.hi[0], gd.hi[1], gd.hi[2] }, mx[3] = { gd.lo[0], gd.lo[1], gd.lo[2] };   // (guard: this thread's bounds, compared once at the end)
 	unsigned long long chk = 0;
+	uint32_t n_outside = 0;
 	#pragma unroll 8
 	for (int i = 0; i < CS_ITEMS; i++) {
 		const size_t e = base + (size_t)i * CS_THREADS + threadIdx.x;
@@ -135,6 +136,8 @@ __global__ void __launch_bounds__(CS_THREADS) k_cs_hist(const float* __restrict_
 						mn[1] = fminf(mn[1], q.y); mx[1] = fmaxf(mx[1], q.y);
 						mn[2] = fminf(mn[2], q.z); mx[2] = fmaxf(mx[2], q.z);
 						bad |= (q.y != q.y) | (q.z != q.z);
+						if (gd.outside) n_outside += (q.x < gd.soft_lo[0]) | (q.x > gd.soft_hi[0]) | (q.y < gd.soft_lo[1]) | (q.y > gd.soft_hi[1]) |
+						                             (q.z < gd.soft_lo[2]) | (q.z > gd.soft_hi[2]);
 					}
 					if (gd.checksum) chk += point_hash((uint32_t)e, q.x, q.y, q.z, radii ? radii[e] : 0.0f);
 				}
@@ -146,6 +149,10 @@ __global__ void __launch_bounds__(CS_THREADS) k_cs_hist(const float* __restrict_
 	if (FIRST && !MORTON) {
 		if (gd.flag) bad |= mn[0] < gd.lo[0] || mn[1] < gd.lo[1] || mn[2] < gd.lo[2] || mx[0] > gd.hi[0] || mx[1] > gd.hi[1] || mx[2] > gd.hi[2];
 		if (gd.flag && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane_id() == 0) atomicOr(gd.flag, 1u);
+		if (gd.flag && gd.outside && __builtin_amdgcn_ballot_w64(n_outside != 0u) != 0ull) {   // (rare by construction: a handful of outliers)
+			const unsigned long long w = wave_sum_u64((unsigned long long)n_outside);
+			if (lane_id() == 0) atomicAdd(gd.outside, w);
+		}
 		// (partial sums spread over CHK_SLOTS cache lines: the L2 serialises atomics on one line, ~88 per microsecond, and ten thousand
 		//  waves adding to ONE word cost 0.12 ms at 10 M points)
 		if (gd.checksum) { chk = wave_sum_u64(chk); if (lane_id() == 0 && chk) atomicAdd(gd.checksum + (blockIdx.x % CHK_SLOTS) * CHK_STRIDE, chk); }

@@ -747,7 +747,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			for (int d = 0; d < 3; d++) { c->grid_lo[d] = lo[d]; c->grid_hi[d] = hi[d]; }
 			c->grid_r_max = r_max;
 			c->grid_variable = variable;
-			c->grid_valid = !trimmed;   // (a trimmed grid is laid out afresh every run: the outliers are outside its box by design)
+			c->grid_valid = true;
 			c->grid_trimmed = trimmed;
 			c->grid_gen++;
 		}
@@ -817,6 +817,13 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			for (int d = 0; d < 3; d++) { gd.lo[d] = c->grid_lo[d]; gd.hi[d] = c->grid_hi[d]; }
 			gd.r_max = c->grid_r_max;
 			gd.flag = reinterpret_cast<uint32_t*>(d_words);
+			if (c->grid_trimmed) {
+				// the grid covers the bulk of the points only: whoever is outside it is binned into its border cells (exact), so the box that
+				// must hold is the WORLD box (whose update needs the true bounds); the points outside the grid's own box are counted, and
+				// the grid is laid out afresh when they become many
+				for (int d = 0; d < 3; d++) { gd.soft_lo[d] = c->grid_lo[d]; gd.soft_hi[d] = c->grid_hi[d]; gd.lo[d] = c->world[d]; gd.hi[d] = c->world[3 + d]; }
+				gd.outside = d_words + tnsx::CHK_STRIDE;
+			}
 		}
 		if (cacheable) gd.checksum = d_words + WB * (size_t)(1 + si);
 		const int t1 = tm.mark();
@@ -1007,6 +1014,9 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	}
 	bool wrong = speculate && (h_words[0] & 0xffffffffull) != 0;   // a point left the box of the grid / a radius outgrew its cell edge
 	if (wrong) c->grid_valid = false;
+	// a reused trimmed grid: results are exact whatever lies outside it, but more than 0.2 % of the points in its border cells is the
+	// sign that the bulk has moved -- the next run lays the grid out afresh
+	if (speculate && c->grid_trimmed && h_words[tnsx::CHK_STRIDE] > (uint64_t)std::max<int64_t>(16, n_total >> 9)) c->grid_valid = false;
 	for (int si = 0; si < n_sets; si++) {
 		PointSet& s = c->sets[si];
 		const bool cacheable = !s.user_ids && s.n > 0;

@@ -46,6 +46,10 @@ struct BuildGuard {
 	float r_max = 3.402823466e+38f;
 	uint32_t* flag = nullptr;
 	unsigned long long* checksum = nullptr;
+	// a grid that covers the bulk of the points only (trim_box): lo / hi above are the WORLD box, and the points outside the grid's
+	// own box [soft_lo, soft_hi] are counted -- they are binned into its border cells, which is exact but slow if they become many
+	float soft_lo[3] = { 0.f, 0.f, 0.f }, soft_hi[3] = { 0.f, 0.f, 0.f };
+	unsigned long long* outside = nullptr;
 };
 // ids != nullptr (tnsx_set_point_ids): the sorted points carry ids[original index] instead of the original index (that is what
 // the query emits), and orig_sorted[sorted position] receives the original index.
