@@ -29,11 +29,12 @@ for path in args.libs:
     for (i, j) in pairs: ns.set_active_search(i, j, True)
     for _ in range(3): ns.run()
     engines.append(ns)
-acc = [dict(fill=[], sort=[], total=[], retries=0) for _ in engines]
+import time
+acc = [dict(fill=[], sort=[], total=[], wall=[], retries=0) for _ in engines]
 for r in range(args.rounds):
     for k, ns in enumerate(engines):
         for _ in range(args.steps):
-            ns.run(); st = ns.get_stats()
+            t_w = time.perf_counter(); ns.run(); acc[k]["wall"].append((time.perf_counter() - t_w) * 1e3); st = ns.get_stats()
             acc[k]["fill"].append(st["ms_fill"]); acc[k]["sort"].append(st["ms_sort"]); acc[k]["total"].append(st["ms_total"]); acc[k]["retries"] += st.get("pool_retries", 0)
 for path, a in zip(args.libs, acc):
-    print(f"{os.path.basename(path):28s} fill med {np.median(a['fill']):.4f} min {np.min(a['fill']):.4f} | sort med {np.median(a['sort']):.4f} | total med {np.median(a['total']):.4f} min {np.min(a['total']):.4f} | pool retries {a['retries']}")
+    print(f"{os.path.basename(path):28s} fill med {np.median(a['fill']):.4f} min {np.min(a['fill']):.4f} | sort med {np.median(a['sort']):.4f} | total med {np.median(a['total']):.4f} min {np.min(a['total']):.4f} | wall med {np.median(a['wall']):.4f} | pool retries {a['retries']}")
