@@ -118,6 +118,7 @@ struct PairResult {
 	// pool mode: `records` is cut into one region per XCD + the common overflow region (tnsx_query.hip, PoolState)
 	static constexpr int NR = tnsx::POOL_REGIONS + 1;
 	uint64_t region_payload[NR] = { 0 };   // ints of records the waves of XCD r produced in the previous run
+	uint64_t region_asked[NR] = { 0 };     // ints they asked their region for (records + the unused ends of their slabs); 0: not known for the current slab size
 	uint64_t region_base[NR] = { 0 }, region_cap[NR] = { 0 }, region_used[NR] = { 0 };
 	bool shared_empty = false;   // int 0 of `records` is the empty record every list without a candidate points at
 	bool dry = false;            // this pass only counts (first run of a pair: nothing is known about its size yet)
@@ -878,6 +879,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		a.heavy = pr.heavy.as<uint2>();
 		a.heavy2 = pr.heavy2.as<uint2>();
 		a.pool_slab = pr.pool_slab;
+		a.pool_slab_heavy = std::max<uint32_t>(pr.pool_slab, 4096u);
 		a.shared_empty = jb.pool && jb.i != jb.j ? 1u : 0u;
 		if (a.shared_empty && pr.n_query > 0) {
 			// the query walks the cells that have candidates at all (launch_mark_cells + launch_filter_marked, enqueued by launch_pool)
@@ -935,12 +937,15 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		return TNSX_OK;
 	};
 
-	// slab size, regions and record storage of a pool pass whose regions are expected to receive payload[r] ints of records (nullptr: dry
-	// pass).  generous: the common region can take EVERYTHING (the redo of a pass that overflowed must not overflow again).
-	auto size_pool = [&](PairResult& pr, const uint64_t* payload, bool generous) -> tnsx_status {
+	// slab size, regions and record storage of a pool pass.  payload[r]: ints of records region r is expected to receive (nullptr: dry
+	// pass); asked[r]: what the waves asked region r for in the previous pass with the same slab size -- records plus the unused ends
+	// of their slabs, which is what the region has to hold (nullptr after a dry pass, whose slabs have another size: the regions then
+	// get a quarter / a half more than the records need).  generous: the common region can take EVERYTHING (the redo of a pass that
+	// overflowed must not overflow again).
+	auto size_pool = [&](PairResult& pr, const uint64_t* payload, const uint64_t* asked, bool generous) -> tnsx_status {
 		for (int r = 0; r < PairResult::NR; r++) { pr.region_base[r] = 0; pr.region_cap[r] = 0; pr.region_used[r] = 0; }
 		if (!payload) {
-			pr.pool_slab = 16384;   // nothing is written, big slabs keep the cursor atomics rare (256-int slabs: 32 ms at 10 M points)
+			pr.pool_slab = 16384;   // nothing is written, big slabs keep the cursor atomics rare
 			HIPCHK(c, pr.records.reserve(1024 * sizeof(int)));
 			return TNSX_OK;
 		}
@@ -948,17 +953,26 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		for (int r = 0; r < PairResult::NR; r++) total += payload[r];
 		const uint64_t expect = total + total / 8 + 1024;
 		// a wave's last slab stays half empty on average: slabs of 1/8 of a wave's share keep the holes at ~6 % of the pool
-		const uint64_t slab = std::min<uint64_t>(16384, std::max<uint64_t>(256, expect / ((uint64_t)query_waves * 8)));
+		uint64_t slab = std::min<uint64_t>(16384, std::max<uint64_t>(256, expect / ((uint64_t)query_waves * 8)));
+		// (the holes depend on the slab size: the previous size is kept while it is within an eighth of the ideal one)
+		if (asked && slab >= (uint64_t)pr.pool_slab - pr.pool_slab / 8 && slab <= (uint64_t)pr.pool_slab + pr.pool_slab / 8) slab = pr.pool_slab;
+		if (asked && slab != pr.pool_slab) asked = nullptr;
 		pr.pool_slab = (uint32_t)slab;
+		const uint64_t slab_heavy = std::max<uint64_t>(slab, 4096);
 		// (a wave takes a slab only if it gets a cell: small sets keep small pools)
 		const uint64_t waves_all = std::min<uint64_t>((uint64_t)query_waves, (uint64_t)pr.n_i + 8);
 		const uint64_t waves_x = std::min<uint64_t>((uint64_t)query_waves / tnsx::POOL_REGIONS, (uint64_t)pr.n_i / tnsx::POOL_REGIONS + 2);
+		// (a cell of the heavy tiers has at least ~19 points and every one of them gets a record)
+		const uint64_t waves_heavy = std::min<uint64_t>(std::min<uint64_t>((uint64_t)query_waves, (uint64_t)pr.n_i / 16 + 8), payload[tnsx::POOL_OVERFLOW] / 16 + 8);
 		uint64_t first = pr.shared_empty ? 64 : 0;
 		for (int r = 0; r < PairResult::NR; r++) {
-			// a region of the fast tier: what its XCD produced last time + 6 % + a slab per wave;
-			// the common region: what the heavy tiers produced + 6 % + a slab per wave of a launch + 6 % of everything (fast-tier overflow)
-			uint64_t cap = payload[r] + payload[r] / 16 + 1024 + (r < tnsx::POOL_REGIONS ? waves_x * slab : expect / 16 + waves_all * slab);
-			if (generous && r == tnsx::POOL_OVERFLOW) cap += expect;
+			const bool common = r == tnsx::POOL_OVERFLOW;
+			uint64_t cap;
+			// steady state: what was asked for last time + 6 % (the common region: + 6 % of everything, for what the others cannot hold);
+			// after a dry pass: the records + a quarter (the common region: a half) + a slab per wave that can get a cell
+			if (asked) cap = asked[r] + asked[r] / 16 + 1024 + (common ? expect / 16 + 4096 : 0);
+			else cap = payload[r] + payload[r] / (common ? 2 : 4) + 1024 + (common ? expect / 16 + waves_heavy * slab_heavy : waves_x * slab);
+			if (generous && common) cap += expect + waves_all * slab_heavy;
 			pr.region_base[r] = first; pr.region_cap[r] = cap;
 			first = (first + cap + 63) & ~(uint64_t)63;
 		}
@@ -979,7 +993,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			// handling below turns into a real pass of the right size.
 			pr.dry = pr.need_hint == 0;
 			pr.shared_empty = jb.i != jb.j && pr.n_query > 0;
-			{ const tnsx_status r = size_pool(pr, pr.dry ? nullptr : pr.region_payload, false); if (r != TNSX_OK) return r; }
+			{ const tnsx_status r = size_pool(pr, pr.dry ? nullptr : pr.region_payload, pr.region_asked[0] || pr.region_asked[tnsx::POOL_OVERFLOW] ? pr.region_asked : nullptr, false); if (r != TNSX_OK) return r; }
 			// worklists of the cells the fast / fat kernels pass on (at most one entry per occupied cell)
 			const size_t max_cells = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_i, n_cells));
 			HIPCHK(c, pr.heavy.reserve(max_cells * sizeof(uint2)));
@@ -1041,11 +1055,12 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			// what every XCD produced: ints it asked for - ints it left unused.  The pass failed if a wave found both its own region and the
 			// overflow region full (or if it was a dry pass): size the pool by what was counted and redo this pair's pass.
 			const uint64_t* hc = h_ctrl + HC * k;
-			uint64_t payload[PairResult::NR];
+			uint64_t payload[PairResult::NR], asked_now[PairResult::NR];
 			auto read_counters = [&]() {
 				n_neighbors = 0;
 				for (int r = 0; r < PairResult::NR; r++) {
 					const uint64_t asked = hc[(size_t)r * tnsx::POOL_CTRL_WORDS];
+					asked_now[r] = asked;
 					// (the common region: what the heavy tiers asked for + what fast-tier waves were diverted to it, the latter counted in their
 					//  own region as well -- a harmless overestimate in the rare run where a region was full)
 					payload[r] = asked - std::min(asked, hc[(size_t)r * tnsx::POOL_CTRL_WORDS + tnsx::POOL_WASTE_WORD]);
@@ -1062,7 +1077,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 					                                            (unsigned long long)hc[(size_t)tnsx::POOL_OVERFLOW * tnsx::POOL_CTRL_WORDS], (unsigned long long)pr.region_cap[tnsx::POOL_OVERFLOW], pr.pool_slab, pr.n_i);
 					S.pool_retries++;
 				}
-				{ const tnsx_status r = size_pool(pr, payload, !was_dry); if (r != TNSX_OK) return r; }
+				{ const tnsx_status r = size_pool(pr, payload, was_dry ? nullptr : asked_now, !was_dry); if (r != TNSX_OK) return r; }
 				const tnsx_status r = launch_pool(k);
 				if (r != TNSX_OK) return r;
 				HIPCHK(c, hipStreamSynchronize(st));
@@ -1072,6 +1087,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			uint64_t sum = 0;
 			for (int r = 0; r < PairResult::NR; r++) {
 				pr.region_payload[r] = payload[r];
+				pr.region_asked[r] = asked_now[r];
 				sum += payload[r];
 				pr.region_used[r] = c->debug_nostore ? 0 : std::min<uint64_t>(hc[(size_t)r * tnsx::POOL_CTRL_WORDS], pr.region_cap[r]);
 				if (pr.region_used[r]) pr.n_records = std::max(pr.n_records, pr.region_base[r] + pr.region_used[r]);

@@ -90,6 +90,8 @@ struct QueryArgs {
 	                                         // waves whose own region was full); [+ POOL_HITS_WORD] neighbour indices emitted, [+ POOL_WASTE_WORD] slab ints left unused
 	const unsigned long long* pool_regions;  // device table: {first int, capacity in ints} of region 0..POOL_OVERFLOW (all capacities 0: a dry pass that only counts)
 	uint32_t pool_slab;                      // ints a wave takes from a cursor per atomic (fast tier: its XCD's region; fat and general tier: region POOL_OVERFLOW)
+	uint32_t pool_slab_heavy;                // the same for the fat and the general tier (their records are several hundred ints long: slabs of the first tier's
+	                                         // size for a small set would be half empty)
 	uint32_t* tickets;                 // ticket counters of the fast kernel: tickets[(xcd * CTRL_SUBRANGES + piece) * CTRL_STRIDE_U32] (zeroed before the launch)
 	uint2* heavy;                      // worklist {first sorted position, key} of the cells the fast kernel skipped
 	uint32_t* n_heavy;                 // its length (zeroed before the launch)

@@ -241,7 +241,8 @@ __device__ __forceinline__ uint64_t pool_alloc(const QueryArgs& a, PoolState& ps
 	(void)lane;
 	if (len > ps.left) {
 		pool_waste(ps, ps.left);
-		const uint32_t sz = len > a.pool_slab ? len : a.pool_slab;
+		const uint32_t slab = HEAVY ? a.pool_slab_heavy : a.pool_slab;
+		const uint32_t sz = len > slab ? len : slab;
 		const unsigned long long first = pool_take_slab(a.pool_cursor, a.pool_regions, sz, HEAVY ? 1u : 0u);
 		ps.cur_lo = readfirstlane_u32((uint32_t)first);
 		ps.cur_hi = readfirstlane_u32((uint32_t)(first >> 32));
@@ -691,7 +692,8 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 			// rare: new slab (one atomic on the global cursor).  The queries so far refer to the old base: write them out first.
 			flush(t);
 			pool_waste(ps, left);
-			const uint32_t sz = len > a.pool_slab ? len : a.pool_slab;
+			const uint32_t slab = NC > 8 ? a.pool_slab_heavy : a.pool_slab;
+			const uint32_t sz = len > slab ? len : slab;
 			const unsigned long long first = pool_take_slab(a.pool_cursor, a.pool_regions, sz, NC > 8 ? 1u : 0u);   // (more than 8 chunks: the fat tier)
 			base = ((uint64_t)readfirstlane_u32((uint32_t)(first >> 32)) << 32) | readfirstlane_u32((uint32_t)first);
 			ok = base != POOL_NONE ? 1u : 0u;
