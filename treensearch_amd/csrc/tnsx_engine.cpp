@@ -962,8 +962,8 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		// (a wave takes a slab only if it gets a cell: small sets keep small pools)
 		const uint64_t waves_all = std::min<uint64_t>((uint64_t)query_waves, (uint64_t)pr.n_i + 8);
 		const uint64_t waves_x = std::min<uint64_t>((uint64_t)query_waves / tnsx::POOL_REGIONS, (uint64_t)pr.n_i / tnsx::POOL_REGIONS + 2);
-		// (a cell of the heavy tiers has at least ~19 points and every one of them gets a record)
-		const uint64_t waves_heavy = std::min<uint64_t>(std::min<uint64_t>((uint64_t)query_waves, (uint64_t)pr.n_i / 16 + 8), payload[tnsx::POOL_OVERFLOW] / 16 + 8);
+		// (a wave of the heavy tiers that gets a cell writes at least a handful of records; should this ever be too little, the pass is repeated)
+		const uint64_t waves_heavy = std::min<uint64_t>(std::min<uint64_t>((uint64_t)query_waves, (uint64_t)pr.n_i / 4 + 8), payload[tnsx::POOL_OVERFLOW] / 16 + 8);
 		uint64_t first = pr.shared_empty ? 64 : 0;
 		for (int r = 0; r < PairResult::NR; r++) {
 			const bool common = r == tnsx::POOL_OVERFLOW;
