@@ -72,8 +72,13 @@ namespace tns
 			ok_(tnsx_run(ctx_));
 			refresh_views_();
 		}
-		/** The reference's scalar twin (double accumulation) is not a separate code path here. */
-		void run_scalar() { run(); }
+		/** The reference's scalar twin (double accumulation) is not a separate code path here; its world box is
+		 *  (TreeNSearch.cpp:415-522: the tight box, without the origin that run()'s SIMD remainder loop adds). */
+		void run_scalar()
+		{
+			ok_(tnsx_run_scalar(ctx_));
+			refresh_views_();
+		}
 
 		NeighborList get_neighborlist(const int set_i, const int set_j, const int point_i) const
 		{

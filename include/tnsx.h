@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TNSX_VERSION 201
+#define TNSX_VERSION 300
 
 typedef struct tnsx_context tnsx_context;
 
@@ -79,7 +79,11 @@ typedef struct tnsx_options {
 	int temporal_reuse;       /* 1 (default): a run lays the previous run's search grid over the points without computing their bounds
 	                             first, and point sets whose input did not change keep their sorted arrays and cell table; both are
 	                             verified on the device during the run and the run is repeated when an assumption was wrong (the
-	                             reference's own reuse, TreeNSearch.cpp:474-482 and :77-79).  0: bounds and full build every run */
+	                             reference's own reuse, TreeNSearch.cpp:474-482 and :77-79).  0: bounds and full build every run.
+	                             Guarantee: grid reuse is verified exactly (every point is tested against the box).  "Input did not
+	                             change" is decided by pointer + size + a 64-bit order-sensitive checksum of the set's raw bits that
+	                             the device recomputes every run: a changed set whose checksum collides (probability ~2^-64 per run
+	                             for unrelated inputs) would keep stale lists.  Callers that need a deterministic guarantee set 0 */
 	int sorted_lists;         /* 1: every neighbour list is put into ascending index order after the query (one wave per record, bitonic
 	                             network), as the reference's lists are by construction (TreeNSearch.cpp:2474-2500) -- sums over
 	                             neighbours are then evaluated in the same order as on the CPU.  0 (default): order unspecified */
@@ -89,7 +93,10 @@ typedef struct tnsx_options {
 	                             bounds drop-in mode.  Device pointers, device views and the tnsx_halo_pack family are not available on
 	                             such a context.  0 / 1: single device (device_id) */
 	int device_ids[8];        /* HIP device ordinals of the n_devices engines (an ordinal may repeat: several engines on one GPU) */
-	int reserved[4];
+	int query_blocks_per_cu;  /* tuning: workgroups per CU of the general query kernel (1..16); 0 = default (7) */
+	int fast_blocks_per_cu;   /* tuning: workgroups per CU of the fast pool kernels (1..16); 0 = default (8).  Both are fixed at tnsx_create:
+	                             nothing in the launch path reads the environment */
+	int reserved[2];
 } tnsx_options;
 
 /* Neighbour lists of one active (set_i -> set_j) pair.  Record layout == the reference's chunk storage
@@ -177,6 +184,11 @@ uint64_t    tnsx_get_neighborlist_n_bytes(const tnsx_context* ctx);      /* Tree
  * Synchronous like the reference: when it returns the lists are complete (in HBM, and in pinned host
  * memory when mirror_to_host). */
 tnsx_status tnsx_run(tnsx_context* ctx);
+/* run_scalar() (TreeNSearch.cpp:150-160).  Same device path and the same neighbour sets as tnsx_run -- the reference's scalar
+ * kernel accumulates the distance in double (TreeNSearch.cpp:2080-2087) and is not a parity target, see DESIGN.md section 2 --
+ * but the WORLD BOX follows _update_world_AABB (:415-522: the tight box), where tnsx_run follows _update_world_AABB_simd
+ * (:523-645: the tight box united with the origin, an artefact of its zero-padded remainder loop :564-569). */
+tnsx_status tnsx_run_scalar(tnsx_context* ctx);
 /* get_neighborlist() backing store (TreeNSearch.cpp:241-249).  Views stay valid until the next tnsx_run. */
 tnsx_status tnsx_get_pair_view(tnsx_context* ctx, int set_i, int set_j, tnsx_csr_view* out);
 /* mirrors one pair to pinned host memory on demand (no-op when already mirrored) */

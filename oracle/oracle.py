@@ -64,6 +64,7 @@ class Oracle:
         L.tnso_world_box_update.restype = C.c_int
         L.tnso_world_box_update.argtypes = [_f32p, _f32p, C.c_float, _i32p]
         L.tnso_tight_bounds.argtypes = [_f32p, C.c_int, _f32p]
+        L.tnso_tight_bounds_simd.argtypes = [_f32p, C.c_int, _f32p]
         L.tnso_zsort_keys.argtypes = [_f32p, C.c_int, _f32p, C.c_float, _u64p]
         L.tnso_zsort_order.argtypes = [_f32p, C.c_int, _f32p, C.c_float, _i32p]
         L.tnso_check_zsort.restype = C.c_int
@@ -113,12 +114,13 @@ class Oracle:
                                             C.c_float(cell_size), C.byref(n))
         return rc, n.value
 
-    def tight_bounds(self, x, tight=None):
+    def tight_bounds(self, x, tight=None, simd=False):
+        """simd=False: run_scalar()'s tight box; simd=True: what run() / prepare_zsort() compute (tight box united with the origin)."""
         if tight is None:
             fm = np.finfo(np.float32).max
             tight = np.array([fm, fm, fm, -fm, -fm, -fm], np.float32)
         x = np.ascontiguousarray(x, np.float32).reshape(-1, 3)
-        self.lib.tnso_tight_bounds(_p(x, _f32p), len(x), _p(tight, _f32p))
+        (self.lib.tnso_tight_bounds_simd if simd else self.lib.tnso_tight_bounds)(_p(x, _f32p), len(x), _p(tight, _f32p))
         return tight
 
     def zsort_keys(self, x, bottom, cell_size_inv):
@@ -202,6 +204,9 @@ def _load_ref(strict: bool):
     L.ref_tns_get_n_points_in_set.argtypes = [vp, C.c_int]
     L.ref_tns_is_search_active.argtypes = [vp, C.c_int, C.c_int]
     L.ref_tns_get_zsort_order.argtypes = [vp, C.c_int, _i32p]
+    L.ref_tns_get_world_box.argtypes = [vp, _f32p]
+    L.ref_tns_get_cell_size.argtypes = [vp]
+    L.ref_tns_get_cell_size.restype = C.c_float
     L.ref_tns_apply_zsort_f.argtypes = [vp, C.c_int, _f32p, C.c_int]
     L.ref_tns_apply_zsort_i.argtypes = [vp, C.c_int, _i32p, C.c_int]
     L.ref_tns_apply_zsort_d.argtypes = [vp, C.c_int, _f64p, C.c_int]
@@ -286,6 +291,15 @@ class RefTreeNSearch:
     def run_scalar(self): self.L.ref_tns_run_scalar(self.h)
     def prepare_zsort(self): self.L.ref_tns_prepare_zsort(self.h)
     def get_n_points_in_set(self, s): return self.L.ref_tns_get_n_points_in_set(self.h, s)
+
+    def get_world_box(self):
+        """{bottom[3], top[3]} of the reference's private world box (TreeNSearch.h:400)."""
+        out = np.zeros(6, np.float32)
+        self.L.ref_tns_get_world_box(self.h, _p(out, _f32p))
+        return out
+
+    def get_cell_size(self):
+        return np.float32(self.L.ref_tns_get_cell_size(self.h))
 
     def get_zsort_order(self, s):
         out = np.zeros(max(self.get_n_points_in_set(s), 1), np.int32)

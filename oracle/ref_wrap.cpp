@@ -8,12 +8,28 @@
 // by oracle/Makefile into oracle/_ref/libtns_ref*.so (git-ignored, travels to the GPU box).
 //
 // Interfaces wrapped: TreeNSearch.h:28-427 (public API), BruteforceNSearch.h:17-51.
-#include <TreeNSearch>
-#include "BruteforceNSearch.h"
-
+// The world box (domain_float, TreeNSearch.h:400) and the cell size (:398) are private members with no getter; the accessors
+// at the end of this file read them.  Every standard header the reference pulls in is included FIRST, so that the keyword
+// override below touches the reference's own class declarations only (same layout, same code: an access specifier changes
+// neither), in this one translation unit.
+#include <algorithm>
+#include <array>
+#include <cassert>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <iostream>
+#include <limits>
+#include <numeric>
+#include <string>
 #include <vector>
+#include <immintrin.h>
+#include <malloc.h>
+#include <omp.h>
+#define private public
+#include <TreeNSearch>
+#undef private
+#include "BruteforceNSearch.h"
 
 extern "C" {
 
@@ -89,6 +105,14 @@ void ref_tns_get_lists(void* h, int i, int j, const int64_t* offsets, int* indic
 		if (sort_each) std::sort(dst, dst + nl.size());
 	}
 }
+
+// private state (see the note at the includes): world box {bottom[3], top[3]} (TreeNSearch.h:400, updated by
+// _update_world_AABB[_simd], TreeNSearch.cpp:415-645) and the grid cell size (TreeNSearch.h:398)
+void ref_tns_get_world_box(void* h, float* out6)
+{
+	for (int d = 0; d < 3; d++) { out6[d] = TNS(h)->domain_float.bottom[d]; out6[3 + d] = TNS(h)->domain_float.top[d]; }
+}
+float ref_tns_get_cell_size(void* h) { return TNS(h)->cell_size; }
 
 // ----------------------------------------------------------------------------- BruteforceNSearch
 void* ref_bf_create() { return new BruteforceNSearch(); }

@@ -314,6 +314,23 @@ void tnso_tight_bounds(const float* x, int n, float* tight)
 	}
 }
 
+/* Tight bounds as run() -- the AVX2 path -- sees them (TreeNSearch.cpp:523-592, _update_world_AABB_simd).  Every thread takes
+ * its points two at a time as [x y z x y z . .] (:558-562) and the LAST 2..3 points of its chunk one at a time as
+ * [x y z 0 0 0 0 0] (:564-569, _mm256_setr_ps with zeros): the zeros sit in lanes 3..5, which the final reduction folds into
+ * the result (:587-590: min(b[d], b[3 + d]), max(t[d], t[3 + d])).  A thread with at least one point always takes the
+ * remainder loop (the pair loop stops at end - 3), and at least one thread has points whenever the set has any.  So the
+ * "tight" box of run() and of the no-tree path of prepare_zsort() (:2674) is the tight box of the points UNITED WITH THE
+ * ORIGIN; run_scalar() (:415-472) has no such padding and uses tnso_tight_bounds.  Pinned against the reference itself by
+ * tests/golden (world blocks) and tests/test_oracle_golden.py. */
+void tnso_tight_bounds_simd(const float* x, int n, float* tight)
+{
+	tnso_tight_bounds(x, n, tight);
+	if (n > 0) for (int d = 0; d < 3; d++) {
+		if (0.0f < tight[d]) tight[d] = 0.0f;
+		if (0.0f > tight[3 + d]) tight[3 + d] = 0.0f;
+	}
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* z-sort                                                                                     */
 /*   cell coords: (uint)((p - bottom) * cell_size_inv)  fp32 sub, mul, truncate (TNS.cpp:713)  */

@@ -161,8 +161,17 @@ def large_cases() -> List[Case]:
     ]
 
 
+_SMALL_CACHE: List[Case] = []
+
+
 def by_name(name: str) -> Case:
-    for c in small_cases() + large_cases():
+    # (the small cases first, built once: large_cases() generates the 10 M cloud)
+    if not _SMALL_CACHE:
+        _SMALL_CACHE.extend(small_cases())
+    for c in _SMALL_CACHE:
+        if c.name == name:
+            return c
+    for c in large_cases():
         if c.name == name:
             return c
     raise KeyError(name)

@@ -138,20 +138,107 @@ def make(case: CS.Case, orc: O.Oracle) -> dict:
             }
         fx["checked_against"] = checked + ["oracle/tns_oracle.c"]
     fx["modes_differ"] = any(e["strict"]["digest_sum"] != e["contracted"]["digest_sum"] for e in fx["pairs"].values())
+    fx["world"] = make_world(case, orc)
     fx["generated_in_s"] = round(time.time() - t0, 2)
     return fx
+
+
+def _fresh_reference(case: CS.Case, strict: bool):
+    ref = O.RefTreeNSearch(strict=strict)
+    variable = case.radii is not None
+    if not variable:
+        ref.set_search_radius(case.radius)
+    pts = [np.ascontiguousarray(p.copy()) for p in case.points]
+    rad = [np.ascontiguousarray(r.copy()) for r in case.radii] if variable else [None] * len(pts)
+    for p, r in zip(pts, rad):
+        ref.add_point_set(p, r)
+    for (i, j) in case.active:
+        ref.set_active_search(i, j, True)
+    ref.set_symmetric_search(case.symmetric)
+    return ref, pts
+
+
+def _hex(a):
+    return [float(v).hex() for v in np.asarray(a, np.float32)]
+
+
+def fine_zsort_cell(world_size: np.float32, cell: np.float32) -> np.float32:
+    """quantisation step of the no-tree z-sort, TreeNSearch.cpp:2686-2690 (fp32 throughout)"""
+    cell = np.float32(cell)
+    while np.float32(world_size) / np.float32(cell / np.float32(2.0)) < np.float32(2097151):
+        cell = np.float32(cell / np.float32(2.0))
+    return cell
+
+
+def make_world(case: CS.Case, orc: O.Oracle) -> dict:
+    """The reference's PRIVATE world box (TreeNSearch.h:400, read through oracle/ref_wrap.cpp) after each of the three entry
+    points that update it, on a fresh instance over the case's points as generated:
+      run          run()           -> _update_world_AABB_simd (TreeNSearch.cpp:523-645)
+      run_scalar   run_scalar()    -> _update_world_AABB      (:415-522)
+      zsort        prepare_zsort() -> no-tree path, _update_world_AABB_simd (:2671-2674)
+    Asserts on the way: both builds of the reference agree; the oracle's restatement reproduces every box bit for bit; the
+    reference's z-sort order is Morton-monotone under the oracle's keys on the REFERENCE's box, on both z-sort paths."""
+    fm = np.finfo(np.float32).max
+    out = {}
+    for path in ("run", "run_scalar", "zsort"):
+        if path != "zsort" and not case.tns_ok:
+            continue      # (outside the octree's valid regime only the box of prepare_zsort is taken: it never builds the tree)
+        boxes = []
+        for strict in (False, True):
+            ref, pts = _fresh_reference(case, strict)
+            getattr(ref, "prepare_zsort" if path == "zsort" else path)()
+            box, cell = ref.get_world_box(), ref.get_cell_size()
+            boxes.append(box)
+            n_total = sum(len(p) for p in pts)
+            # -- the oracle's restatement
+            tight = np.array([fm, fm, fm, -fm, -fm, -fm], np.float32)
+            for p in pts:
+                orc.tight_bounds(np.asarray(p, np.float32), tight, simd=(path != "run_scalar"))
+            obox = np.array([fm, fm, fm, -fm, -fm, -fm], np.float32)
+            n_pow2 = 0
+            if n_total > 0:
+                rc, n_pow2 = orc.world_box_update(obox, tight, cell)
+                assert rc == 1
+            assert np.array_equal(obox, box), f"{case.name} {path}: oracle world box != reference"
+            # -- the reference's z-sort order under the oracle's keys, on the reference's box
+            if n_total > 0 and path == "zsort":
+                inv = np.float32(1.0) / fine_zsort_cell(box[3] - box[0], cell)
+                for s, p in enumerate(pts):
+                    keys = orc.zsort_keys(np.asarray(p, np.float32), box[:3], inv)
+                    assert orc.check_zsort(keys, ref.get_zsort_order(s)) == 0, f"{case.name}: no-tree z-sort of set {s} not Morton-ordered"
+            if n_total > 0 and path == "run":
+                ref.prepare_zsort()                    # tree path (:2595-2660): cells ordered by the 32-bit code of their coordinates
+                assert np.array_equal(ref.get_world_box(), box)
+                inv = np.float32(1.0) / cell
+                for s, p in enumerate(pts):
+                    keys = orc.zsort_keys(np.asarray(p, np.float32), box[:3], inv)
+                    assert orc.check_zsort(keys, ref.get_zsort_order(s)) == 0, f"{case.name}: tree z-sort of set {s} not Morton-ordered"
+        assert np.array_equal(boxes[0], boxes[1]), f"{case.name} {path}: the two reference builds disagree on the world box"
+        out[path] = {"bottom": _hex(boxes[0][:3]), "top": _hex(boxes[0][3:]), "cells_pow2": int(n_pow2), "cell_size": float(cell).hex()}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--large", action="store_true", help="also (re)generate the medium/large digest fixtures")
     ap.add_argument("--only", default=None)
+    ap.add_argument("--world-only", action="store_true", help="only (re)write the `world` block of the existing fixtures")
     args = ap.parse_args()
     assert O.have_ref(), "oracle/_ref missing: run `make -C oracle ref` (needs /root/reference)"
     orc = O.Oracle()
     todo = CS.small_cases() + (CS.large_cases() if args.large else [])
     for case in todo:
         if args.only and args.only not in case.name:
+            continue
+        if args.world_only:
+            path = os.path.join(HERE, case.name + ".json")
+            with open(path) as f:
+                fx = json.load(f)
+            t0 = time.time()
+            fx["world"] = make_world(case, orc)
+            with open(path, "w") as f:
+                json.dump(fx, f, separators=(",", ":"))
+            print(f"{case.name}: world {fx['world'].get('run', fx['world']['zsort'])['cells_pow2']} cells, {time.time() - t0:.1f} s", flush=True)
             continue
         if case.size_class != "small":
             case.full_lists = min(case.full_lists, 64)

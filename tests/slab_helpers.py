@@ -66,8 +66,20 @@ class LocalTransport:
 
     def __init__(self, world: int, timeout: float = 120.0):
         import queue
+        import threading
         self.q = {(s, d): queue.Queue() for s in range(world) for d in range(world) if abs(s - d) == 1}
         self.timeout = timeout
+        self.world = world
+        self._flags = [False] * world
+        self._barrier = threading.Barrier(world)
+
+    def any_flag(self, rank, flag):
+        """all-reduce(max) of one flag over the emulated ranks (what SlabSearch uses torch.distributed for otherwise)"""
+        self._flags[rank] = bool(flag)
+        self._barrier.wait(timeout=self.timeout)
+        out = any(self._flags)
+        self._barrier.wait(timeout=self.timeout)     # nobody overwrites its flag before everybody has read
+        return out
 
     def round_trip(self, rank, peers, out_msgs, in_msgs):
         for p in peers:

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(built_library):
 def test_version(built_library):
     from treensearch_amd import api
     L = api.load_library()
-    assert L.tnsx_version() == 201   # TNSX_VERSION of include/tnsx.h (round 2: slab support entry points; 201: tnsx_stats.grid_trimmed)
+    assert L.tnsx_version() == 300   # TNSX_VERSION of include/tnsx.h (round 3: tnsx_run_scalar, slab layer behind the C ABI)
 
 
 def test_no_cpu_fallback(built_library):
@@ -57,6 +57,17 @@ def test_product_never_touches_the_oracle():
                             if re.search(r"(import|include|CDLL|dlopen).*oracle", line):
                                 bad.append((f, line.strip()))
     assert not bad, bad
+
+
+def test_no_environment_switches_in_the_engine():
+    """Nothing in the engine's sources reads the environment: no run-time switch can make a timed pass skip work or change a
+    launch (the store-free pool pass is a compile-time variant for tools/, the launch widths are tnsx_options fields).  The C++
+    shim reads TNSX_DEVICES once, in its constructor -- the only way a drop-in user who cannot touch the call site can ask for
+    the multi-device mode."""
+    for dp, _, files in os.walk(os.path.join(ROOT, "treensearch_amd", "csrc")):
+        for f in files:
+            txt = open(os.path.join(dp, f), errors="ignore").read()
+            assert "getenv" not in txt, f"{f} reads the environment"
 
 
 def test_cpp_shim_compiles(built_library, tmp_path):

@@ -293,7 +293,7 @@ def test_grid_and_world_box_follow_the_tight_bounds(n, on_device, oracle):
     st = ns.get_stats()
     tight = np.concatenate([pts.min(axis=0), pts.max(axis=0)]).astype(np.float32)
     box = np.array([np.finfo(np.float32).max] * 3 + [-np.finfo(np.float32).max] * 3, np.float32)    # the empty box every engine starts with
-    rc, n_pow2 = oracle.world_box_update(box, tight, np.float32(1.5) * r)
+    rc, n_pow2 = oracle.world_box_update(box, oracle.tight_bounds(pts, simd=True), np.float32(1.5) * r)   # (run(): tight box + origin)
     assert rc == 1                                           # (1: the box was replaced)
     assert np.array_equal(np.array(st["world_bottom"] + st["world_top"], np.float32), box) and st["world_cells_pow2"] == n_pow2
     h = float(st["grid_cell_size"])
@@ -443,3 +443,91 @@ def test_zsort_resolution_follows_the_reference(oracle):
     assert np.all(np.diff(order)[same] > 0), "points of one cell must keep their order"
     ns.prepare_zsort()                                   # twice in a row: the cells are gone again (TreeNSearch.cpp:2659-2660)
     assert np.float32(ns.get_stats()["zsort_cell_size_inv"]) == inv_fine
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# World box and z-sort grid against the REFERENCE's private world box (the `world` block of every fixture: domain_float read through
+# oracle/ref_wrap.cpp after run() / run_scalar() / prepare_zsort() on a fresh instance; tests/golden/make_golden.py::make_world).
+# ---------------------------------------------------------------------------------------------------------------------
+def _fixture_box(w):
+    return np.array([float.fromhex(v) for v in w["bottom"] + w["top"]], np.float32)
+
+
+_WORLD_CASES = [c for c in CS.small_cases() if c.n_total() > 0]
+
+
+@pytest.mark.parametrize("case", _WORLD_CASES, ids=[c.name for c in _WORLD_CASES])
+def test_world_box_and_zsort_grid_equal_the_references(case, oracle):
+    from conftest import load_golden
+    world = load_golden(case.name)["world"]
+
+    def engine_box(ns):
+        st = ns.get_stats()
+        return np.array(st["world_bottom"] + st["world_top"], np.float32), st
+
+    # -- prepare_zsort() on a fresh engine: the no-tree path (TreeNSearch.cpp:2671-2699) -> box of the SIMD bounds, refined grid
+    ns = P.make_engine(case, 0)
+    ns.prepare_zsort()
+    box, st = engine_box(ns)
+    w = world["zsort"]
+    assert np.array_equal(box, _fixture_box(w)), f"prepare_zsort: {box} != {_fixture_box(w)}"
+    assert st["world_cells_pow2"] == w["cells_pow2"]
+    cell = np.float32(float.fromhex(w["cell_size"]))
+    fine = cell
+    while np.float32(box[3] - box[0]) / np.float32(fine / np.float32(2.0)) < np.float32(2097151):
+        fine = np.float32(fine / np.float32(2.0))
+    assert np.float32(st["zsort_cell_size_inv"]) == np.float32(1.0) / fine
+    for s, p in enumerate(case.points):
+        if len(p):
+            keys = oracle.zsort_keys(np.asarray(p, np.float32), _fixture_box(w)[:3], np.float32(1.0) / fine)   # keys on the FIXTURE's box
+            assert oracle.check_zsort(keys, ns.get_zsort_order(s)) == 0
+    if not case.tns_ok:
+        return
+    # -- run() on a fresh engine: _update_world_AABB_simd (:523-645), then the tree path of prepare_zsort (:2603-2660) on the cell grid
+    ns = P.make_engine(case, 0)
+    ns.run()
+    box, st = engine_box(ns)
+    w = world["run"]
+    assert np.array_equal(box, _fixture_box(w)), f"run: {box} != {_fixture_box(w)}"
+    assert st["world_cells_pow2"] == w["cells_pow2"]
+    ns.prepare_zsort()
+    box2, st = engine_box(ns)
+    assert np.array_equal(box2, box) and np.float32(st["zsort_cell_size_inv"]) == np.float32(1.0) / cell
+    for s, p in enumerate(case.points):
+        if len(p):
+            keys = oracle.zsort_keys(np.asarray(p, np.float32), _fixture_box(w)[:3], np.float32(1.0) / cell)
+            assert oracle.check_zsort(keys, ns.get_zsort_order(s)) == 0
+    # -- run_scalar() on a fresh engine: _update_world_AABB (:415-522), no origin
+    ns = P.make_engine(case, 0)
+    ns.run_scalar()
+    box, st = engine_box(ns)
+    w = world["run_scalar"]
+    assert np.array_equal(box, _fixture_box(w)), f"run_scalar: {box} != {_fixture_box(w)}"
+    assert st["world_cells_pow2"] == w["cells_pow2"]
+    # a later run() on the same engine re-snaps only if the origin is outside the scalar box (the persistence rule, :474-482)
+    ns.run()
+    box3, _ = engine_box(ns)
+    sb = _fixture_box(w)
+    if np.all(sb[:3] <= 0) and np.all(sb[3:] >= 0):
+        assert np.array_equal(box3, sb)
+    else:
+        assert np.array_equal(box3, _fixture_box(world["run"]))
+
+
+def test_cloud_far_from_the_origin_hits_the_cell_limit_like_the_reference():
+    """TreeNSearch.cpp:633-638 with the SIMD bounds of :564-590: run() snaps a box that contains the ORIGIN, so a small cloud far away
+    from it needs more than 2^15 cells per axis and the reference exits; the engine reports TNSX_ERR_GRID_TOO_LARGE (5) and stays
+    usable.  run_scalar() (tight box) accepts the same cloud, as the reference's does."""
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    pts = (D.uniform_cloud(5000, 5) + np.float32(2000.0)).astype(np.float32)
+    r = np.float32(0.03)          # cell 0.045: 2000 / 0.045 = 44 k cells from the origin
+    ns = T.TreeNSearch()
+    ns.set_search_radius(r)
+    ns.add_point_set(pts)
+    ns.set_active_search(0, 0, True)
+    with pytest.raises(T.TnsxError) as e:
+        ns.run()
+    assert e.value.status == 5 and "32768" in e.value.message
+    ns.run_scalar()
+    assert ns.get_stats()["world_cells_pow2"] <= 64

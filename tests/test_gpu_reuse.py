@@ -26,6 +26,10 @@ def _oracle_box(oracle, box, pts_list, cell):
         if len(p):
             tight[:3] = np.minimum(tight[:3], p.min(axis=0))
             tight[3:] = np.maximum(tight[3:], p.max(axis=0))
+    if np.all(tight[:3] <= tight[3:]):
+        # run() sees the tight box united with the origin (TreeNSearch.cpp:564-569 + :587-590; pinned by the `world` fixtures)
+        tight[:3] = np.minimum(tight[:3], np.float32(0.0))
+        tight[3:] = np.maximum(tight[3:], np.float32(0.0))
     oracle.world_box_update(box, tight, cell)
     return box
 

@@ -45,7 +45,7 @@ def _single_device(case):
     return ns.neighbor_csr(0, 0, sort_each=False)
 
 
-def _run_slabs(case, world, n_steps=2, speculative=True, shrink_caps_before_step=None):
+def _run_slabs(case, world, n_steps=2, speculative=True, shrink_caps_before_step=None, shrink_link=None):
     import torch
     from treensearch_amd.multi import SlabDecomposition, SlabSearch
     pts_h = case.points[0]
@@ -75,7 +75,8 @@ def _run_slabs(case, world, n_steps=2, speculative=True, shrink_caps_before_step
         if shrink_caps_before_step == s:
             # pretend the halos were much thinner when the capacities were agreed: the speculative exchange overflows
             for p in list(slab.ex._caps):
-                slab.ex._caps[p] = (8, 8)
+                if shrink_link is None or {k, p} == set(shrink_link):     # (shrink_link: only the two ends of ONE link)
+                    slab.ex._caps[p] = (8, 8)
         pp, gg, rr = owned[k]
         slab.step(pp, gg, rr) if variable else slab.step(pp, gg)
         log[k].append((slab.ex.speculative_last, slab.redone_last, slab.ex.rounds_last))
@@ -139,6 +140,19 @@ def test_speculative_overflow_is_redone(oracle):
     _check_union(case, union, single, oracle)
     assert any(l[1][1] for l in log), "the overflow should have forced a redo"
     assert all(l[2] == (True, False, 1) for l in log), "the step after the redo is speculative again"
+
+
+def test_overflow_on_one_link_is_redone_by_every_rank(oracle):
+    """Only the link 1 <-> 2 of a chain of four slabs overflows: ranks 0 and 3 validate fine on their own, but the repeated step
+    exchanges with BOTH neighbours, so all four must agree to repeat it (one all-reduce of a flag) -- otherwise the messages of
+    ranks 1 and 2 to their healthy sides stay unmatched or pair up with the next step's."""
+    case = CS.by_name("uniform_fixed_1000000")
+    single = _single_device(case)
+    union, log, _, _ = _run_slabs(case, 4, n_steps=4, shrink_caps_before_step=1, shrink_link=(1, 2))
+    _check_union(case, union, single, oracle)
+    for k in range(4):
+        assert log[k][1][1] is True, f"rank {k} must take part in the repeated step"
+        assert log[k][2] == (True, False, 1) and log[k][3] == (True, False, 1), f"rank {k}: the steps after the redo are speculative again"
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -35,7 +35,8 @@ class TnsxError(RuntimeError):
 class _Options(C.Structure):
     _fields_ = [("device_id", C.c_int), ("stream", C.c_void_p), ("arith", C.c_int), ("mirror_to_host", C.c_int),
                 ("collect_stage_times", C.c_int), ("exact_layout", C.c_int), ("max_dense_cells", C.c_uint64), ("temporal_reuse", C.c_int),
-                ("sorted_lists", C.c_int), ("n_devices", C.c_int), ("device_ids", C.c_int * 8), ("reserved", C.c_int * 4)]
+                ("sorted_lists", C.c_int), ("n_devices", C.c_int), ("device_ids", C.c_int * 8), ("query_blocks_per_cu", C.c_int),
+                ("fast_blocks_per_cu", C.c_int), ("reserved", C.c_int * 2)]
 
 
 class _CsrView(C.Structure):
@@ -73,7 +74,7 @@ ABI_SYMBOLS = [
     "tnsx_set_active_search_all", "tnsx_set_all_searches", "tnsx_set_arithmetic",
     "tnsx_get_n_sets", "tnsx_get_n_points_in_set", "tnsx_get_total_n_points", "tnsx_is_search_active",
     "tnsx_does_set_exist", "tnsx_get_neighborlist_n_bytes",
-    "tnsx_run", "tnsx_get_pair_view", "tnsx_mirror_pair_to_host", "tnsx_copy_pair",
+    "tnsx_run", "tnsx_run_scalar", "tnsx_get_pair_view", "tnsx_mirror_pair_to_host", "tnsx_copy_pair",
     "tnsx_prepare_zsort", "tnsx_get_zsort_order", "tnsx_apply_zsort", "tnsx_get_stats",
     "tnsx_halo_pack", "tnsx_x_histogram", "tnsx_set_query_count", "tnsx_translate_neighbors", "tnsx_set_point_ids", "tnsx_synchronize",
 ]
@@ -128,6 +129,7 @@ def load_library():
     L.tnsx_get_neighborlist_n_bytes.argtypes = [vp]
     L.tnsx_get_neighborlist_n_bytes.restype = C.c_uint64
     L.tnsx_run.argtypes = [vp]
+    L.tnsx_run_scalar.argtypes = [vp]
     L.tnsx_get_pair_view.argtypes = [vp, ci, ci, C.POINTER(_CsrView)]
     L.tnsx_mirror_pair_to_host.argtypes = [vp, ci, ci]
     L.tnsx_copy_pair.argtypes = [vp, ci, ci, vp, vp, ci]
@@ -186,7 +188,8 @@ class NeighborList:
 class TreeNSearch:
     def __init__(self, *, arith: int = ARITH_STRICT, mirror_to_host: bool = False, device_id: int = -1,
                  stream: Optional[int] = None, collect_stage_times: bool = False, max_dense_cells: int = 0,
-                 exact_layout: bool = False, temporal_reuse: bool = True, sorted_lists: bool = False, devices=None):
+                 exact_layout: bool = False, temporal_reuse: bool = True, sorted_lists: bool = False, devices=None,
+                 query_blocks_per_cu: int = 0, fast_blocks_per_cu: int = 0):
         """devices: a list of HIP device ordinals -> multi-device mode (host-resident inputs only, see include/tnsx.h)"""
         self._L = load_library()
         opt = _Options()
@@ -200,6 +203,8 @@ class TreeNSearch:
         opt.exact_layout = int(exact_layout)
         opt.temporal_reuse = int(temporal_reuse)
         opt.sorted_lists = int(sorted_lists)
+        opt.query_blocks_per_cu = int(query_blocks_per_cu)
+        opt.fast_blocks_per_cu = int(fast_blocks_per_cu)
         if devices is not None and len(devices) > 1:
             opt.n_devices = len(devices)
             for k, d in enumerate(devices):
@@ -285,8 +290,11 @@ class TreeNSearch:
 
     def run_scalar(self) -> None:
         """The reference's scalar twin accumulates in double (TreeNSearch.cpp:2080-2087) and is not a parity
-        target; here it is the same GPU path as run()."""
-        self.run()
+        target; here it is the same GPU path as run(), with the world box of the reference's
+        scalar path (the tight box; run() unites it with the origin like the reference's SIMD path does)."""
+        self._views = {}
+        self._wait_for_producers()
+        self._check(self._L.tnsx_run_scalar(self._h))
 
     # ------------------------------------------------------------------ searches
     def set_all_searches(self, active: bool) -> None:

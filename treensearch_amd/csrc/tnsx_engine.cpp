@@ -151,6 +151,7 @@ struct tnsx_context {
 	float cell_size = -1.0f, cell_size_inv = -1.0f;
 	float world[6] = { FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX };   // bottom, top (octree_internals.h:29-30)
 	int world_cells_pow2 = 0;
+	bool scalar_world_box = false;   // this run is run_scalar(): the world box follows _update_world_AABB (no origin, see update_world_box)
 	bool ran = false;
 	bool cells_valid = false;   // the reference's are_cells_valid: a run() has happened since the sets last changed (selects the z-sort resolution)
 	// the search grid of the last run and what it was laid out for (temporal reuse, see run_once)
@@ -161,7 +162,11 @@ struct tnsx_context {
 	uint32_t grid_gen = 0;
 	float zsort_inv_h = 0.0f;   // 1 / quantisation step of the last prepare_zsort (tnsx_stats.zsort_cell_size_inv)
 	bool auto_dense_cells = true;
-	bool debug_nostore = std::getenv("TNSX_DEBUG_NOSTORE") != nullptr;   // timing experiments only: pool pass without its stores
+#ifdef TNSX_BUILD_NOSTORE
+	static constexpr bool debug_nostore = true;    // a tools/ build for timing experiments only (tools/build_variant.sh -DTNSX_BUILD_NOSTORE): pool pass without its stores
+#else
+	static constexpr bool debug_nostore = false;   // the product: nothing at run time can make a pass skip its stores
+#endif
 
 	// scratch
 	DevBuf bounds_partials, bounds_out, sort_temp, scan_temp, n_occ, permute_tmp, pool_ctrl, run_words, cell_map, trim_hist;
@@ -198,9 +203,17 @@ void new_point_set(tnsx_context* c)
 	c->active.emplace_back(n, 0);
 }
 
-// world box update, TreeNSearch.cpp:474-521 (shared by the scalar and SIMD versions)
-tnsx_status update_world_box(tnsx_context* c, const float tight[6])
+// world box update, TreeNSearch.cpp:474-521 (shared by the scalar and SIMD versions).
+// simd_path: the tight bounds as run() and the no-tree prepare_zsort() see them (_update_world_AABB_simd, TreeNSearch.cpp:523-592):
+// every thread of the reference takes the last points of its chunk as [x y z 0 0 0 0 0] (:564-569) and the final reduction
+// folds lanes 3..5 into the result (:587-590), so that box is the tight box UNITED WITH THE ORIGIN whenever there is a point.
+// run_scalar() (_update_world_AABB, :415-472) uses the tight box as it is.  Pinned against the reference's private
+// domain_float by the `world` blocks of tests/golden/*.json.
+tnsx_status update_world_box(tnsx_context* c, const float tight_in[6], bool simd_path)
 {
+	float tight[6];
+	for (int d = 0; d < 6; d++) tight[d] = tight_in[d];
+	if (simd_path) for (int d = 0; d < 3; d++) { tight[d] = std::min(tight[d], 0.0f); tight[3 + d] = std::max(tight[3 + d], 0.0f); }
 	const float* wb = c->world; const float* wt = c->world + 3;
 	if (wb[0] <= tight[0] && tight[3] <= wt[0] && wb[1] <= tight[1] && tight[4] <= wt[1] && wb[2] <= tight[2] && tight[5] <= wt[2]) {
 		return TNSX_OK;
@@ -684,7 +697,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	uint64_t n_cells = 1;
 	if (!speculate) {
 		// ---- world box of the reference semantics (kept for zsort + the 2^15 cells/dimension limit)
-		if (n_total > 0) { const tnsx_status r = update_world_box(c, b8); if (r != TNSX_OK) return r; }
+		if (n_total > 0) { const tnsx_status r = update_world_box(c, b8, !c->scalar_world_box); if (r != TNSX_OK) return r; }
 		const float r_max = variable ? b8[7] : c->radius;
 		if (n_total > 0 && !(r_max > 0.0f) ) TNSX_FAIL(c, TNSX_ERR_CONFIG, "TreeNSearch error: search radius must be > 0");
 		if (n_total > 0 && !std::isfinite(r_max)) TNSX_FAIL(c, TNSX_ERR_INVALID, "a search radius is not finite");
@@ -892,6 +905,8 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	qc.arith = c->opt.arith;
 	qc.variable = variable;
 	qc.symmetric = variable && c->symmetric;   // TreeNSearch.cpp:2431
+	qc.blocks_per_cu = c->opt.query_blocks_per_cu;
+	qc.fast_blocks_per_cu = c->opt.fast_blocks_per_cu;
 
 	auto launch_pool = [&](size_t k) -> tnsx_status {
 		const Job& jb = jobs[k];
@@ -1073,8 +1088,10 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 				const bool was_dry = pr.dry;
 				if (pr.dry) { pr.dry = false; S.cold_passes++; }   // the dry pass counted everything: the real pass is sized exactly
 				else {
-					if (std::getenv("TNSX_DEBUG_POOL")) fprintf(stderr, "[tnsx] pool overflow pair %zu: overflow region asked %llu of %llu, slab %u n_i %d\n", k,
+#ifdef TNSX_BUILD_DEBUG_POOL
+					fprintf(stderr, "[tnsx] pool overflow pair %zu: overflow region asked %llu of %llu, slab %u n_i %d\n", k,
 					                                            (unsigned long long)hc[(size_t)tnsx::POOL_OVERFLOW * tnsx::POOL_CTRL_WORDS], (unsigned long long)pr.region_cap[tnsx::POOL_OVERFLOW], pr.pool_slab, pr.n_i);
+#endif
 					S.pool_retries++;
 				}
 				{ const tnsx_status r = size_pool(pr, payload, was_dry ? nullptr : asked_now, !was_dry); if (r != TNSX_OK) return r; }
@@ -1166,6 +1183,16 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	c->ran = true;
 	c->cells_valid = true;
 	return TNSX_OK;
+}
+
+tnsx_status tnsx_run_scalar(tnsx_context* c)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	if (c->multi) return tnsx_run(c);   // (multi-device contexts keep one world box, the one of run())
+	c->scalar_world_box = true;
+	const tnsx_status r = tnsx_run(c);
+	c->scalar_world_box = false;
+	return r;
 }
 
 tnsx_status tnsx_run(tnsx_context* c)
@@ -1296,7 +1323,8 @@ tnsx_status tnsx_prepare_zsort(tnsx_context* c)
 	}
 	int64_t n_total = 0;
 	for (const PointSet& s : c->sets) n_total += s.n;
-	if (n_total > 0) { const tnsx_status r = update_world_box(c, b8); if (r != TNSX_OK) return r; }
+	// (the reference updates the box on its no-tree path only, TreeNSearch.cpp:2671-2674, always through the SIMD version)
+	if (n_total > 0 && !c->cells_valid) { const tnsx_status r = update_world_box(c, b8, true); if (r != TNSX_OK) return r; }
 	int n_pow2 = std::max(c->world_cells_pow2, 1);
 	float zs_inv_h = c->cell_size_inv;
 	if (!c->cells_valid && n_total > 0) {

@@ -118,6 +118,7 @@ struct QueryConfig {
 	bool symmetric;  // d2 <= r_i^2 || d2 <= r_j^2 (only meaningful with variable)
 	bool self;       // set_i == set_j: exclude the point itself
 	int mode;        // QUERY_COUNT / QUERY_FILL (exact two-pass layout) / QUERY_POOL (single pass)
+	int blocks_per_cu = 0, fast_blocks_per_cu = 0;   // launch widths (workgroups per CU) of the general / the fast kernels; 0 = default
 };
 void launch_query(const QueryArgs& a, const QueryConfig& c, int n_compute_units, hipStream_t s);
 // pool pass over two different sets, candidate-presence filter: launch_mark_cells writes `value` into the byte of every grid cell

@@ -59,6 +59,8 @@ struct HostSet {
 	const void* radii = nullptr;
 	int n = 0;
 	bool is_double = false, has_radii = false;
+	bool radii_is_double = false;        // element type of `radii`: set where radii are handed over, kept by a points-only resize
+	                                     // (set_radii / set_radii_double of the reference are separate arrays, TreeNSearch.h:375-378)
 	std::vector<float> f32_xyz, f32_r;   // (float) casts of double inputs, TreeNSearch.cpp:277-296
 	const float* x = nullptr;            // what this run reads
 	const float* r = nullptr;
@@ -143,12 +145,17 @@ tnsx_status ensure_zctx(State* m, std::string& error)
 	if (m->cell_size > 0.0f) (void)tnsx_set_cell_size(m->zctx, m->cell_size);   // (write-once in the engine: later calls fail silently, same value)
 	for (int s = 0; s < (int)m->sets.size(); s++) {
 		const HostSet& h = m->sets[(size_t)s];
-		const unsigned flags = (h.is_double ? TNSX_F64 : TNSX_F32) | TNSX_HOST | (h.has_radii ? TNSX_VARIABLE : 0u);
+		const unsigned common = TNSX_HOST | (h.has_radii ? TNSX_VARIABLE : 0u);
+		const unsigned flags_r = ((h.has_radii ? h.radii_is_double : h.is_double) ? TNSX_F64 : TNSX_F32) | common;
+		const unsigned flags_x = (h.is_double ? TNSX_F64 : TNSX_F32) | common;
+		// registered with the element type of the radii; points of another type follow as a points-only resize (pointers are only
+		// stored here, they are read at the run)
 		if (s >= m->zctx_sets) {
-			if (tnsx_add_point_set(m->zctx, h.xyz, h.radii, h.n, flags) < 0) MFAIL(TNSX_ERR_INVALID, "%s", tnsx_last_error(m->zctx));
+			if (tnsx_add_point_set(m->zctx, h.xyz, h.radii, h.n, flags_r) < 0) MFAIL(TNSX_ERR_INVALID, "%s", tnsx_last_error(m->zctx));
 			m->zctx_sets++;
 		}
-		else if (tnsx_resize_point_set(m->zctx, s, h.xyz, h.radii, h.n, flags) != TNSX_OK) MFAIL(TNSX_ERR_INVALID, "%s", tnsx_last_error(m->zctx));
+		else if (tnsx_resize_point_set(m->zctx, s, h.xyz, h.radii, h.n, flags_r) != TNSX_OK) MFAIL(TNSX_ERR_INVALID, "%s", tnsx_last_error(m->zctx));
+		if (flags_x != flags_r && tnsx_resize_point_set(m->zctx, s, h.xyz, nullptr, h.n, flags_x) != TNSX_OK) MFAIL(TNSX_ERR_INVALID, "%s", tnsx_last_error(m->zctx));
 	}
 	return TNSX_OK;
 }
@@ -198,6 +205,7 @@ int add_point_set(State* m, const void* xyz, const void* radii, int n, unsigned 
 	HostSet h;
 	h.xyz = xyz; h.radii = radii; h.n = n;
 	h.is_double = (flags & TNSX_F64) != 0;
+	h.radii_is_double = h.is_double;
 	h.has_radii = radii != nullptr || (flags & TNSX_VARIABLE);
 	if (h.has_radii) m->n_sets_with_radii++;
 	m->sets.push_back(std::move(h));
@@ -216,8 +224,8 @@ tnsx_status resize_point_set(State* m, int set_id, const void* xyz, const void* 
 	if (with_radii && m->n_sets_with_radii == 0) MFAIL(TNSX_ERR_INVALID, "TreeNSearch::resize_point_set error: Cannot resize a set with a radii array if it previously didn't have one.");
 	HostSet& h = m->sets[(size_t)set_id];
 	h.xyz = xyz; h.n = n;
-	if (with_radii) h.radii = radii;
 	h.is_double = (flags & TNSX_F64) != 0;
+	if (with_radii) { h.radii = radii; h.radii_is_double = h.is_double; }
 	return TNSX_OK;
 }
 
@@ -281,15 +289,16 @@ tnsx_status run(State* m, std::string& error)
 			float* dst = h.f32_xyz.data();
 			parallel_chunks(3 * (size_t)h.n, 64, [&](size_t, size_t b, size_t e) { for (size_t i = b; i < e; i++) dst[i] = (float)src[i]; });
 			h.x = dst;
-			if (h.has_radii) {
-				h.f32_r.resize((size_t)h.n);
-				const double* rs = (const double*)h.radii;
-				float* rd = h.f32_r.data();
-				parallel_chunks((size_t)h.n, 64, [&](size_t, size_t b, size_t e) { for (size_t i = b; i < e; i++) rd[i] = (float)rs[i]; });
-				h.r = rd;
-			}
 		}
-		else { h.x = (const float*)h.xyz; h.r = h.has_radii ? (const float*)h.radii : nullptr; }
+		else h.x = (const float*)h.xyz;
+		if (h.has_radii && h.radii_is_double) {
+			h.f32_r.resize((size_t)h.n);
+			const double* rs = (const double*)h.radii;
+			float* rd = h.f32_r.data();
+			parallel_chunks((size_t)h.n, 64, [&](size_t, size_t b, size_t e) { for (size_t i = b; i < e; i++) rd[i] = (float)rs[i]; });
+			h.r = rd;
+		}
+		else h.r = h.has_radii ? (const float*)h.radii : nullptr;
 	}
 
 	// ---- x range and largest radius
@@ -446,6 +455,7 @@ tnsx_status run(State* m, std::string& error)
 		if (m->radius_set && tnsx_set_search_radius(c, m->radius) != TNSX_OK) return fail(TNSX_ERR_CONFIG, "set_search_radius");
 		(void)tnsx_set_symmetric_search(c, m->symmetric ? 1 : 0);
 		(void)tnsx_set_arithmetic(c, m->arith);
+		if (m->cell_size > 0.0f) (void)tnsx_set_cell_size(c, m->cell_size);   // (write-once in the engine: later calls fail, same value)
 		for (int s = 0; s < S; s++) {
 			SlabSet& ss = d.sets[(size_t)s];
 			const HostSet& h = m->sets[(size_t)s];
@@ -497,6 +507,9 @@ tnsx_status run(State* m, std::string& error)
 		PairOut& po = m->pairs[(size_t)jb.i * S + jb.j];
 		po.n_i = m->sets[(size_t)jb.i].n;
 		po.n_neighbors = 0;
+		// int 0 of the gathered records is a shared EMPTY record and every offset starts out pointing at it: a point no slab owns
+		// (x = NaN: no point) then has an empty list instead of an offset nobody wrote
+		base[q][0] = 1;
 		for (int k = 0; k < D; k++) {
 			const PairLocal& pl = m->dev[(size_t)k].pairs[(size_t)jb.i * S + jb.j];
 			base[q][(size_t)k + 1] = base[q][(size_t)k] + pl.n_records;
@@ -505,6 +518,11 @@ tnsx_status run(State* m, std::string& error)
 		po.n_records = base[q][(size_t)D];
 		if (!po.records.reserve(std::max<uint64_t>(po.n_records, 1) * sizeof(int)) || !po.offsets.reserve((size_t)std::max(po.n_i, 1) * sizeof(uint64_t)))
 			MFAIL(TNSX_ERR_HIP, "multi-device mode: pinned host memory exhausted (lists: %llu ints)", (unsigned long long)po.n_records);
+		po.records.as<int>()[0] = 0;
+		{
+			uint64_t* go = po.offsets.as<uint64_t>();
+			parallel_chunks((size_t)std::max(po.n_i, 1), 8, [&](size_t, size_t b, size_t e) { std::memset(go + b, 0, (e - b) * sizeof(uint64_t)); });
+		}
 	}
 	auto device_fetch = [&](int k) {
 		Device& d = m->dev[(size_t)k];

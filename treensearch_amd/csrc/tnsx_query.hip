@@ -1194,15 +1194,13 @@ static void launch_pool_t(const QueryArgs& a, int blocks_fast, int blocks_heavy,
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF>
 static void launch_query_3(const QueryArgs& a, const QueryConfig& c, int n_cus, hipStream_t s)
 {
-	int per_cu = 7;
-	if (const char* e = getenv("TNSX_QUERY_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) per_cu = v; }   // tuning knob
+	const int per_cu = (c.blocks_per_cu >= 1 && c.blocks_per_cu <= 16) ? c.blocks_per_cu : 7;             // (tnsx_options.query_blocks_per_cu)
 	// a multiple of 8 workgroups so that every XCD gets the same number (workgroup b runs on XCD b % 8)
 	const int blocks = ((n_cus * per_cu + 7) / 8) * 8;
 	if (c.mode == QUERY_COUNT) launch_query_t<ARITH, VARIABLE, SYM, SELF, MODE_COUNT>(a, blocks, s);
 	else if (c.mode == QUERY_FILL) launch_query_t<ARITH, VARIABLE, SYM, SELF, MODE_FILL>(a, blocks, s);
 	else {
-		int fast_per_cu = 8;
-		if (const char* e = getenv("TNSX_FAST_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) fast_per_cu = v; }   // tuning knob
+		const int fast_per_cu = (c.fast_blocks_per_cu >= 1 && c.fast_blocks_per_cu <= 16) ? c.fast_blocks_per_cu : 8;   // (tnsx_options.fast_blocks_per_cu)
 		launch_pool_t<ARITH, VARIABLE, SYM, SELF>(a, ((n_cus * fast_per_cu + 7) / 8) * 8, ((n_cus * 2 + 7) / 8) * 8, s);
 	}
 }

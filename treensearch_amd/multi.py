@@ -496,15 +496,32 @@ class SlabSearch:
         self.redone_last = False
         spec = self.speculative and all(self._set(k).ex.can_speculate(s[0]) for k, s in enumerate(sets))
         self._step_once(sets, spec)
-        if spec and not all(self.sets[k].ex.validate() for k in range(len(sets))):
-            # a capacity was exceeded: some ghosts are missing.  Once more, with the counts read on the host.
-            self.redone_last = True
-            self._step_once(sets, False)
+        if spec:
+            # validate() of EVERY set (it also raises the capacities it found too small: no short-circuit), then ONE agreement over
+            # all ranks: the repeated step exchanges with both neighbours, so a rank whose own links were fine must repeat it too
+            # -- left to each rank alone, an overflow on one link of a chain of >= 3 slabs would leave the neighbours' messages
+            # unmatched (or matched with the NEXT step's message of the same shape).
+            oks = [self.sets[k].ex.validate() for k in range(len(sets))]
+            if self._agree_any(not all(oks), sets[0][0].device):
+                # a capacity was exceeded somewhere: some ghosts are missing.  Once more, with the counts read on the host.
+                self.redone_last = True
+                self._step_once(sets, False)
         if self._radius_check is not None:
             bad = bool(self._radius_check.item())
             self._radius_check = None
             if bad:
                 raise ValueError(f"a search radius exceeds max_radius = {self.max_radius}: the halo is too thin for exact results")
+
+    def _agree_any(self, flag: bool, device) -> bool:
+        """True on every rank if `flag` is set on any rank (one 4-byte all-reduce; an injected transport provides any_flag())."""
+        tr = self._ex_args.get("transport")
+        if tr is not None:
+            return bool(tr.any_flag(self._set(0).ex.rank, bool(flag)))
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(t.item())
 
     def _step_once(self, sets, speculative: bool):
         e = self.engine
