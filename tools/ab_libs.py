@@ -9,6 +9,7 @@ import treensearch_amd.api as A
 from treensearch_amd import datagen as D
 ap = argparse.ArgumentParser(); ap.add_argument("libs", nargs="+"); ap.add_argument("--rounds", type=int, default=6); ap.add_argument("--steps", type=int, default=15)
 ap.add_argument("--points", type=int, default=10_000_000)
+ap.add_argument("--check", action="store_true", help="compare the neighbour lists of every build with the first one's (order-independent digest, oracle/tns_oracle.c: test infrastructure)")
 ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2", help="c2 uniform fixed radius; c3 two sets 0->0,0->1; c4 dam break, per-point radii, symmetric")
 args = ap.parse_args()
 n = args.points
@@ -29,6 +30,17 @@ for path in args.libs:
     for (i, j) in pairs: ns.set_active_search(i, j, True)
     for _ in range(3): ns.run()
     engines.append(ns)
+if args.check:
+    from oracle import oracle as O
+    orc = O.Oracle()
+    digs = []
+    for path, ns in zip(args.libs, engines):
+        d = []
+        for (i, j) in pairs:
+            offs, idx = ns.neighbor_csr(i, j, sort_each=False)
+            d.append((int(offs[-1]),) + orc.digest(offs, idx, already_sorted=False))
+        digs.append(d)
+        print(f"{os.path.basename(path):28s} lists {'== first build' if d == digs[0] else '!!! DIFFER from the first build !!!'} {d}", flush=True)
 import time
 acc = [dict(fill=[], sort=[], total=[], wall=[], retries=0) for _ in engines]
 for r in range(args.rounds):

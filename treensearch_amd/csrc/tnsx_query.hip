@@ -158,6 +158,46 @@ __device__ __forceinline__ uint32_t slot_to_src_t(uint32_t slot, const Runs R)
 	return slot + d;
 }
 
+#ifndef TNSX_DEAL_LDS
+#define TNSX_DEAL_LDS 1
+#endif
+// ---------------------------------------------------------------------------------------------------------------------
+// Candidate dealing through an LDS table (round 3).  slot_to_src_t costs nine compare + select pairs per slot and chunk -- all of
+// them instructions that touch an SGPR or VCC, 4.3 cycles each: 77 cycles per chunk, 22 % of the kernel's vector instructions
+// (profiles/r2_c2_pmc.json).  Instead every run writes the sorted positions of its candidates into a table in the wave's staging
+// area ONCE per cell: run r covers the slots [p_r, p_r+1), lane l of the piece writes p_r + d_r + l at table[p_r + l] with
+// ds_write_addtid_b32 (address = M0 + 4 * lane: no address register, no per-lane address arithmetic; the run's extent is the exec
+// mask).  One scalar-operand add and one LDS store per run instead of 18 vector instructions per chunk; a chunk then reads its 64
+// table entries with one ds_read.  The table lives where the cell's records are staged afterwards (the staging area is empty while
+// the candidates are loaded; LDS operations of a wave execute in order).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void deal_run(uint32_t tbl, uint32_t p0, uint32_t p1, uint32_t d, uint32_t lane)
+{
+	uint32_t n = p1 - p0;   // wave-uniform
+	uint32_t pos = p0;
+	while (n != 0u) {       // (one piece: a run is three cells of the grid)
+		const uint32_t c = n < 64u ? n : 64u;
+		const uint32_t v = lane + (pos + d);
+		asm volatile("s_mov_b32 m0, %[b]\n\ts_lshr_b64 exec, -1, %[sh]\n\tds_write_addtid_b32 %[v]\n\ts_mov_b64 exec, -1"
+		             : : [b] "s"(tbl + 4u * pos), [sh] "s"(64u - c), [v] "v"(v) : "memory");
+		n -= c; pos += c;
+	}
+}
+template <bool OWN_FIRST>
+__device__ __forceinline__ void deal_table(uint32_t tbl, const Runs R, uint32_t lane)
+{
+	deal_run(tbl, 0u, R.p1, R.d0, lane);
+	deal_run(tbl, R.p1, R.p2, R.d1, lane);
+	deal_run(tbl, R.p2, R.p3, R.d2, lane);
+	deal_run(tbl, R.p3, R.p4, R.d3, lane);
+	deal_run(tbl, R.p4, R.p5, R.d4, lane);
+	deal_run(tbl, R.p5, R.p6, R.d5, lane);
+	deal_run(tbl, R.p6, R.p7, R.d6, lane);
+	deal_run(tbl, R.p7, R.p8, R.d7, lane);
+	deal_run(tbl, R.p8, R.p9, R.d8, lane);
+	if (OWN_FIRST) deal_run(tbl, R.p9, R.total, R.d9, lane);
+}
+
 // 27 neighbour lookups of the cell with this key (lanes 0..26), wave-uniform key
 __device__ __forceinline__ void lookup_cell(const QueryArgs& a, uint32_t key, bool valid, int lane, uint32_t& s, uint32_t& e)
 {
@@ -616,6 +656,161 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 //     offset once per cell.
 // The query loop of one simple cell: NC register-resident candidate chunks (packed pairs) against the nq query points held one
 // per lane in qv / qr2.  Tests, record allocation, emission.
+template <int NC> struct StageSize { static constexpr uint32_t ints = NC > 8 ? 2048u : 1536u; };   // ints of a wave's staging area: > 2 x the longest record of the tier
+#ifndef TNSX_CELL_STAGE
+#define TNSX_CELL_STAGE 1
+#endif
+#if TNSX_CELL_STAGE
+// ---------------------------------------------------------------------------------------------------------------------
+// Whole-cell staging (round 3).  The records of the queries of one cell are consecutive in the pool, so the WHOLE BLOCK is built in
+// the wave's LDS staging area -- [count, ids...] [count, ids...] ... exactly as it will lie in memory -- and leaves at the end of the
+// cell: ONE allocation per cell (not per query), full-wave coalesced stores of 64 consecutive ints bounded by the buffer's
+// NUM_RECORDS (no compare, no exec moves), one store of the offsets.  Per query nothing is left but the tests, the compaction
+// into LDS, one count word (lane 0, through M0: ds_write_addtid needs no address register) and the bump of the staging position.
+// Against the per-query version of round 2 (record read back and stored while the next query is tested): no per-query store
+// pipeline, no slab test, no flags in vector registers -- see profiles/r3_query_ab.txt.
+// ---------------------------------------------------------------------------------------------------------------------
+#define TNSX_LDS_PIECE4(K)                  \
+	"s_mov_b64 exec, %[m" #K "]\n\t"       \
+	"ds_write_b32 %[addr], %[v" #K "] offset:4\n\t" \
+	"v_add_u32 %[addr], 4, %[addr]\n\t"
+template <int N>
+__device__ __forceinline__ void stage_chunks4(uint32_t& addr, const uint64_t* m, const uint32_t* v)
+{
+	if (N == 1) {
+		asm volatile(TNSX_LDS_PIECE4(0) "s_mov_b64 exec, -1" : [addr] "+v"(addr) : TNSX_LDS_IN(0, m[0], v[0]) : "memory");
+	}
+	else if (N == 2) {
+		asm volatile(TNSX_LDS_PIECE4(0) TNSX_LDS_PIECE4(1) "s_mov_b64 exec, -1" : [addr] "+v"(addr) : TNSX_LDS_IN(0, m[0], v[0]), TNSX_LDS_IN(1, m[1], v[1]) : "memory");
+	}
+	else if (N == 3) {
+		asm volatile(TNSX_LDS_PIECE4(0) TNSX_LDS_PIECE4(1) TNSX_LDS_PIECE4(2) "s_mov_b64 exec, -1"
+		             : [addr] "+v"(addr) : TNSX_LDS_IN(0, m[0], v[0]), TNSX_LDS_IN(1, m[1], v[1]), TNSX_LDS_IN(2, m[2], v[2]) : "memory");
+	}
+	else {
+		asm volatile(TNSX_LDS_PIECE4(0) TNSX_LDS_PIECE4(1) TNSX_LDS_PIECE4(2) TNSX_LDS_PIECE4(3) "s_mov_b64 exec, -1"
+		             : [addr] "+v"(addr) : TNSX_LDS_IN(0, m[0], v[0]), TNSX_LDS_IN(1, m[1], v[1]), TNSX_LDS_IN(2, m[2], v[2]), TNSX_LDS_IN(3, m[3], v[3]) : "memory");
+	}
+}
+template <int NC>
+__device__ __forceinline__ void stage_all4(uint32_t& addr, const uint64_t (&m)[NC], const uint32_t* v)
+{
+	#pragma unroll
+	for (int g = 0; g < NC; g += 4) {
+		if (NC - g >= 4) stage_chunks4<4>(addr, m + g, v + g);
+		else if (NC - g == 3) stage_chunks4<3>(addr, m + g, v + g);
+		else if (NC - g == 2) stage_chunks4<2>(addr, m + g, v + g);
+		else stage_chunks4<1>(addr, m + g, v + g);
+	}
+}
+
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int NC>
+__device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits,
+                                                const v2f (&cx)[(NC + 1) / 2], const v2f (&cy)[(NC + 1) / 2], const v2f (&cz)[(NC + 1) / 2],
+                                                const uint32_t (&cid)[2 * ((NC + 1) / 2)], const float (&cr2)[2 * ((NC + 1) / 2)], const float4 qv,
+                                                const float qr2, const uint32_t qidx)
+{
+	constexpr int NP = (NC + 1) / 2;
+	constexpr uint32_t STAGE = StageSize<NC>::ints;
+	// Only points with original index < query_limit get lists (tnsx_set_query_count: the tail of a set can be candidates only,
+	// e.g. the ghost points of a slab).  The cell sort is stable, so inside a cell these queries come first: a prefix.
+	const uint32_t nq = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((uint32_t)lane < cur_q.y - cur_q.x && qidx < a.query_limit));
+	uint32_t left = readfirstlane_u32(ps.left);
+	uint32_t ok = readfirstlane_u32(ps.ok);
+	uint64_t base = ((uint64_t)readfirstlane_u32(ps.cur_hi) << 32) | readfirstlane_u32(ps.cur_lo);
+	uint32_t* const stage = record_stage<(int)STAGE>();
+	const uint32_t stage_base = readfirstlane_u32((uint32_t)(uintptr_t)stage);   // (the low half of a generic LDS address is the LDS offset)
+	const uint32_t max_len = RR.total + 1u;   // no record of this cell is longer (<= STAGE / 2 by the tiers' limits)
+
+	uint32_t spos = 0;      // ints staged: the block so far
+	uint32_t t0 = 0;        // first query of the block
+	uint32_t v_pos = 0;     // lane t: where record t starts inside its block
+	uint32_t hits = 0;
+	// the block [0, spos) = the records of queries [t0, t1) -> the pool
+	auto flush = [&](uint32_t t1) {
+		const uint32_t block = spos;
+		if (block > left) {
+			// rare: new slab (one atomic on the cursor of this XCD's region)
+			pool_waste(ps, left);
+			const uint32_t slab = NC > 8 ? a.pool_slab_heavy : a.pool_slab;
+			const uint32_t sz = block > slab ? block : slab;
+			const unsigned long long first = pool_take_slab(a.pool_cursor, a.pool_regions, sz, NC > 8 ? 1u : 0u);   // (more than 8 chunks: the fat tier)
+			base = ((uint64_t)readfirstlane_u32((uint32_t)(first >> 32)) << 32) | readfirstlane_u32((uint32_t)first);
+			ok = base != POOL_NONE ? 1u : 0u;
+			if (ok == 0u) base = 0;
+			left = sz;
+		}
+		if (ok != 0u) {
+			v4i rsrc = record_rsrc(a.records + base);
+			rsrc.z = (int)block;   // NUM_RECORDS: the hardware drops the lanes of the last store that lie beyond the block
+			// four reads in flight per round trip to the LDS (STAGE is a multiple of 256: the reads stay inside the wave's area)
+			for (uint32_t f = 0; f < block; f += 4u * (uint32_t)WAVE) {
+				const uint32_t i = f + (uint32_t)lane;
+				const uint32_t v0 = stage[i], v1 = stage[i + 64u], v2 = stage[i + 128u], v3 = stage[i + 192u];
+				// (every store is bounded by its own index: the instruction offset takes no part in the hardware's range check)
+				asm volatile("buffer_store_dword %[v0], %[i0], %[rsrc], 0 idxen\n\t"
+				             "buffer_store_dword %[v1], %[i1], %[rsrc], 0 idxen\n\t"
+				             "buffer_store_dword %[v2], %[i2], %[rsrc], 0 idxen\n\t"
+				             "buffer_store_dword %[v3], %[i3], %[rsrc], 0 idxen"
+				             : : [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [i0] "v"(i), [i1] "v"(i + 64u), [i2] "v"(i + 128u), [i3] "v"(i + 192u),
+				                 [rsrc] "s"(rsrc) : "memory");
+			}
+			if ((uint32_t)lane >= t0 && (uint32_t)lane < t1) a.offs_by_orig[qidx] = base + v_pos;
+		}
+		hits += block - (t1 - t0);
+		base += block;
+		left -= block;
+		t0 = t1;
+		spos = 0;
+	};
+
+	for (uint32_t t = 0; t < nq; t++) {
+		if (spos + max_len > STAGE) flush(t);   // (cells with many query points: the block leaves in pieces)
+		const float qx = readlane_f32(qv.x, (int)t), qy = readlane_f32(qv.y, (int)t), qz = readlane_f32(qv.z, (int)t);
+		const float r2q = VARIABLE ? readlane_f32(qr2, (int)t) : a.r2_fixed;
+		uint64_t m[NC];
+		#pragma unroll
+		for (int h = 0; h < NP; h++) {
+			const v2f d2 = dist_sq2<ARITH>(qx, qy, qz, cx[h], cy[h], cz[h]);
+			#pragma unroll
+			for (int u = 0; u < 2; u++) {
+				const int k = 2 * h + u;
+				if (k < NC) {
+					m[k] = __builtin_amdgcn_ballot_w64(d2[u] <= (SYM ? max_raw(r2q, cr2[k]) : r2q));   // (SYM: see process_batch)
+				}
+			}
+		}
+		if (SELF) {
+			// the query is always a hit of itself (d2 == 0) and sits at slot t (own-cell-first slot order)
+			asm("s_bitset0_b64 %0, %1" : "+s"(m[0]) : "s"(t));
+		}
+		// hits -> the staging area, lane-major behind the count word: lane l writes at rec + 4 + 4 * (hits of all chunks in lower lanes)
+		const uint32_t rec = stage_base + (spos << 2);
+		uint32_t addr;
+		{
+			uint32_t P = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[0] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[0], 0u));
+			#pragma unroll
+			for (int k = 1; k < NC; k++) P = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[k], P));
+			addr = rec + (P << 2);
+		}
+		stage_all4<NC>(addr, m, cid);
+		const uint32_t cnt = (readlane_u32(addr, WAVE - 1) - rec) >> 2;
+		{
+			// the count word, by lane 0 through M0 (address = M0 + 4 * lane; m0 is reserved: the compiler reloads it before its own uses)
+			uint32_t tmp;
+			asm volatile("s_mov_b32 m0, %[rec]\n\ts_mov_b64 exec, 1\n\tv_mov_b32 %[t], %[c]\n\tds_write_addtid_b32 %[t]\n\ts_mov_b64 exec, -1"
+			             : [t] "=&v"(tmp) : [rec] "s"(rec), [c] "s"(cnt) : "memory");
+		}
+		asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v_pos) : "s"(spos), "s"(t));
+		spos += cnt + 1u;
+	}
+	if (spos != 0u) flush(nq);
+	wave_hits += hits;
+	ps.cur_lo = (uint32_t)base; ps.cur_hi = (uint32_t)(base >> 32);
+	ps.left = left;
+	ps.ok = ok;
+}
+#else
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int NC>
 __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits,
                                                 const v2f (&cx)[(NC + 1) / 2], const v2f (&cy)[(NC + 1) / 2], const v2f (&cz)[(NC + 1) / 2],
@@ -648,7 +843,7 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 		flushed = upto;
 	};
 
-	uint32_t* const stage = record_stage<(NC > 8 ? 1024 : 512)>();
+	uint32_t* const stage = record_stage<(int)StageSize<NC>::ints>();
 	const uint32_t stage_base = readfirstlane_u32((uint32_t)(uintptr_t)stage);   // (the low half of a generic LDS address is the LDS offset)
 	uint32_t pend_v = 0, pend_cnt = 0, pend_pos = 0;   // TNSX_STAGE_PIPE: first 64 ints of the previous query's record, read back but not yet stored
 	// ---- the query loop.  (Fetching the query point with a scalar load one iteration ahead instead of v_readlane was
@@ -733,6 +928,8 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 	}
 }
 
+#endif   // TNSX_CELL_STAGE
+
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int NC>
 __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits)
 {
@@ -740,6 +937,10 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 	constexpr bool OWN_FIRST = SELF;
 	const uint32_t nq = cur_q.y - cur_q.x;
 	const Runs R = extract_runs_t<OWN_FIRST>(RR.run_start, RR.run_len, cur_q.x);
+#if TNSX_DEAL_LDS
+	const uint32_t* const tbl = record_stage<(int)StageSize<NC>::ints>();
+	deal_table<OWN_FIRST>(readfirstlane_u32((uint32_t)(uintptr_t)tbl), R, (uint32_t)lane);
+#endif
 	// ---- candidates -> registers (branch-free, see process_batch)
 	v2f cx[NP], cy[NP], cz[NP];
 	uint32_t cid[2 * NP];
@@ -750,7 +951,11 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 	for (int k = 0; k < 2 * NP; k++) {
 		if (k < NC) {
 			const uint32_t slot = (uint32_t)(k * WAVE + lane);
+#if TNSX_DEAL_LDS
+			const uint32_t src = (k < NC - 1 || slot < R.total) ? tbl[slot] : R.d0;
+#else
 			const uint32_t src = (k < NC - 1 || slot < R.total) ? slot_to_src_t<OWN_FIRST>(slot, R) : R.d0;
+#endif
 			craw[k] = a.xyzi_j[src];
 			if (SYM) r2raw[k] = a.r2_j[src];
 		}
@@ -801,7 +1006,7 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 // ---------------------------------------------------------------------------------------------------------------------
 template <int ARITH, bool SYM, bool OWN_FIRST>
 __device__ __forceinline__ uint32_t cull_round(const QueryArgs& a, const Runs R, int lane, uint32_t base, uint32_t kept, float lox, float loy, float loz,
-                                               float hix, float hiy, float hiz, float r2q_max, uint16_t* __restrict__ lds_slots)
+                                               float hix, float hiy, float hiz, float r2q_max, uint16_t* __restrict__ lds_slots, const uint32_t* __restrict__ tbl)
 {
 	const uint32_t nc = (R.total - base + WAVE - 1) / WAVE;   // chunks of this round that hold candidates (the rest is skipped)
 	float4 craw[Q_MAXPAIRS * 2];
@@ -810,7 +1015,11 @@ __device__ __forceinline__ uint32_t cull_round(const QueryArgs& a, const Runs R,
 	for (int k = 0; k < Q_MAXPAIRS * 2; k++) {
 		if ((uint32_t)k < nc) {
 			const uint32_t slot = base + (uint32_t)(k * WAVE + lane);
+#if TNSX_DEAL_LDS
+			const uint32_t src = slot < R.total ? tbl[slot] : R.d0;
+#else
 			const uint32_t src = slot < R.total ? slot_to_src_t<OWN_FIRST>(slot, R) : R.d0;
+#endif
 			craw[k] = a.xyzi_j[src];
 			if (SYM) r2raw[k] = a.r2_j[src];
 		}
@@ -849,12 +1058,18 @@ __device__ __forceinline__ void fast_cell_from_slots(const QueryArgs& a, const R
 	float cr2[2 * NP];
 	float4 craw[2 * NP];
 	float r2raw[2 * NP];
+	const uint32_t* const tbl = record_stage<(int)StageSize<NC>::ints>();   // (the table fast_cell_culled built; NC <= 8: the first tier's area)
+	(void)tbl;
 	#pragma unroll
 	for (int k = 0; k < 2 * NP; k++) {
 		if (k < NC) {
 			const uint32_t i = (uint32_t)(k * WAVE + lane);
 			const uint32_t slot = lds_slots[i];                     // (slots past `kept` hold stale numbers: clamped below)
+#if TNSX_DEAL_LDS
+			const uint32_t src = (k < NC - 1 || i < kept) ? tbl[slot < R.total ? slot : 0u] : R.d0;
+#else
 			const uint32_t src = (k < NC - 1 || i < kept) ? slot_to_src_t<SELF>(slot < R.total ? slot : 0u, R) : R.d0;
+#endif
 			craw[k] = a.xyzi_j[src];
 			if (SYM) r2raw[k] = a.r2_j[src];
 		}
@@ -898,9 +1113,13 @@ __device__ __forceinline__ bool fast_cell_culled(const QueryArgs& a, const RunRe
 	wave_bbox(lox, loy, loz, hix, hiy, hiz);
 	const float r2q_max = VARIABLE ? wave_max_dpp(qr2) : a.r2_fixed;
 
+	const uint32_t* const tbl = record_stage<(int)StageSize<8>::ints>();
+#if TNSX_DEAL_LDS
+	deal_table<OWN_FIRST>(readfirstlane_u32((uint32_t)(uintptr_t)tbl), R, (uint32_t)lane);   // up to 1024 slots: inside the staging area
+#endif
 	uint32_t kept = 0;
 	for (uint32_t base = 0; base < R.total; base += (uint32_t)Q_SLOTS)
-		kept = readfirstlane_u32(cull_round<ARITH, SYM, OWN_FIRST>(a, R, lane, base, kept, lox, loy, loz, hix, hiy, hiz, r2q_max, lds_slots));
+		kept = readfirstlane_u32(cull_round<ARITH, SYM, OWN_FIRST>(a, R, lane, base, kept, lox, loy, loz, hix, hiy, hiz, r2q_max, lds_slots, tbl));
 	if (kept > (uint32_t)Q_SLOTS) return false;
 	wave_lds_fence();
 	switch ((kept + WAVE - 1) / WAVE) {
