@@ -226,6 +226,8 @@ def main():
     ap.add_argument("--arith", choices=["strict", "contracted"], default="strict")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
+    ap.add_argument("--slab-backend", choices=["abi", "torch"], default="abi", help="c5: who moves the halos -- libtnsx.so itself (tnsx_slab_step over RCCL, default) "
+                    "or treensearch_amd/multi.py over torch.distributed")
     ap.add_argument("--no-secondary", action="store_true", help="c2 only: do not append the reduced runs of c3 and c4 (`secondary`)")
     ap.add_argument("--exact-layout", action="store_true", help="two-pass count/scan/fill result layout instead of the single pass")
     ap.add_argument("--static-input", action="store_true", help="do not move the points between steps (the engine then reuses everything it may)")
@@ -370,16 +372,28 @@ def main():
         desc = (f"{n}-point SPH dam break (70 % dense column, 25 % floor layer, 5 % spray), per-point radii r0*(1+u) with r0={float(r0):.6f}, "
                 f"symmetric search; every step: perturb <= 0.1 r0, prepare_zsort, apply_zsort(xyz), apply_zsort(radii), run; BASELINE.json configs[3]")
     else:   # c5
-        from treensearch_amd.multi import SlabDecomposition, SlabSearch
+        from treensearch_amd.multi import SlabDecomposition, SlabSearch, SlabSearchC, SlabTransportC, balanced_cuts_c
         n_total = points_total or 200_000_000
         radius = D.radius_for_neighbors(n_total)
         lo_i, hi_i = (n_total * rank) // world, (n_total * (rank + 1)) // world            # generated: a contiguous index range per rank
         mine = torch.from_numpy(D.uniform_cloud(hi_i - lo_i, args.seed, start=lo_i)).cuda()
         gids = torch.arange(lo_i, hi_i, dtype=torch.int64, device="cuda")
         amp = 0.1 * float(radius)
+        # The slab layer behind the C ABI (tnsx_slab_balanced_cuts / tnsx_slab_step: ncclSend / ncclRecv issued by libtnsx.so itself) is the
+        # default; --slab-backend torch keeps the exchange in treensearch_amd/multi.py (torch.distributed P2P, the same wire protocol).
+        backend, transport = args.slab_backend, None
+        if backend == "abi" and distributed and world > 1:
+            try:
+                transport = SlabTransportC.rccl(rank, world, device=local_rank)
+            except Exception as e:   # (the same on every rank: the library is missing or not)
+                backend = "torch"
+                extra["slab_backend_note"] = f"RCCL transport of the C ABI unavailable ({e}); exchange through torch.distributed"
         dec = SlabDecomposition(engine=make_engine())
         t_dec = time.perf_counter()
-        cuts = dec.balanced_cuts([mine], plane_width=float(radius) * 1.15)
+        if backend == "abi":
+            cuts = balanced_cuts_c(dec.engine, transport, rank, world, [mine], float(radius) * 1.15)
+        else:
+            cuts = dec.balanced_cuts([mine], plane_width=float(radius) * 1.15)
         owned, owned_gids, _ = dec.redistribute(mine, gids, None, cuts)
         torch.cuda.synchronize()
         extra["decomposition_s"] = round(time.perf_counter() - t_dec, 3)
@@ -388,9 +402,15 @@ def main():
         zsorted(owned, radius, owned_gids)
         n_owned = int(owned.shape[0])
         # the points oscillate by <= 0.1 r around the positions the slabs were cut for: the halo is 0.11 r wider than the radius
-        slab = SlabSearch(float(cuts[rank]), float(cuts[rank + 1]), float(radius), make_engine, halo_margin=0.11)
+        if backend == "abi":
+            ns = make_engine()
+            slab = SlabSearchC(float(cuts[rank]), float(cuts[rank + 1]), float(radius), ns, transport, rank, world, halo_margin=0.11)
+            extra["slab_backend"] = "C ABI: tnsx_slab_step (" + ("RCCL ncclSend / ncclRecv issued by libtnsx.so" if transport is not None else "one slab, no exchange") + ")"
+        else:
+            slab = SlabSearch(float(cuts[rank]), float(cuts[rank + 1]), float(radius), make_engine, halo_margin=0.11)
+            ns = slab.engine
+            extra["slab_backend"] = "treensearch_amd/multi.py (torch.distributed P2P)"
         copies = osc(owned, amp, 100 + rank)
-        ns = slab.engine
         extra["owned_points_order"] = "z-order (sorted once after the redistribution)" if args.zsort_input else "as redistributed"
 
         def step(k):
@@ -495,6 +515,7 @@ def main():
         # (the engine and its gigabytes of lists are released before the counter passes start a second process on the same GPU)
         del ns
         step = None
+        slab = None
         copies = None
         torch.cuda.empty_cache()
         if not args.no_pmc and world == 1 and pooled:

@@ -241,6 +241,70 @@ tnsx_status tnsx_synchronize(tnsx_context* ctx);
  * [owned | ghosts]); id_map_dev must have one entry per point of set_j.  Waits for completion. */
 tnsx_status tnsx_translate_neighbors(tnsx_context* ctx, int set_i, int set_j, const int* id_map_dev);
 
+/* ---- slab layer: the multi-GPU path behind the C ABI (tnsx_slab.cpp) ---------------------------------------
+ * One tnsx_slab per GPU (one process per GPU, or one thread per GPU) on top of an ordinary single-device context.  Rank k owns the
+ * points with slab_lo <= x < slab_hi; tnsx_slab_step() sends the points within one halo width of a slab face to that neighbour
+ * (tnsx_halo_pack + ONE grouped ncclSend / ncclRecv per step over RCCL), appends the received ghosts to the owned points of their set
+ * as candidates-only points with their global ids, and runs the engine: the lists of the owned points then hold GLOBAL ids.  The
+ * lists are read through the engine as usual (tnsx_get_pair_view(engine, tnsx_slab_engine_set(slab, i), tnsx_slab_engine_set(slab, j))).
+ * Steady state is speculative (fixed-capacity messages, nothing read on the host before the search, capacities checked afterwards);
+ * a link whose capacity was exceeded is repaired by its two ends alone and only they search again. */
+typedef struct tnsx_slab tnsx_slab;
+
+/* one message pair with one neighbour: send_bytes from `send` to rank `peer`, recv_bytes from `peer` into `recv` (device memory; 0 bytes: no message) */
+typedef struct tnsx_slab_op { int peer; const void* send; size_t send_bytes; void* recv; size_t recv_bytes; } tnsx_slab_op;
+enum { TNSX_SLAB_SUM_U32 = 0, TNSX_SLAB_MIN_F32 = 1, TNSX_SLAB_MAX_F32 = 2 };
+/* How the messages move.  tnsx_slab_transport_rccl fills it for RCCL; tnsx_slab_transport_local for slabs that live in one process
+ * (tests on a single GPU); an application with its own communication layer (MPI, ...) fills it itself.  Both calls order their work
+ * after what `stream` (a hipStream_t) already holds and must be complete, or ordered on `stream`, when they return. */
+typedef struct tnsx_slab_transport {
+	void* user;
+	int (*exchange)(void* user, int rank, int world, const tnsx_slab_op* ops, int n_ops, void* stream);   /* all ops of one round, 0 = ok */
+	int (*allreduce)(void* user, int rank, int world, void* dev_buf, int count, int op, void* stream);    /* in place, 32-bit elements */
+	void (*release)(void* user);
+} tnsx_slab_transport;
+typedef struct tnsx_slab_info {
+	int n_owned, n_ghost;        /* set 0 of the last step */
+	int speculative_last;        /* 1: the last step was one round of fixed-capacity messages */
+	int redone_last;             /* 1: a capacity was exceeded, the overflowed link(s) were repaired and the search repeated */
+	int rounds_last;             /* exchange rounds of the last step (exact step: 2, speculative: 1, + 1 repair round) */
+	unsigned long long bytes_sent;   /* so far */
+} tnsx_slab_info;
+
+/* RCCL: rank 0 makes the 128-byte id, the application hands it to every rank (MPI_Bcast, torch.distributed.broadcast, a file, ...) */
+tnsx_status tnsx_slab_rccl_unique_id(void* out128);
+tnsx_status tnsx_slab_transport_rccl(const void* unique_id128, int rank, int world, int device /* -1: current */, tnsx_slab_transport* out);
+const char* tnsx_slab_rccl_error(void);
+/* all slabs inside one process */
+tnsx_status tnsx_slab_local_group_create(int world, void** group_out);
+void        tnsx_slab_local_group_release(void* group);
+tnsx_status tnsx_slab_transport_local(void* group, int rank, tnsx_slab_transport* out);
+void        tnsx_slab_transport_release(tnsx_slab_transport* t);
+
+/* Balanced cuts: global x range (all-reduce min / max), one histogram of the x planes of width plane_width (>= the halo, so that only
+ * adjacent slabs ever exchange ghosts) per rank, all-reduce(sum), cuts at the plane boundaries closest to the k / n_slabs quantiles.
+ * cuts_out[0 .. n_slabs]: cuts_out[0] = -inf, cuts_out[n_slabs] = +inf; slab k owns cuts[k] <= x < cuts[k + 1].  Collective: every
+ * rank calls it with its own points (device memory).  n_slabs <= 0: one slab per rank. */
+tnsx_status tnsx_slab_balanced_cuts(tnsx_context* engine, const tnsx_slab_transport* transport, int rank, int world, int n_sets,
+                                    const float* const* xyz, const int* n_points, float plane_width, int n_slabs, float* cuts_out);
+
+/* radius > 0: fixed search radius of all sets (set on the engine here); radius <= 0: per-point radii, max_radius must bound every
+ * radius of every rank (it sizes the halo; checked on the owned radii at every step).  halo_margin: the halo is
+ * max_radius * (1 + halo_margin) wide (<= 0: 1e-3).  transport may be NULL when world == 1. */
+tnsx_status tnsx_slab_create(tnsx_context* engine, const tnsx_slab_transport* transport, int rank, int world, float slab_lo, float slab_hi,
+                             float radius, float max_radius, float halo_margin, int speculative, tnsx_slab** out);
+void        tnsx_slab_destroy(tnsx_slab* slab);
+const char* tnsx_slab_last_error(const tnsx_slab* slab);
+/* searches between the slab's sets (indices as in tnsx_slab_step); default: set 0 in itself */
+tnsx_status tnsx_slab_set_active_search(tnsx_slab* slab, int set_i, int set_j, int active);
+/* One step: exchange + search.  Per set k: xyz[k] (n_points[k] x 3 floats), gids[k] (global ids, must fit 31 bits: they become the
+ * int indices of the lists), radii[k] (per-point radii mode only) -- device memory, the OWNED points of this rank. */
+tnsx_status tnsx_slab_step(tnsx_slab* slab, int n_sets, const float* const* xyz, const long long* const* gids, const float* const* radii,
+                           const int* n_points);
+int         tnsx_slab_engine_set(const tnsx_slab* slab, int set_index);   /* the engine's id of [owned | ghosts] of that set, -1 before its first step */
+tnsx_status tnsx_slab_get_info(const tnsx_slab* slab, tnsx_slab_info* out);
+tnsx_status tnsx_slab_debug_set_capacity(tnsx_slab* slab, int side, unsigned rows);   /* tests: shrink the agreed capacity of one link (0 = left) */
+
 #ifdef __cplusplus
 }
 #endif

@@ -260,3 +260,142 @@ def test_halo_pack_asymmetric_capacities():
             assert np.array_equal(rows[:, 0:3].numpy(), pts[got])
             if cnt <= cap:
                 assert len(got) == cnt
+
+
+# ======================================================================================================================
+# The same decomposition through the C entry points of the slab layer (include/tnsx.h: tnsx_slab_balanced_cuts, tnsx_slab_create,
+# tnsx_slab_step; treensearch_amd/csrc/tnsx_slab.cpp) -- what a C++ consumer calls.  The messages move through the library's
+# in-process transport (tnsx_slab_transport_local: a thread per slab, one GPU); on several GPUs the same code runs over
+# tnsx_slab_transport_rccl (ncclSend / ncclRecv).
+# ======================================================================================================================
+def _run_slabs_c(case, world, n_steps=2, speculative=True, shrink_link_before_step=None, shrink_link=None, sets=None, active=None):
+    """sets: [(points, radii or None)] of the WHOLE cloud (default: set 0 of the case); -> ({(i, j): union csr}, log, slabs' sizes)"""
+    import threading
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd.multi import SlabSearchC, SlabTransportC, balanced_cuts_c
+    if sets is None:
+        sets = [(case.points[0], case.radii[0] if case.radii is not None else None)]
+    active = active or [(0, 0)]
+    variable = sets[0][1] is not None
+    max_r = float(max(r.max() for _, r in sets)) if variable else float(case.radius)
+    halo_w = max_r * 1.001
+    group = SlabTransportC.local_group(world)
+    d_sets = [torch.from_numpy(np.ascontiguousarray(p)).cuda() for p, _ in sets]
+    # -- cuts: every emulated rank calls the collective with an equal share of the cloud (the histogram is all-reduced)
+    cuts_by_rank = [None] * world
+    results, errors = [None] * world, []
+    barrier = threading.Barrier(world)
+    owned = [None] * world
+    log = [[] for _ in range(world)]
+
+    def work(k):
+        try:
+            torch.cuda.set_device(0)
+            eng = T.TreeNSearch()
+            tr = SlabTransportC.local(group, k)
+            share = [d[(d.shape[0] * k) // world:(d.shape[0] * (k + 1)) // world].contiguous() for d in d_sets]
+            cuts = balanced_cuts_c(eng, tr, k, world, share, halo_w * 1.001)
+            cuts_by_rank[k] = cuts
+            barrier.wait()
+            mine = []
+            for (p_h, r_h), d in zip(sets, d_sets):
+                own = np.nonzero((p_h[:, 0] >= cuts[k]) & (p_h[:, 0] < cuts[k + 1]))[0]
+                mine.append((torch.from_numpy(np.ascontiguousarray(p_h[own])).cuda(), torch.from_numpy(own.astype(np.int64)).cuda(),
+                             torch.from_numpy(np.ascontiguousarray(r_h[own])).cuda() if r_h is not None else None, own))
+            owned[k] = mine
+            slab = SlabSearchC(float(cuts[k]), float(cuts[k + 1]), None if variable else float(case.radius), eng, tr, k, world,
+                               max_radius=max_r if variable else None, speculative=speculative)
+            slab.set_symmetric_search(case.symmetric)
+            for (i, j) in active:
+                slab.set_active_search(i, j, True)
+            for s in range(n_steps):
+                if shrink_link_before_step == s and shrink_link is not None and k in shrink_link:
+                    slab.debug_set_capacity(1 if k == min(shrink_link) else 0, 8)       # both ends of ONE link
+                slab.step(*[(p, g, r) if variable else (p, g) for (p, g, r, _) in mine])
+                inf = slab.info()
+                log[k].append((bool(inf.speculative_last), bool(inf.redone_last), int(inf.rounds_last)))
+            out = {}
+            for (i, j) in active:
+                offs, idx = eng.neighbor_csr(slab.set_id(i), slab.set_id(j), sort_each=False)
+                assert len(offs) == len(mine[i][3]) + 1, "ghosts must not get lists"
+                out[(i, j)] = (mine[i][3], offs, idx.astype(np.int64))
+            results[k] = out
+            del slab
+            tr.release()
+        except BaseException as e:   # noqa: BLE001
+            errors.append((k, e))
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    SlabTransportC.local_group_release(group)
+    if errors:
+        raise errors[0][1]
+    for k in range(1, world):
+        assert np.array_equal(cuts_by_rank[0], cuts_by_rank[k]), "every rank must arrive at the same cuts"
+    unions = {pr: union_csr(len(sets[pr[0]][0]), [results[k][pr] for k in range(world)]) for pr in active}
+    return unions, log, [len(owned[k][0][3]) for k in range(world)], cuts_by_rank[0]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_c_abi_slab_union_uniform(world, uniform_2m, oracle):
+    """configs[4] at 2 M points through tnsx_slab_*: union of 2 / 4 / 8 slabs == single device == the reference's digest; first step
+    exact (two rounds), second step ONE speculative round without a repair; the cuts equal the Python decomposition's."""
+    import torch
+    from treensearch_amd.multi import SlabDecomposition
+    case, single = uniform_2m
+    unions, log, sizes, cuts = _run_slabs_c(case, world)
+    _check_union(case, unions[(0, 0)], single, oracle)
+    assert max(sizes) < 1.2 * (len(case.points[0]) / world), f"unbalanced slabs {sizes}"
+    for k in range(world):
+        assert log[k][0] == (False, False, 2), f"rank {k}: first step should be exact with two rounds, got {log[k][0]}"
+        assert log[k][1] == (True, False, 1), f"rank {k}: second step should be one speculative round without a repair, got {log[k][1]}"
+    dec = SlabDecomposition(engine=_engine_factory())
+    ref_cuts = dec.balanced_cuts([torch.from_numpy(case.points[0]).cuda()], plane_width=float(case.radius) * 1.001 * 1.001, n_slabs=world)
+    assert np.array_equal(cuts, ref_cuts), f"{cuts} != {ref_cuts}"
+
+
+def test_c_abi_overflow_on_one_link_is_repaired_by_its_two_ends(oracle):
+    """Link 1 <-> 2 of four slabs overflows in a speculative step: ranks 1 and 2 move the missing rows between themselves and search
+    again; ranks 0 and 3 never notice (no collective, no repeated step for them); the union is exact and the next step is
+    speculative again."""
+    case = CS.by_name("uniform_fixed_1000000")
+    single = _single_device(case)
+    unions, log, _, _ = _run_slabs_c(case, 4, n_steps=4, shrink_link_before_step=1, shrink_link=(1, 2))
+    _check_union(case, unions[(0, 0)], single, oracle)
+    assert log[1][1] == (True, True, 2) and log[2][1] == (True, True, 2), (log[1][1], log[2][1])
+    assert log[0][1] == (True, False, 1) and log[3][1] == (True, False, 1), (log[0][1], log[3][1])
+    for k in range(4):
+        assert log[k][2] == (True, False, 1) and log[k][3] == (True, False, 1), f"rank {k}: the steps after the repair are speculative again"
+
+
+def test_c_abi_dam_break_variable_radii(oracle):
+    """clustered cloud (unequal cuts), per-point radii, symmetric search, three slabs"""
+    case = CS.by_name("dam_break_sym_1000000")
+    single = _single_device(case)
+    unions, log, sizes, _ = _run_slabs_c(case, 3)
+    _check_union(case, unions[(0, 0)], single, oracle)
+    assert max(sizes) < 1.35 * (len(case.points[0]) / 3), f"unbalanced slabs {sizes}"
+
+
+def test_c_abi_two_sets_asymmetric_searches(oracle):
+    """two sets (fluid + boundary), searches 0->0 and 0->1 only, three slabs: both sets travel in the same exchange round"""
+    case = CS.by_name("two_set_asym_800000_200000")
+    sets = [(case.points[0], None), (case.points[1], None)]
+    unions, log, _, _ = _run_slabs_c(case, 3, sets=sets, active=[(0, 0), (0, 1)])
+    for (i, j) in [(0, 0), (0, 1)]:
+        g_offs, g_idx = unions[(i, j)]
+        ro, ri = oracle.pair_search(case.points[i], case.points[j], radius=case.radius, same_set=(i == j))
+        assert np.array_equal(g_offs, ro)
+        assert oracle.digest(g_offs, g_idx.astype(np.int32)) == oracle.digest(ro, ri, already_sorted=True)
+        fx = load_golden(case.name)["pairs"][f"{i}->{j}"]["strict"]
+        assert int(g_offs[-1]) == fx["total"]
+    for k in range(3):
+        assert log[k][1] == (True, False, 1)

@@ -59,6 +59,33 @@ __global__ void __launch_bounds__(256) k(float* out, float seed)
 			asm volatile("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8"
 			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
 		}
+		else if (MODE == 13) {  // 8 x v_addc_co_u32 with an sgpr-pair carry-in (per-lane hit counting)
+			asm volatile("v_addc_co_u32 %0, vcc, 0, %0, s[20:21]\n v_addc_co_u32 %1, vcc, 0, %1, s[20:21]\n v_addc_co_u32 %2, vcc, 0, %2, s[20:21]\n v_addc_co_u32 %3, vcc, 0, %3, s[20:21]\n v_addc_co_u32 %4, vcc, 0, %4, s[20:21]\n v_addc_co_u32 %5, vcc, 0, %5, s[20:21]\n v_addc_co_u32 %6, vcc, 0, %6, s[20:21]\n v_addc_co_u32 %7, vcc, 0, %7, s[20:21]"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "vcc", "s20", "s21");
+		}
+		else if (MODE == 14) {  // 8 x v_add_u32 dpp row_shr:1 (scan step)
+			asm volatile("v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %1, %2, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %2, %3, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %3, %4, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+			             "v_add_u32_dpp %4, %5, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %5, %6, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %6, %7, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %7, %0, %7 row_shr:1 row_mask:0xf bank_mask:0xf"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+		}
+		else if (MODE == 15) {  // 8 x v_cmpx_ge_f32 (writes exec) + restore
+			asm volatile("v_cmpx_ge_f32 s[20:21], %0, %8\n s_mov_b64 exec, -1\n v_cmpx_ge_f32 s[22:23], %1, %8\n s_mov_b64 exec, -1\n v_cmpx_ge_f32 s[24:25], %2, %8\n s_mov_b64 exec, -1\n v_cmpx_ge_f32 s[26:27], %3, %8\n s_mov_b64 exec, -1\n"
+			             "v_cmpx_ge_f32 s[28:29], %4, %8\n s_mov_b64 exec, -1\n v_cmpx_ge_f32 s[30:31], %5, %8\n s_mov_b64 exec, -1\n v_cmpx_ge_f32 s[32:33], %6, %8\n s_mov_b64 exec, -1\n v_cmpx_ge_f32 s[34:35], %7, %8\n s_mov_b64 exec, -1"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c) : "s20","s21","s22","s23","s24","s25","s26","s27","s28","s29","s30","s31","s32","s33","s34","s35");
+		}
+		else if (MODE == 16) {  // 8 x v_sub_f32 vgpr + v_alignbit (sign collect)
+			asm volatile("v_alignbit_b32 %0, %0, %8, 31\n v_alignbit_b32 %1, %1, %8, 31\n v_alignbit_b32 %2, %2, %8, 31\n v_alignbit_b32 %3, %3, %8, 31\n v_alignbit_b32 %4, %4, %8, 31\n v_alignbit_b32 %5, %5, %8, 31\n v_alignbit_b32 %6, %6, %8, 31\n v_alignbit_b32 %7, %7, %8, 31"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+		}
+		else if (MODE == 17) {  // 8 x v_writelane_b32 (sgpr data, m0 lane)
+			asm volatile("s_mov_b32 m0, 5\n v_writelane_b32 %0, s20, m0\n v_writelane_b32 %1, s20, m0\n v_writelane_b32 %2, s20, m0\n v_writelane_b32 %3, s20, m0\n v_writelane_b32 %4, s20, m0\n v_writelane_b32 %5, s20, m0\n v_writelane_b32 %6, s20, m0\n v_writelane_b32 %7, s20, m0"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "s20");
+		}
+		else if (MODE == 18) {  // 8 x v_pk_mul_f32 with VGPR-pair broadcast operand (op_sel_hi:[0,1]): the query in vector registers
+			asm volatile("v_pk_add_f32 %0, %8, %0 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %1, %8, %1 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %2, %8, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %3, %8, %3 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+			             "v_pk_add_f32 %4, %8, %4 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %5, %8, %5 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %6, %8, %6 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %7, %8, %7 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]"
+			             : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7) : "v"(b0));
+		}
 		else if (MODE == 12) {  // 8 x v_add_f32 vgpr operands
 			asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8"
 			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
@@ -84,5 +111,7 @@ int main()
 	run<0>("v_mul_f32", d); run<1>("v_pk_mul_f32", d); run<2>("v_fma_f32", d); run<3>("v_pk_fma_f32", d);
 	run<4>("v_cmp_ge_f32 -> sgpr", d); run<5>("v_pk_add_f32 sgpr bcast operand", d); run<6>("v_sub_f32 sgpr operand", d);
 	run<7>("v_cmp_ge_f32 e32 -> vcc", d); run<8>("v_mbcnt_lo/hi (per instr)", d); run<9>("v_cndmask_b32 vcc", d); run<10>("v_readlane_b32", d); run<11>("v_add_u32", d); run<12>("v_add_f32 vgpr", d);
+	run<13>("v_addc_co_u32 sgpr carry-in", d); run<14>("v_add_u32_dpp row_shr:1", d); run<15>("v_cmpx_ge_f32 + s_mov exec", d); run<16>("v_alignbit_b32", d);
+	run<17>("v_writelane_b32", d); run<18>("v_pk_add_f32 vgpr bcast operand", d);
 	return 0;
 }

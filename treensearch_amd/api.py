@@ -77,7 +77,22 @@ ABI_SYMBOLS = [
     "tnsx_run", "tnsx_run_scalar", "tnsx_get_pair_view", "tnsx_mirror_pair_to_host", "tnsx_copy_pair",
     "tnsx_prepare_zsort", "tnsx_get_zsort_order", "tnsx_apply_zsort", "tnsx_get_stats",
     "tnsx_halo_pack", "tnsx_x_histogram", "tnsx_set_query_count", "tnsx_translate_neighbors", "tnsx_set_point_ids", "tnsx_synchronize",
+    # slab layer (tnsx_slab.cpp)
+    "tnsx_slab_rccl_unique_id", "tnsx_slab_transport_rccl", "tnsx_slab_rccl_error", "tnsx_slab_local_group_create", "tnsx_slab_local_group_release",
+    "tnsx_slab_transport_local", "tnsx_slab_transport_release", "tnsx_slab_balanced_cuts", "tnsx_slab_create", "tnsx_slab_destroy",
+    "tnsx_slab_last_error", "tnsx_slab_set_active_search", "tnsx_slab_step", "tnsx_slab_engine_set", "tnsx_slab_get_info",
+    "tnsx_slab_debug_set_capacity",
 ]
+
+
+class SlabTransport(C.Structure):
+    """tnsx_slab_transport (include/tnsx.h): filled by tnsx_slab_transport_rccl / tnsx_slab_transport_local"""
+    _fields_ = [("user", C.c_void_p), ("exchange", C.c_void_p), ("allreduce", C.c_void_p), ("release", C.c_void_p)]
+
+
+class SlabInfo(C.Structure):
+    _fields_ = [("n_owned", C.c_int), ("n_ghost", C.c_int), ("speculative_last", C.c_int), ("redone_last", C.c_int), ("rounds_last", C.c_int),
+                ("bytes_sent", C.c_ulonglong)]
 
 _lib = None
 
@@ -137,6 +152,28 @@ def load_library():
     L.tnsx_get_zsort_order.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(ci)]
     L.tnsx_apply_zsort.argtypes = [vp, ci, vp, C.c_size_t, ci, ci]
     L.tnsx_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    # slab layer
+    tp = C.POINTER(SlabTransport)
+    L.tnsx_slab_rccl_unique_id.argtypes = [vp]
+    L.tnsx_slab_transport_rccl.argtypes = [vp, ci, ci, ci, tp]
+    L.tnsx_slab_rccl_error.restype = C.c_char_p
+    L.tnsx_slab_local_group_create.argtypes = [ci, C.POINTER(vp)]
+    L.tnsx_slab_local_group_release.argtypes = [vp]
+    L.tnsx_slab_local_group_release.restype = None
+    L.tnsx_slab_transport_local.argtypes = [vp, ci, tp]
+    L.tnsx_slab_transport_release.argtypes = [tp]
+    L.tnsx_slab_transport_release.restype = None
+    L.tnsx_slab_balanced_cuts.argtypes = [vp, tp, ci, ci, ci, C.POINTER(vp), C.POINTER(ci), C.c_float, ci, C.POINTER(C.c_float)]
+    L.tnsx_slab_create.argtypes = [vp, tp, ci, ci, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, ci, C.POINTER(vp)]
+    L.tnsx_slab_destroy.argtypes = [vp]
+    L.tnsx_slab_destroy.restype = None
+    L.tnsx_slab_last_error.argtypes = [vp]
+    L.tnsx_slab_last_error.restype = C.c_char_p
+    L.tnsx_slab_set_active_search.argtypes = [vp, ci, ci, ci]
+    L.tnsx_slab_step.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(ci)]
+    L.tnsx_slab_engine_set.argtypes = [vp, ci]
+    L.tnsx_slab_get_info.argtypes = [vp, C.POINTER(SlabInfo)]
+    L.tnsx_slab_debug_set_capacity.argtypes = [vp, ci, C.c_uint]
     _lib = L
     return L
 
@@ -280,6 +317,12 @@ class TreeNSearch:
         ITS current stream (position updates, ghost copies, NCCL receives) is not ordered before it -- wait for it.  With a
         caller-supplied stream everything is in stream order and nothing is waited for."""
         if self._own_stream and any(_is_torch(k) and k.is_cuda for pair in self._keep.values() for k in pair if k is not None):
+            import torch
+            torch.cuda.current_stream().synchronize()
+
+    def _wait_for_producers_of(self, tensors) -> None:
+        """the same for tensors the engine does not hold (slab layer: the owned points handed to tnsx_slab_step)"""
+        if self._own_stream and any(_is_torch(t) and t.is_cuda for t in tensors):
             import torch
             torch.cuda.current_stream().synchronize()
 

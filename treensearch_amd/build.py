@@ -15,7 +15,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libtnsx.so")
-SOURCES = ["tnsx_kernels.hip", "tnsx_build.hip", "tnsx_query.hip", "tnsx_engine.cpp", "tnsx_multi.cpp"]
+SOURCES = ["tnsx_kernels.hip", "tnsx_build.hip", "tnsx_query.hip", "tnsx_engine.cpp", "tnsx_multi.cpp", "tnsx_slab.cpp"]
 HEADERS = ["tnsx_kernels.h", "tnsx_device.h", "tnsx_multi.h", os.path.join(ROOT, "include", "tnsx.h")]
 
 # -ffp-contract=off: the neighbour predicate must not be re-associated or fused behind our back
@@ -52,7 +52,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -1494,6 +1494,10 @@ tnsx_status tnsx_set_query_count(tnsx_context* c, int set_i, int n_query)
 	return TNSX_OK;
 }
 
+// (tnsx_slab.cpp) the stream / device a single-device context works on
+void* tnsx_internal_stream(tnsx_context* c) { return c && !c->multi ? (void*)c->stream : nullptr; }
+int tnsx_internal_device(tnsx_context* c) { return c ? c->device : 0; }
+
 tnsx_status tnsx_get_stats(const tnsx_context* c, tnsx_stats* out)
 {
 	if (!c || !out) return TNSX_ERR_INVALID;

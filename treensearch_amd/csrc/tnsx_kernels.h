@@ -136,6 +136,14 @@ void launch_x_histogram(const float* xyz, int n, float x0, float inv_dx, int n_b
 // list entries j of the records of the first n_query points -> id_map[j], in place
 void launch_translate_records(int* records, const uint64_t* offs_by_orig, int n_query, const int* id_map, int n_cus, hipStream_t s);
 
+// slab layer (tnsx_slab.cpp): rows of W floats [x, y, z, (r,) gid_lo, gid_hi] received from a neighbour -> the tail of a set's [owned | ghosts]
+// arrays.  count == nullptr: all n_rows rows exist; else the first *count do and the others become NaN points (x = NaN: the engine ignores them).
+// *flag is set when a global id does not fit the 32-bit indices of the lists.
+void launch_slab_unpack(const float* rows, uint32_t n_rows, const unsigned int* count, int W, float* xyz, float* radii, int* ids, unsigned int* flag, hipStream_t s);
+void launch_slab_ids(const long long* gids, int n, int* ids, unsigned int* flag, hipStream_t s);          // ids[i] = (int)gids[i]; *flag on overflow
+void launch_slab_flag_gt(const float* v, int n, float limit, unsigned int* flag, hipStream_t s);         // *flag = 1 if any v[i] > limit
+void launch_slab_x_range(const float* xyz, int n, float* minmax, hipStream_t s);                          // minmax[0] = min(.., x), minmax[1] = max(.., x) (NaN skipped)
+
 // ---- start of a pool pass: regions[2 * (POOL_REGIONS + 1)] = {first int, capacity} of every region -> the device table the query reads;
 //      n_shared_empty > 0 (a pair of two different sets): offs[0..n) = 0 and records[0] = 0, the shared empty record at int 0 of the pool
 void launch_pool_begin(const unsigned long long* regions, unsigned long long* table, uint64_t* offs, size_t n_shared_empty, int* records, hipStream_t s);

@@ -7,6 +7,7 @@
 #include "tnsx_kernels.h"
 #include "tnsx_device.h"
 
+#include <algorithm>
 #include <cfloat>
 
 namespace tnsx {
@@ -311,6 +312,84 @@ void launch_halo_pack(const float* xyz, const float* radii, const long long* gid
 	const dim3 grid((n + 256 * HP_ITEMS - 1) / (256 * HP_ITEMS)), block(256);
 	if (radii) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_halo_pack<true>), grid, block, 0, s, xyz, radii, gids, n, left_cut, right_cut, out_left, out_right, cap_left, cap_right, counts);
 	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_halo_pack<false>), grid, block, 0, s, xyz, radii, gids, n, left_cut, right_cut, out_left, out_right, cap_left, cap_right, counts);
+}
+
+// =====================================================================================================
+// slab layer: received halo rows -> the [owned | ghosts] arrays of a set; 64-bit ids -> the 32-bit indices of the lists; checks
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_slab_unpack(const float* __restrict__ rows, uint32_t n_rows, const unsigned int* __restrict__ count, int W,
+                                                     float* __restrict__ xyz, float* __restrict__ radii, int* __restrict__ ids, unsigned int* __restrict__ flag)
+{
+	const uint32_t have = count ? *count : n_rows;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n_rows; i += (size_t)gridDim.x * 256) {
+		const float* r = rows + i * (size_t)W;
+		const bool valid = i < (size_t)have;
+		xyz[3 * i] = valid ? r[0] : __uint_as_float(0x7fc00000u);     // x = NaN: no point
+		xyz[3 * i + 1] = valid ? r[1] : 0.0f;
+		xyz[3 * i + 2] = valid ? r[2] : 0.0f;
+		if (radii) radii[i] = valid ? r[3] : 0.0f;
+		const uint32_t lo = __float_as_uint(r[W - 2]), hi = __float_as_uint(r[W - 1]);
+		ids[i] = valid ? (int)lo : -1;
+		if (valid && (hi != 0u || lo > 0x7fffffffu)) *flag = 1u;
+	}
+}
+__global__ void __launch_bounds__(256) k_slab_ids(const long long* __restrict__ gids, int n, int* __restrict__ ids, unsigned int* __restrict__ flag)
+{
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * 256) {
+		const long long g = gids[i];
+		ids[i] = (int)g;
+		if (g < 0 || g > 0x7fffffffll) *flag = 1u;
+	}
+}
+__global__ void __launch_bounds__(256) k_slab_flag_gt(const float* __restrict__ v, int n, float limit, unsigned int* __restrict__ flag)
+{
+	bool any = false;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * 256) any = any || v[i] > limit;
+	if (__ballot(any) != 0ull && lane_id() == 0) *flag = 1u;
+}
+__global__ void __launch_bounds__(256) k_slab_x_range(const float* __restrict__ xyz, int n, float* __restrict__ minmax)
+{
+	float lo = FLT_MAX, hi = -FLT_MAX;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * 256) {
+		const float x = xyz[3 * i];
+		if (x == x) { lo = fminf(lo, x); hi = fmaxf(hi, x); }
+	}
+	for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, WAVE)); hi = fmaxf(hi, __shfl_xor(hi, o, WAVE)); }
+	if (lane_id() == 0) {
+		// float min / max through integer atomics on the ordered encoding (sign-magnitude -> two's complement order)
+		auto enc = [](float f) { const int b = __float_as_int(f); return b >= 0 ? b : (int)(0x80000000u - (uint32_t)b); };
+		auto dec = [](int e) { return __int_as_float(e >= 0 ? e : (int)(0x80000000u - (uint32_t)e)); };
+		int* mm = reinterpret_cast<int*>(minmax);
+		int old = mm[0];
+		while (enc(lo) < enc(__int_as_float(old))) { const int seen = atomicCAS(mm, old, __float_as_int(lo)); if (seen == old) break; old = seen; }
+		old = mm[1];
+		while (enc(hi) > enc(__int_as_float(old))) { const int seen = atomicCAS(mm + 1, old, __float_as_int(hi)); if (seen == old) break; old = seen; }
+		(void)dec;
+	}
+}
+void launch_slab_unpack(const float* rows, uint32_t n_rows, const unsigned int* count, int W, float* xyz, float* radii, int* ids, unsigned int* flag, hipStream_t s)
+{
+	if (!n_rows) return;
+	const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n_rows + 255) / 256, 4096);
+	hipLaunchKernelGGL(k_slab_unpack, dim3(blocks), dim3(256), 0, s, rows, n_rows, count, W, xyz, radii, ids, flag);
+}
+void launch_slab_ids(const long long* gids, int n, int* ids, unsigned int* flag, hipStream_t s)
+{
+	if (n <= 0) return;
+	const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n + 1023) / 1024, 4096);
+	hipLaunchKernelGGL(k_slab_ids, dim3(blocks), dim3(256), 0, s, gids, n, ids, flag);
+}
+void launch_slab_flag_gt(const float* v, int n, float limit, unsigned int* flag, hipStream_t s)
+{
+	if (n <= 0) return;
+	const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n + 2047) / 2048, 2048);
+	hipLaunchKernelGGL(k_slab_flag_gt, dim3(blocks), dim3(256), 0, s, v, n, limit, flag);
+}
+void launch_slab_x_range(const float* xyz, int n, float* minmax, hipStream_t s)
+{
+	if (n <= 0) return;
+	const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n + 4095) / 4096, 1024);
+	hipLaunchKernelGGL(k_slab_x_range, dim3(blocks), dim3(256), 0, s, xyz, n, minmax);
 }
 
 // =====================================================================================================

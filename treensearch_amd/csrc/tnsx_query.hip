@@ -175,7 +175,13 @@ __device__ __forceinline__ void deal_run(uint32_t tbl, uint32_t p0, uint32_t p1,
 {
 	uint32_t n = p1 - p0;   // wave-uniform
 	uint32_t pos = p0;
-	while (n != 0u) {       // (one piece: a run is three cells of the grid)
+	if (n - 1u < 64u) {     // the usual case, without the loop's bookkeeping: one piece (a run is three cells of the grid)
+		const uint32_t v = lane + (pos + d);
+		asm volatile("s_mov_b32 m0, %[b]\n\ts_lshr_b64 exec, -1, %[sh]\n\tds_write_addtid_b32 %[v]\n\ts_mov_b64 exec, -1"
+		             : : [b] "s"(tbl + 4u * pos), [sh] "s"(64u - n), [v] "v"(v) : "memory");
+		return;
+	}
+	while (n != 0u) {
 		const uint32_t c = n < 64u ? n : 64u;
 		const uint32_t v = lane + (pos + d);
 		asm volatile("s_mov_b32 m0, %[b]\n\ts_lshr_b64 exec, -1, %[sh]\n\tds_write_addtid_b32 %[v]\n\ts_mov_b64 exec, -1"
@@ -209,7 +215,7 @@ __device__ __forceinline__ void lookup_cell(const QueryArgs& a, uint32_t key, bo
 	// branch-free (a load inside an exec region would be waited for inside it): lanes without a neighbour cell read entry 0
 	const int x = cx + (lane % 3) - 1, y = cy + ((lane / 3) % 3) - 1, z = cz + (lane / 9) - 1;
 	const bool use = valid && lane < 27 && x >= 0 && x < (int)nx && y >= 0 && y < (int)ny && z >= 0 && z < (int)nz;
-	const size_t idx = use ? ((size_t)z * ny + y) * nx + x : 0;
+	const uint32_t idx = use ? ((uint32_t)z * ny + (uint32_t)y) * nx + (uint32_t)x : 0u;   // (the dense table has at most 2^30 cells)
 	const uint2 r = a.table_j[idx];
 	s = use ? r.x : 0u;
 	e = use ? r.y : 0u;
@@ -791,7 +797,8 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 			uint32_t P = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[0] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[0], 0u));
 			#pragma unroll
 			for (int k = 1; k < NC; k++) P = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[k], P));
-			addr = rec + (P << 2);
+			// (spelled out: left to itself the compiler adds spos and the staging base in two vector instructions)
+			asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(addr) : "v"(P), "s"(rec));
 		}
 		stage_all4<NC>(addr, m, cid);
 		const uint32_t cnt = (readlane_u32(addr, WAVE - 1) - rec) >> 2;

@@ -1,0 +1,711 @@
+// Spatial-slab layer behind the C ABI (include/tnsx.h, "slab layer"): one process (or thread) per GPU, slabs along x, ONE ghost-halo
+// exchange per step over RCCL (ncclSend / ncclRecv inside one group -- xGMI is point to point, only the two neighbours of a slab
+// ever talk to it), balanced cuts from an all-reduced x histogram.  No counterpart in the single-process reference
+// (SURVEY.md section 8e); the search itself is the unchanged engine of tnsx_engine.cpp, driven through its public entry points:
+// the ghosts are APPENDED to the owned points of their set, marked candidates-only (tnsx_set_query_count) and carry their global
+// ids (tnsx_set_point_ids), so the lists the engine writes are global ids and no collective touches the data path.
+//
+// Wire format per neighbour, set and step: rows of W = 5 (+1 with per-point radii) floats [x, y, z, (r,) gid_lo, gid_hi]; row 0
+// is a header whose first word is the row count.
+//   exact step        (first step, after an overflow): counts first (4 bytes each way), then exactly the rows -- two rounds.
+//   speculative step  (capacities known): ONE round of fixed-capacity messages, nothing is read on the host; rows past the count
+//                     become NaN points on the receiver (the engine ignores them).  The counts are checked after the search
+//                     (which synchronises anyway); an overflowed LINK is repaired by its two ends alone -- both see the same
+//                     two numbers, so they agree without any collective -- and only they search again.
+// RCCL is loaded at run time (dlopen): a single-GPU user of libtnsx.so needs no RCCL at all.
+#include "tnsx.h"
+#include "tnsx_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <vector>
+
+extern "C" {
+// (tnsx_engine.cpp) the stream / device a context works on
+void* tnsx_internal_stream(tnsx_context* c);
+int tnsx_internal_device(tnsx_context* c);
+}
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------- RCCL, loaded lazily
+struct RcclApi {
+	void* lib = nullptr;
+	ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+	ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*GroupStart)() = nullptr;
+	ncclResult_t (*GroupEnd)() = nullptr;
+	ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+	const char* (*GetErrorString)(ncclResult_t) = nullptr;
+	std::string error;
+	bool load()
+	{
+		if (lib) return true;
+		// the copy the process already has (PyTorch ships its own) first, then the ROCm installation's
+		const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" };
+		for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+		if (!lib) for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+		if (!lib) { error = std::string("RCCL not found (dlopen librccl.so): ") + (dlerror() ? dlerror() : ""); return false; }
+#define TNSX_SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(lib, name)); if (!field) { error = std::string("RCCL symbol missing: ") + name; lib = nullptr; return false; }
+		TNSX_SYM(GetUniqueId, "ncclGetUniqueId") TNSX_SYM(CommInitRank, "ncclCommInitRank") TNSX_SYM(CommDestroy, "ncclCommDestroy")
+		TNSX_SYM(GroupStart, "ncclGroupStart") TNSX_SYM(GroupEnd, "ncclGroupEnd") TNSX_SYM(Send, "ncclSend") TNSX_SYM(Recv, "ncclRecv")
+		TNSX_SYM(AllReduce, "ncclAllReduce") TNSX_SYM(GetErrorString, "ncclGetErrorString")
+#undef TNSX_SYM
+		return true;
+	}
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mu;
+
+struct RcclTransport {
+	ncclComm_t comm = nullptr;
+	int device = 0;
+};
+
+int rccl_exchange(void* user, int, int, const tnsx_slab_op* ops, int n_ops, void* stream)
+{
+	RcclTransport* t = static_cast<RcclTransport*>(user);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	bool any = false;
+	for (int k = 0; k < n_ops; k++) any = any || ops[k].send_bytes || ops[k].recv_bytes;
+	if (!any) return 0;
+	if (g_rccl.GroupStart() != ncclSuccess) return 1;
+	int rc = 0;
+	for (int k = 0; k < n_ops && rc == 0; k++) {
+		if (ops[k].send_bytes && g_rccl.Send(ops[k].send, ops[k].send_bytes, ncclChar, ops[k].peer, t->comm, s) != ncclSuccess) rc = 1;
+		if (ops[k].recv_bytes && g_rccl.Recv(ops[k].recv, ops[k].recv_bytes, ncclChar, ops[k].peer, t->comm, s) != ncclSuccess) rc = 1;
+	}
+	if (g_rccl.GroupEnd() != ncclSuccess) rc = 1;
+	return rc;
+}
+int rccl_allreduce(void* user, int, int, void* buf, int count, int op, void* stream)
+{
+	RcclTransport* t = static_cast<RcclTransport*>(user);
+	const ncclDataType_t dt = op == TNSX_SLAB_SUM_U32 ? ncclUint32 : ncclFloat32;
+	const ncclRedOp_t ro = op == TNSX_SLAB_SUM_U32 ? ncclSum : (op == TNSX_SLAB_MIN_F32 ? ncclMin : ncclMax);
+	return g_rccl.AllReduce(buf, buf, (size_t)count, dt, ro, t->comm, static_cast<hipStream_t>(stream)) == ncclSuccess ? 0 : 1;
+}
+void rccl_release(void* user)
+{
+	RcclTransport* t = static_cast<RcclTransport*>(user);
+	if (t && t->comm) (void)g_rccl.CommDestroy(t->comm);
+	delete t;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- in-process transport
+// All slabs of a decomposition inside ONE process (a thread per slab, any streams, one or several devices that can reach each
+// other's memory): what tests/test_gpu_slabs.py runs on a single GPU.  A message is handed over as {pointer, bytes, event}: the
+// receiver orders its stream behind the sender's event and copies device to device; the sender orders its stream behind the copy.
+struct LocalMsg { const void* ptr; size_t bytes; hipEvent_t ready; hipEvent_t* done; bool* consumed; };
+struct LocalGroup {
+	int world = 0;
+	std::mutex mu;
+	std::condition_variable cv;
+	std::vector<std::deque<LocalMsg>> box;     // [src * world + dst]
+	// all-reduce
+	int ar_arrived = 0, ar_left = 0;
+	uint64_t ar_gen = 0;
+	std::vector<uint32_t> ar_acc;
+	int refs = 0;
+};
+struct LocalTransport { LocalGroup* g; int rank; };
+
+int local_exchange(void* user, int rank, int world, const tnsx_slab_op* ops, int n_ops, void* stream)
+{
+	LocalTransport* t = static_cast<LocalTransport*>(user);
+	LocalGroup* g = t->g;
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	struct Sent { hipEvent_t ready, done; bool consumed; };
+	std::vector<Sent> sent((size_t)n_ops);
+	// 1. post every send
+	for (int k = 0; k < n_ops; k++) {
+		sent[(size_t)k] = { nullptr, nullptr, true };
+		if (!ops[k].send_bytes) continue;
+		Sent& e = sent[(size_t)k];
+		e.consumed = false;
+		if (hipEventCreateWithFlags(&e.ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(e.ready, s) != hipSuccess) return 1;
+		std::lock_guard<std::mutex> lk(g->mu);
+		g->box[(size_t)rank * world + ops[k].peer].push_back({ ops[k].send, ops[k].send_bytes, e.ready, &e.done, &e.consumed });
+		g->cv.notify_all();
+	}
+	// 2. take every message addressed to this rank, in the order of the ops
+	int rc = 0;
+	for (int k = 0; k < n_ops; k++) {
+		if (!ops[k].recv_bytes) continue;
+		LocalMsg m;
+		{
+			std::unique_lock<std::mutex> lk(g->mu);
+			auto& q = g->box[(size_t)ops[k].peer * world + rank];
+			g->cv.wait(lk, [&] { return !q.empty(); });
+			m = q.front();
+			q.pop_front();
+		}
+		hipEvent_t done = nullptr;
+		if (m.bytes != ops[k].recv_bytes) rc = 2;   // the two ends disagree on a message size: a protocol error
+		if (rc == 0 && (hipStreamWaitEvent(s, m.ready, 0) != hipSuccess ||
+		                hipMemcpyAsync(ops[k].recv, m.ptr, m.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)) rc = 1;
+		if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess || hipEventRecord(done, s) != hipSuccess) rc = rc ? rc : 1;
+		std::lock_guard<std::mutex> lk(g->mu);
+		*m.done = done;
+		*m.consumed = true;
+		g->cv.notify_all();
+	}
+	// 3. the send buffers may be reused once the receivers' copies are ordered before this stream's later work
+	for (int k = 0; k < n_ops; k++) {
+		Sent& e = sent[(size_t)k];
+		if (!ops[k].send_bytes) continue;
+		{
+			std::unique_lock<std::mutex> lk(g->mu);
+			g->cv.wait(lk, [&] { return e.consumed; });
+		}
+		if (e.done) { if (hipStreamWaitEvent(s, e.done, 0) != hipSuccess) rc = rc ? rc : 1; }
+		// (events are destroyed by their users: `ready` by the sender once consumed, `done` by the sender after the wait was enqueued)
+		(void)hipEventDestroy(e.ready);
+		if (e.done) (void)hipEventDestroy(e.done);
+	}
+	return rc;
+}
+int local_allreduce(void* user, int, int world, void* buf, int count, int op, void* stream)
+{
+	LocalTransport* t = static_cast<LocalTransport*>(user);
+	LocalGroup* g = t->g;
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	std::vector<uint32_t> mine((size_t)count);
+	if (hipMemcpyAsync(mine.data(), buf, (size_t)count * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return 1;
+	std::vector<uint32_t> result;
+	{
+		std::unique_lock<std::mutex> lk(g->mu);
+		g->cv.wait(lk, [&] { return g->ar_left == 0; });             // the previous reduction has been read by everybody
+		if (g->ar_arrived == 0) g->ar_acc = mine;
+		else for (int i = 0; i < count; i++) {
+			uint32_t& a = g->ar_acc[(size_t)i];
+			if (op == TNSX_SLAB_SUM_U32) a += mine[(size_t)i];
+			else {
+				float fa, fb; std::memcpy(&fa, &a, 4); std::memcpy(&fb, &mine[(size_t)i], 4);
+				fa = op == TNSX_SLAB_MIN_F32 ? std::min(fa, fb) : std::max(fa, fb);
+				std::memcpy(&a, &fa, 4);
+			}
+		}
+		const uint64_t gen = g->ar_gen;
+		if (++g->ar_arrived == world) { g->ar_arrived = 0; g->ar_left = world; g->ar_gen++; g->cv.notify_all(); }
+		else g->cv.wait(lk, [&] { return g->ar_gen != gen; });
+		result = g->ar_acc;
+		if (--g->ar_left == 0) g->cv.notify_all();
+	}
+	if (hipMemcpyAsync(buf, result.data(), (size_t)count * 4, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return 1;
+	return 0;
+}
+void local_release(void* user)
+{
+	LocalTransport* t = static_cast<LocalTransport*>(user);
+	if (!t) return;
+	bool last;
+	{ std::lock_guard<std::mutex> lk(t->g->mu); last = --t->g->refs == 0; }
+	if (last) delete t->g;
+	delete t;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- the slab
+struct DBuf {
+	void* p = nullptr; size_t cap = 0;
+	~DBuf() { if (p) (void)hipFree(p); }
+	bool reserve(size_t bytes, bool keep = false)
+	{
+		if (bytes <= cap) return true;
+		void* q = nullptr;
+		const size_t want = bytes + bytes / 8 + 4096;
+		if (hipMalloc(&q, want) != hipSuccess) return false;
+		if (keep && p && cap) (void)hipMemcpy(q, p, cap, hipMemcpyDeviceToDevice);
+		if (p) (void)hipFree(p);
+		p = q; cap = want;
+		return true;
+	}
+	template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+struct SetState {
+	int set_id = -1;
+	DBuf send[2], recv[2];        // rows of W floats behind one header row
+	uint32_t cap_s[2] = { 0, 0 }, cap_r[2] = { 0, 0 };
+	bool caps_known[2] = { false, false };
+	DBuf xyz, radii, ids;         // [owned | ghosts]
+	int n_owned = 0, n_ghost = 0;
+	uint32_t n_out[2] = { 0, 0 }, n_in[2] = { 0, 0 };
+};
+inline uint32_t capacity_rule(uint32_t count) { return count + count / 4 + 256; }
+
+}  // namespace
+
+struct tnsx_slab {
+	tnsx_context* engine = nullptr;
+	tnsx_slab_transport tr{};
+	int rank = 0, world = 1;
+	float lo = 0, hi = 0, radius = -1, max_radius = 0, halo = 0;
+	bool variable = false, speculative = true;
+	hipStream_t stream = nullptr;
+	int device = 0;
+	std::vector<SetState> sets;
+	std::vector<std::pair<std::pair<int, int>, int>> active;   // ((i, j), on) in terms of slab set indices
+	bool active_applied = false;
+	DBuf d_small;                 // device scratch: pack counts (2 per set), flags
+	unsigned int* h_small = nullptr;   // pinned mirror
+	size_t small_words = 0;
+	tnsx_slab_info info{};
+	std::string last_error;
+};
+
+namespace {
+tnsx_status sfail(tnsx_slab* s, tnsx_status st, const char* fmt, ...)
+{
+	char buf[512];
+	va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+	s->last_error = buf;
+	return st;
+}
+#define SHIP(s, call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return sfail(s, TNSX_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
+#define SENG(s, call) do { const tnsx_status r_ = (call); if (r_ != TNSX_OK) return sfail(s, r_, "%s: %s", #call, tnsx_last_error((s)->engine)); } while (0)
+
+inline int peer_of(const tnsx_slab* s, int side) { return side == 0 ? s->rank - 1 : s->rank + 1; }
+inline bool has_side(const tnsx_slab* s, int side) { const int p = peer_of(s, side); return p >= 0 && p < s->world; }
+
+// scratch layout (32-bit words): [set * 8 + 0..1] pack counts, [+2..3] received header counts, [+4] radius flag, [+5] id flag
+inline unsigned int* small_dev(tnsx_slab* s, size_t k) { return s->d_small.as<unsigned int>() + k * 8; }
+inline unsigned int* small_host(tnsx_slab* s, size_t k) { return s->h_small + k * 8; }
+
+tnsx_status ensure_small(tnsx_slab* s, size_t n_sets)
+{
+	if (n_sets * 8 <= s->small_words) return TNSX_OK;
+	if (!s->d_small.reserve(n_sets * 8 * sizeof(unsigned int))) return sfail(s, TNSX_ERR_HIP, "out of device memory");
+	if (s->h_small) (void)hipHostFree(s->h_small);
+	SHIP(s, hipHostMalloc((void**)&s->h_small, n_sets * 8 * sizeof(unsigned int)));
+	s->small_words = n_sets * 8;
+	return TNSX_OK;
+}
+
+// pack the halo rows of one set; sides[] says which sides are wanted; cap_rows[] = rows the send buffers may take (without header)
+tnsx_status pack(tnsx_slab* s, size_t k, const float* xyz, const long long* gids, const float* radii, int n, const bool want[2], const uint32_t cap_rows[2], bool wait_counts)
+{
+	SetState& st = s->sets[k];
+	const size_t W = s->variable ? 6 : 5;
+	for (int side = 0; side < 2; side++) if (want[side] && !st.send[side].reserve(((size_t)cap_rows[side] + 1) * W * 4, false)) return sfail(s, TNSX_ERR_HIP, "out of device memory (halo buffers)");
+	unsigned int host_counts[2] = { 0, 0 };
+	SENG(s, tnsx_halo_pack(s->engine, xyz, radii, gids, n, s->lo + s->halo, s->hi - s->halo,
+	                       want[0] ? st.send[0].as<float>() + W : nullptr, want[1] ? st.send[1].as<float>() + W : nullptr, cap_rows[0], cap_rows[1],
+	                       small_dev(s, k), wait_counts ? host_counts : nullptr));
+	if (wait_counts) for (int side = 0; side < 2; side++) if (want[side]) st.n_out[side] = host_counts[side];
+	// header word = the count, device to device
+	for (int side = 0; side < 2; side++) if (want[side]) SHIP(s, hipMemcpyAsync(st.send[side].p, small_dev(s, k) + side, 4, hipMemcpyDeviceToDevice, s->stream));
+	return TNSX_OK;
+}
+
+// [owned | ghosts] of one set -> the engine.  counts_on_device: the ghost rows of side `side` that exist are given by the header word
+// of its receive buffer (rows past it become NaN points); else by n_in (exact).
+tnsx_status assemble(tnsx_slab* s, size_t k, const float* xyz, const long long* gids, const float* radii, int n, const uint32_t rows[2], bool counts_on_device)
+{
+	SetState& st = s->sets[k];
+	const size_t W = s->variable ? 6 : 5;
+	const size_t m = (size_t)rows[0] + rows[1];
+	const size_t total = (size_t)n + m;
+	if (total > 0x7fffffffull) return sfail(s, TNSX_ERR_LIST_TOO_LONG, "a slab holds more than 2^31 - 1 points");
+	if (!st.xyz.reserve(std::max<size_t>(total, 1) * 12) || !st.ids.reserve(std::max<size_t>(total, 1) * 4) || (s->variable && !st.radii.reserve(std::max<size_t>(total, 1) * 4)))
+		return sfail(s, TNSX_ERR_HIP, "out of device memory (slab point buffers)");
+	if (n > 0) {
+		if (xyz != st.xyz.as<float>()) SHIP(s, hipMemcpyAsync(st.xyz.p, xyz, (size_t)n * 12, hipMemcpyDeviceToDevice, s->stream));
+		if (s->variable) SHIP(s, hipMemcpyAsync(st.radii.p, radii, (size_t)n * 4, hipMemcpyDeviceToDevice, s->stream));
+		tnsx::launch_slab_ids(gids, n, st.ids.as<int>(), small_dev(s, k) + 5, s->stream);
+		if (s->variable) tnsx::launch_slab_flag_gt(radii, n, s->max_radius, small_dev(s, k) + 4, s->stream);
+	}
+	size_t at = (size_t)n;
+	for (int side = 0; side < 2; side++) {
+		if (!rows[side]) continue;
+		const float* rbuf = st.recv[side].as<float>();
+		tnsx::launch_slab_unpack(rbuf + W, rows[side], counts_on_device ? reinterpret_cast<const unsigned int*>(rbuf) : nullptr, (int)W,
+		                         st.xyz.as<float>() + 3 * at, s->variable ? st.radii.as<float>() + at : nullptr, st.ids.as<int>() + at, small_dev(s, k) + 5, s->stream);
+		at += rows[side];
+	}
+	SHIP(s, hipGetLastError());
+	st.n_owned = n; st.n_ghost = (int)m;
+	const unsigned flags = TNSX_F32 | TNSX_DEVICE | (s->variable ? TNSX_VARIABLE : 0u);
+	const void* rp = s->variable ? st.radii.p : nullptr;
+	if (st.set_id < 0) {
+		const int id = tnsx_add_point_set(s->engine, st.xyz.p, rp, (int)total, flags);
+		if (id < 0) return sfail(s, (tnsx_status)(-id), "tnsx_add_point_set: %s", tnsx_last_error(s->engine));
+		st.set_id = id;
+	}
+	else SENG(s, tnsx_resize_point_set(s->engine, st.set_id, st.xyz.p, rp, (int)total, flags));
+	SENG(s, tnsx_set_query_count(s->engine, st.set_id, n));
+	SENG(s, tnsx_set_point_ids(s->engine, st.set_id, st.ids.as<int>()));
+	return TNSX_OK;
+}
+
+tnsx_status run_engine(tnsx_slab* s)
+{
+	if (!s->active_applied) {
+		if (s->active.empty()) s->active.push_back({ { 0, 0 }, 1 });
+		for (const auto& a : s->active) {
+			if ((size_t)a.first.first >= s->sets.size() || (size_t)a.first.second >= s->sets.size()) return sfail(s, TNSX_ERR_INVALID, "tnsx_slab_set_active_search: set %d or %d was never stepped", a.first.first, a.first.second);
+			SENG(s, tnsx_set_active_search(s->engine, s->sets[(size_t)a.first.first].set_id, s->sets[(size_t)a.first.second].set_id, a.second));
+		}
+		s->active_applied = true;
+	}
+	SENG(s, tnsx_run(s->engine));
+	return TNSX_OK;
+}
+
+int do_exchange(tnsx_slab* s, const std::vector<tnsx_slab_op>& ops)
+{
+	if (ops.empty() || !s->tr.exchange) return 0;
+	s->info.rounds_last++;
+	for (const tnsx_slab_op& o : ops) s->info.bytes_sent += o.send_bytes;
+	return s->tr.exchange(s->tr.user, s->rank, s->world, ops.data(), (int)ops.size(), s->stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tnsx_slab_last_error(const tnsx_slab* s) { return s ? s->last_error.c_str() : "null slab"; }
+
+// ------------------------------------------------------------------------------------------------ transports
+tnsx_status tnsx_slab_rccl_unique_id(void* out128)
+{
+	std::lock_guard<std::mutex> lk(g_rccl_mu);
+	if (!out128 || !g_rccl.load()) return TNSX_ERR_STATE;
+	ncclUniqueId id;
+	if (g_rccl.GetUniqueId(&id) != ncclSuccess) return TNSX_ERR_HIP;
+	std::memcpy(out128, id.internal, NCCL_UNIQUE_ID_BYTES);
+	return TNSX_OK;
+}
+const char* tnsx_slab_rccl_error(void) { return g_rccl.error.c_str(); }
+
+tnsx_status tnsx_slab_transport_rccl(const void* unique_id128, int rank, int world, int device, tnsx_slab_transport* out)
+{
+	if (!unique_id128 || !out || rank < 0 || rank >= world) return TNSX_ERR_INVALID;
+	{
+		std::lock_guard<std::mutex> lk(g_rccl_mu);
+		if (!g_rccl.load()) return TNSX_ERR_STATE;
+	}
+	if (device >= 0 && hipSetDevice(device) != hipSuccess) return TNSX_ERR_HIP;
+	ncclUniqueId id;
+	std::memcpy(id.internal, unique_id128, NCCL_UNIQUE_ID_BYTES);
+	RcclTransport* t = new RcclTransport();
+	t->device = device;
+	const ncclResult_t r = g_rccl.CommInitRank(&t->comm, world, id, rank);
+	if (r != ncclSuccess) { g_rccl.error = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); delete t; return TNSX_ERR_HIP; }
+	out->user = t; out->exchange = rccl_exchange; out->allreduce = rccl_allreduce; out->release = rccl_release;
+	return TNSX_OK;
+}
+
+tnsx_status tnsx_slab_local_group_create(int world, void** group_out)
+{
+	if (world < 1 || !group_out) return TNSX_ERR_INVALID;
+	LocalGroup* g = new LocalGroup();
+	g->world = world;
+	g->box.resize((size_t)world * world);
+	g->refs = 1;            // the creator's reference, dropped by tnsx_slab_local_group_release
+	*group_out = g;
+	return TNSX_OK;
+}
+void tnsx_slab_local_group_release(void* group)
+{
+	LocalGroup* g = static_cast<LocalGroup*>(group);
+	if (!g) return;
+	bool last;
+	{ std::lock_guard<std::mutex> lk(g->mu); last = --g->refs == 0; }
+	if (last) delete g;
+}
+tnsx_status tnsx_slab_transport_local(void* group, int rank, tnsx_slab_transport* out)
+{
+	LocalGroup* g = static_cast<LocalGroup*>(group);
+	if (!g || !out || rank < 0 || rank >= g->world) return TNSX_ERR_INVALID;
+	{ std::lock_guard<std::mutex> lk(g->mu); g->refs++; }
+	LocalTransport* t = new LocalTransport{ g, rank };
+	out->user = t; out->exchange = local_exchange; out->allreduce = local_allreduce; out->release = local_release;
+	return TNSX_OK;
+}
+void tnsx_slab_transport_release(tnsx_slab_transport* t)
+{
+	if (t && t->release) t->release(t->user);
+	if (t) { t->user = nullptr; t->exchange = nullptr; t->allreduce = nullptr; t->release = nullptr; }
+}
+
+// ------------------------------------------------------------------------------------------------ decomposition
+tnsx_status tnsx_slab_balanced_cuts(tnsx_context* engine, const tnsx_slab_transport* tr, int rank, int world, int n_sets, const float* const* xyz,
+                                    const int* n_points, float plane_width, int n_slabs, float* cuts_out)
+{
+	if (!engine || !cuts_out || n_sets < 0 || world < 1 || !(plane_width > 0.0f)) return TNSX_ERR_INVALID;
+	if (n_slabs <= 0) n_slabs = world;
+	const int device = tnsx_internal_device(engine);
+	hipStream_t stream = static_cast<hipStream_t>(tnsx_internal_stream(engine));
+	if (hipSetDevice(device) != hipSuccess) return TNSX_ERR_HIP;
+	const int MAX_PLANES = 32768;   // the reference's cells-per-axis limit (TreeNSearch.cpp:510-515)
+	DBuf d;
+	if (!d.reserve((size_t)(MAX_PLANES + 8) * 4)) return TNSX_ERR_HIP;
+	// ---- global x range: min / max over all sets and ranks
+	float init[2] = { FLT_MAX, -FLT_MAX };
+	if (hipMemcpyAsync(d.p, init, 8, hipMemcpyHostToDevice, stream) != hipSuccess) return TNSX_ERR_HIP;
+	for (int k = 0; k < n_sets; k++) if (n_points[k] > 0) tnsx::launch_slab_x_range(xyz[k], n_points[k], d.as<float>(), stream);
+	if (world > 1 && tr && tr->allreduce) {
+		if (tr->allreduce(tr->user, rank, world, d.as<float>(), 1, TNSX_SLAB_MIN_F32, stream) || tr->allreduce(tr->user, rank, world, d.as<float>() + 1, 1, TNSX_SLAB_MAX_F32, stream)) return TNSX_ERR_HIP;
+	}
+	float range[2];
+	if (hipMemcpyAsync(range, d.p, 8, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return TNSX_ERR_HIP;
+	float x0 = range[0], x1 = range[1];
+	if (!(std::isfinite(x0) && std::isfinite(x1)) || x1 < x0) { x0 = 0.0f; x1 = 0.0f; }   // no points anywhere
+	const int n_planes = (int)((x1 - x0) / plane_width) + 1;
+	if (n_planes > MAX_PLANES || n_planes < n_slabs) return TNSX_ERR_GRID_TOO_LARGE;     // (too many planes, or fewer planes than slabs)
+	// ---- histogram of the x planes, all ranks
+	unsigned int* hist = d.as<unsigned int>() + 8;
+	if (hipMemsetAsync(hist, 0, (size_t)n_planes * 4, stream) != hipSuccess) return TNSX_ERR_HIP;
+	const float inv = 1.0f / plane_width;
+	for (int k = 0; k < n_sets; k++) if (n_points[k] > 0 && tnsx_x_histogram(engine, xyz[k], n_points[k], x0, inv, n_planes, hist) != TNSX_OK) return TNSX_ERR_HIP;
+	if (world > 1 && tr && tr->allreduce && tr->allreduce(tr->user, rank, world, hist, n_planes, TNSX_SLAB_SUM_U32, stream)) return TNSX_ERR_HIP;
+	std::vector<unsigned int> h((size_t)n_planes);
+	if (hipMemcpyAsync(h.data(), hist, (size_t)n_planes * 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return TNSX_ERR_HIP;
+	// ---- cuts at the plane boundaries closest to the k / n_slabs quantiles, at least one plane per slab
+	std::vector<uint64_t> cum((size_t)n_planes);
+	uint64_t run = 0;
+	for (int b = 0; b < n_planes; b++) { run += h[(size_t)b]; cum[(size_t)b] = run; }
+	const uint64_t total = run;
+	cuts_out[0] = -INFINITY; cuts_out[n_slabs] = INFINITY;
+	int prev = 0;
+	for (int k = 1; k < n_slabs; k++) {
+		int b = k;
+		if (total) {
+			const double target = (double)total * k / n_slabs;
+			b = (int)(std::lower_bound(cum.begin(), cum.end(), target, [](uint64_t c, double t) { return (double)c < t; }) - cum.begin()) + 1;   // boundary b has cum[b - 1] points to its left
+			if (b >= 2 && std::fabs((double)cum[(size_t)b - 2] - target) <= std::fabs((double)cum[(size_t)std::min(b, n_planes) - 1] - target)) b -= 1;
+		}
+		b = std::min(std::max(b, prev + 1), n_planes - (n_slabs - k));
+		cuts_out[k] = x0 + (float)b * plane_width;
+		prev = b;
+	}
+	return TNSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ the slab
+tnsx_status tnsx_slab_create(tnsx_context* engine, const tnsx_slab_transport* transport, int rank, int world, float slab_lo, float slab_hi, float radius,
+                             float max_radius, float halo_margin, int speculative, tnsx_slab** out)
+{
+	if (!engine || !out || world < 1 || rank < 0 || rank >= world) return TNSX_ERR_INVALID;
+	if (world > 1 && (!transport || !transport->exchange)) return TNSX_ERR_INVALID;
+	tnsx_slab* s = new tnsx_slab();
+	s->engine = engine;
+	if (transport) s->tr = *transport;
+	s->rank = rank; s->world = world;
+	s->lo = slab_lo; s->hi = slab_hi;
+	s->variable = !(radius > 0.0f);
+	s->radius = radius;
+	s->max_radius = s->variable ? max_radius : radius;
+	if (!(s->max_radius > 0.0f)) { delete s; return TNSX_ERR_INVALID; }   // per-point radii: an upper bound of every radius sizes the halo
+	s->halo = s->max_radius * (1.0f + (halo_margin > 0.0f ? halo_margin : 1.0e-3f));
+	s->speculative = speculative != 0;
+	s->stream = static_cast<hipStream_t>(tnsx_internal_stream(engine));
+	s->device = tnsx_internal_device(engine);
+	if (!s->stream) { delete s; return TNSX_ERR_STATE; }   // (a multi-device context shards host data itself: tnsx_options.n_devices)
+	if (!s->variable && tnsx_set_search_radius(engine, radius) != TNSX_OK) { delete s; return TNSX_ERR_CONFIG; }
+	*out = s;
+	return TNSX_OK;
+}
+
+void tnsx_slab_destroy(tnsx_slab* s)
+{
+	if (!s) return;
+	(void)hipSetDevice(s->device);
+	(void)hipStreamSynchronize(s->stream);
+	if (s->h_small) (void)hipHostFree(s->h_small);
+	delete s;
+}
+
+tnsx_status tnsx_slab_set_active_search(tnsx_slab* s, int set_i, int set_j, int active)
+{
+	if (!s || set_i < 0 || set_j < 0) return TNSX_ERR_INVALID;
+	for (auto& a : s->active) if (a.first.first == set_i && a.first.second == set_j) { a.second = active ? 1 : 0; s->active_applied = false; return TNSX_OK; }
+	s->active.push_back({ { set_i, set_j }, active ? 1 : 0 });
+	s->active_applied = false;
+	return TNSX_OK;
+}
+
+int tnsx_slab_engine_set(const tnsx_slab* s, int set_index)
+{
+	return (s && set_index >= 0 && (size_t)set_index < s->sets.size()) ? s->sets[(size_t)set_index].set_id : -1;
+}
+
+tnsx_status tnsx_slab_get_info(const tnsx_slab* s, tnsx_slab_info* out)
+{
+	if (!s || !out) return TNSX_ERR_INVALID;
+	*out = s->info;
+	return TNSX_OK;
+}
+
+tnsx_status tnsx_slab_step(tnsx_slab* s, int n_sets, const float* const* xyz, const long long* const* gids, const float* const* radii, const int* n_points)
+{
+	if (!s || n_sets < 1 || !xyz || !gids || !n_points) return TNSX_ERR_INVALID;
+	if (hipSetDevice(s->device) != hipSuccess) return sfail(s, TNSX_ERR_HIP, "hipSetDevice failed");
+	for (int k = 0; k < n_sets; k++) {
+		if (n_points[k] < 0 || (n_points[k] > 0 && (!xyz[k] || !gids[k]))) return sfail(s, TNSX_ERR_INVALID, "tnsx_slab_step: null pointer or negative size (set %d)", k);
+		if (s->variable && n_points[k] > 0 && (!radii || !radii[k])) return sfail(s, TNSX_ERR_INVALID, "per-point radii must be given for every set, or for none (fixed radius)");
+	}
+	if ((size_t)n_sets > s->sets.size()) s->sets.resize((size_t)n_sets);
+	{ const tnsx_status r = ensure_small(s, (size_t)n_sets); if (r != TNSX_OK) return r; }
+	const size_t W = s->variable ? 6 : 5;
+	const bool side_on[2] = { has_side(s, 0), has_side(s, 1) };
+	s->info.rounds_last = 0;
+	s->info.redone_last = 0;
+	SHIP(s, hipMemsetAsync(s->d_small.p, 0, (size_t)n_sets * 8 * 4, s->stream));
+	bool spec = s->speculative && (side_on[0] || side_on[1]);
+	for (int k = 0; k < n_sets && spec; k++) for (int side = 0; side < 2; side++) if (side_on[side] && !s->sets[(size_t)k].caps_known[side]) spec = false;
+	s->info.speculative_last = spec ? 1 : 0;
+	auto rad = [&](int k) { return s->variable ? radii[k] : nullptr; };
+
+	if (spec) {
+		// ---- ONE round of fixed-capacity messages; nothing is read on the host before the search
+		std::vector<tnsx_slab_op> ops;
+		for (int k = 0; k < n_sets; k++) {
+			SetState& st = s->sets[(size_t)k];
+			{ const tnsx_status r = pack(s, (size_t)k, xyz[k], gids[k], rad(k), n_points[k], side_on, st.cap_s, false); if (r != TNSX_OK) return r; }
+			for (int side = 0; side < 2; side++) {
+				if (!side_on[side]) continue;
+				if (!st.recv[side].reserve(((size_t)st.cap_r[side] + 1) * W * 4)) return sfail(s, TNSX_ERR_HIP, "out of device memory (halo buffers)");
+				ops.push_back({ peer_of(s, side), st.send[side].p, ((size_t)st.cap_s[side] + 1) * W * 4, st.recv[side].p, ((size_t)st.cap_r[side] + 1) * W * 4 });
+			}
+		}
+		if (do_exchange(s, ops)) return sfail(s, TNSX_ERR_HIP, "halo exchange failed (transport)");
+		for (int k = 0; k < n_sets; k++) {
+			SetState& st = s->sets[(size_t)k];
+			const uint32_t rows[2] = { side_on[0] ? st.cap_r[0] : 0u, side_on[1] ? st.cap_r[1] : 0u };
+			{ const tnsx_status r = assemble(s, (size_t)k, xyz[k], gids[k], rad(k), n_points[k], rows, true); if (r != TNSX_OK) return r; }
+			// what validate() needs, fetched behind the search: the received header words next to the pack counts
+			for (int side = 0; side < 2; side++) if (side_on[side]) SHIP(s, hipMemcpyAsync(small_dev(s, (size_t)k) + 2 + side, st.recv[side].p, 4, hipMemcpyDeviceToDevice, s->stream));
+		}
+		SHIP(s, hipMemcpyAsync(s->h_small, s->d_small.p, (size_t)n_sets * 8 * 4, hipMemcpyDeviceToHost, s->stream));
+		{ const tnsx_status r = run_engine(s); if (r != TNSX_OK) return r; }       // (synchronises the stream)
+		SHIP(s, hipStreamSynchronize(s->stream));
+		// ---- validate: every link on its own.  Both ends of a link see the same two numbers (what travelled, what was agreed).
+		bool repair_link[2] = { false, false };
+		for (int k = 0; k < n_sets; k++) {
+			SetState& st = s->sets[(size_t)k];
+			for (int side = 0; side < 2; side++) {
+				if (!side_on[side]) continue;
+				st.n_out[side] = small_host(s, (size_t)k)[side];
+				st.n_in[side] = small_host(s, (size_t)k)[2 + side];
+				if (st.n_out[side] > st.cap_s[side] || st.n_in[side] > st.cap_r[side]) repair_link[side] = true;
+			}
+		}
+		if (repair_link[0] || repair_link[1]) {
+			// a capacity was exceeded: some ghosts are missing.  The two ends of that link move exactly the rows that did not fit
+			// (nobody else takes part), then this slab searches again.
+			s->info.redone_last = 1;
+			std::vector<tnsx_slab_op> fix;
+			for (int k = 0; k < n_sets; k++) {
+				SetState& st = s->sets[(size_t)k];
+				bool want[2] = { false, false };
+				uint32_t cap_rows[2] = { st.cap_s[0], st.cap_s[1] };
+				for (int side = 0; side < 2; side++) if (side_on[side] && repair_link[side] && st.n_out[side] > st.cap_s[side]) { want[side] = true; cap_rows[side] = st.n_out[side]; }
+				if (want[0] || want[1]) { const tnsx_status r = pack(s, (size_t)k, xyz[k], gids[k], rad(k), n_points[k], want, cap_rows, false); if (r != TNSX_OK) return r; }
+				for (int side = 0; side < 2; side++) {
+					if (!side_on[side] || !repair_link[side]) continue;
+					const bool out_over = st.n_out[side] > st.cap_s[side], in_over = st.n_in[side] > st.cap_r[side];
+					if (in_over && !st.recv[side].reserve(((size_t)st.n_in[side] + 1) * W * 4, true)) return sfail(s, TNSX_ERR_HIP, "out of device memory (halo buffers)");
+					if (out_over || in_over)
+						fix.push_back({ peer_of(s, side), out_over ? (const void*)(st.send[side].as<float>() + W) : nullptr, out_over ? (size_t)st.n_out[side] * W * 4 : 0,
+						                in_over ? (void*)(st.recv[side].as<float>() + W) : nullptr, in_over ? (size_t)st.n_in[side] * W * 4 : 0 });
+				}
+			}
+			if (do_exchange(s, fix)) return sfail(s, TNSX_ERR_HIP, "halo exchange failed (transport, repair round)");
+			SHIP(s, hipMemsetAsync(s->d_small.p, 0, (size_t)n_sets * 8 * 4, s->stream));
+			for (int k = 0; k < n_sets; k++) {
+				SetState& st = s->sets[(size_t)k];
+				const uint32_t rows[2] = { side_on[0] ? st.n_in[0] : 0u, side_on[1] ? st.n_in[1] : 0u };
+				{ const tnsx_status r = assemble(s, (size_t)k, xyz[k], gids[k], rad(k), n_points[k], rows, false); if (r != TNSX_OK) return r; }
+			}
+			SHIP(s, hipMemcpyAsync(s->h_small, s->d_small.p, (size_t)n_sets * 8 * 4, hipMemcpyDeviceToHost, s->stream));
+			{ const tnsx_status r = run_engine(s); if (r != TNSX_OK) return r; }
+			SHIP(s, hipStreamSynchronize(s->stream));
+		}
+	}
+	else {
+		// ---- exact step: the counts first, then exactly the rows
+		std::vector<tnsx_slab_op> ops;
+		for (int k = 0; k < n_sets; k++) {
+			SetState& st = s->sets[(size_t)k];
+			uint32_t cap_rows[2];
+			for (int side = 0; side < 2; side++) cap_rows[side] = std::max<uint32_t>({ st.cap_s[side], (uint32_t)(n_points[k] / 32), 1024u });
+			for (;;) {
+				{ const tnsx_status r = pack(s, (size_t)k, xyz[k], gids[k], rad(k), n_points[k], side_on, cap_rows, true); if (r != TNSX_OK) return r; }
+				bool grown = false;
+				for (int side = 0; side < 2; side++) if (side_on[side] && st.n_out[side] > cap_rows[side]) { cap_rows[side] = st.n_out[side] + st.n_out[side] / 8 + 1024; grown = true; }
+				if (!grown) break;
+			}
+			for (int side = 0; side < 2; side++) {
+				if (!side_on[side]) continue;
+				if (!st.recv[side].reserve(std::max<size_t>(((size_t)st.cap_r[side] + 1) * W * 4, W * 4))) return sfail(s, TNSX_ERR_HIP, "out of device memory (halo buffers)");
+				ops.push_back({ peer_of(s, side), st.send[side].p, 4, st.recv[side].p, 4 });
+			}
+		}
+		if (do_exchange(s, ops)) return sfail(s, TNSX_ERR_HIP, "halo exchange failed (transport, counts)");
+		for (int k = 0; k < n_sets; k++) for (int side = 0; side < 2; side++) if (side_on[side])
+			SHIP(s, hipMemcpyAsync(small_dev(s, (size_t)k) + 2 + side, s->sets[(size_t)k].recv[side].p, 4, hipMemcpyDeviceToDevice, s->stream));
+		SHIP(s, hipMemcpyAsync(s->h_small, s->d_small.p, (size_t)n_sets * 8 * 4, hipMemcpyDeviceToHost, s->stream));
+		SHIP(s, hipStreamSynchronize(s->stream));
+		ops.clear();
+		for (int k = 0; k < n_sets; k++) {
+			SetState& st = s->sets[(size_t)k];
+			for (int side = 0; side < 2; side++) {
+				if (!side_on[side]) continue;
+				st.n_in[side] = small_host(s, (size_t)k)[2 + side];
+				if (!st.recv[side].reserve(((size_t)st.n_in[side] + 1) * W * 4)) return sfail(s, TNSX_ERR_HIP, "out of device memory (halo buffers)");
+				if (st.n_out[side] || st.n_in[side])
+					ops.push_back({ peer_of(s, side), st.n_out[side] ? (const void*)(st.send[side].as<float>() + W) : nullptr, (size_t)st.n_out[side] * W * 4,
+					                st.n_in[side] ? (void*)(st.recv[side].as<float>() + W) : nullptr, (size_t)st.n_in[side] * W * 4 });
+			}
+		}
+		if (do_exchange(s, ops)) return sfail(s, TNSX_ERR_HIP, "halo exchange failed (transport, rows)");
+		for (int k = 0; k < n_sets; k++) {
+			SetState& st = s->sets[(size_t)k];
+			const uint32_t rows[2] = { side_on[0] ? st.n_in[0] : 0u, side_on[1] ? st.n_in[1] : 0u };
+			{ const tnsx_status r = assemble(s, (size_t)k, xyz[k], gids[k], rad(k), n_points[k], rows, false); if (r != TNSX_OK) return r; }
+		}
+		SHIP(s, hipMemcpyAsync(s->h_small, s->d_small.p, (size_t)n_sets * 8 * 4, hipMemcpyDeviceToHost, s->stream));
+		{ const tnsx_status r = run_engine(s); if (r != TNSX_OK) return r; }
+		SHIP(s, hipStreamSynchronize(s->stream));
+	}
+	// ---- capacities for the next step: grow only, the same rule on the same numbers at both ends of a link
+	for (int k = 0; k < n_sets; k++) {
+		SetState& st = s->sets[(size_t)k];
+		for (int side = 0; side < 2; side++) {
+			if (!side_on[side]) continue;
+			if (st.n_out[side] > st.cap_s[side] || !st.caps_known[side]) st.cap_s[side] = std::max(st.cap_s[side], capacity_rule(st.n_out[side]));
+			if (st.n_in[side] > st.cap_r[side] || !st.caps_known[side]) st.cap_r[side] = std::max(st.cap_r[side], capacity_rule(st.n_in[side]));
+			st.caps_known[side] = true;
+		}
+		if (small_host(s, (size_t)k)[4]) return sfail(s, TNSX_ERR_INVALID, "a search radius exceeds max_radius = %g: the halo is too thin for exact results", (double)s->max_radius);
+		if (small_host(s, (size_t)k)[5]) return sfail(s, TNSX_ERR_LIST_TOO_LONG, "a global id does not fit the 32-bit neighbour indices of the reference's list layout");
+	}
+	s->info.n_owned = s->sets[0].n_owned; s->info.n_ghost = s->sets[0].n_ghost;
+	return TNSX_OK;
+}
+
+tnsx_status tnsx_slab_debug_set_capacity(tnsx_slab* s, int side, unsigned rows)
+{
+	// tests: pretend the halos were thinner when the capacities were agreed (both ends of the link must be given the same number)
+	if (!s || side < 0 || side > 1) return TNSX_ERR_INVALID;
+	for (SetState& st : s->sets) if (st.caps_known[side]) { st.cap_s[side] = rows; st.cap_r[side] = rows; }
+	return TNSX_OK;
+}
+
+}  // extern "C"

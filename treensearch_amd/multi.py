@@ -586,3 +586,174 @@ class SlabSearch:
         lid = np.repeat(np.arange(n), np.diff(offs))
         order = np.lexsort((out, lid))
         return offs, out[order]
+
+
+# ======================================================================================================================
+# The slab layer BEHIND THE C ABI (include/tnsx.h "slab layer", treensearch_amd/csrc/tnsx_slab.cpp): the same step -- pack, one
+# exchange, ghosts appended as candidates-only points with global ids, search, capacities checked afterwards -- done by
+# libtnsx.so itself with RCCL (ncclSend / ncclRecv in one group per step); this class only hands over pointers.  A C++ consumer
+# (SPlisHSPlasH + MPI) calls the same entry points.
+# ======================================================================================================================
+class SlabTransportC:
+    """A tnsx_slab_transport.  rccl(): one communicator per rank, the 128-byte unique id travels over torch.distributed (any
+    backend) or is given; local(group, rank): all slabs in one process (tests on one GPU)."""
+
+    def __init__(self):
+        from . import api as A
+        self._A = A
+        self._L = A.load_library()
+        self.t = A.SlabTransport()
+        self.kind = None
+
+    @classmethod
+    def rccl(cls, rank: int, world: int, device: int = -1, unique_id: Optional[bytes] = None, group=None):
+        import ctypes as C
+        self = cls()
+        if unique_id is None:
+            buf = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                raw = (C.c_ubyte * 128)()
+                if self._L.tnsx_slab_rccl_unique_id(raw) != 0:
+                    raise RuntimeError("tnsx_slab_rccl_unique_id failed: " + (self._L.tnsx_slab_rccl_error() or b"").decode())
+                buf = torch.tensor(list(raw), dtype=torch.uint8)
+            if world > 1:
+                dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+                buf = buf.to(dev)
+                dist.broadcast(buf, src=0, group=group)
+                buf = buf.cpu()
+            unique_id = bytes(buf.tolist())
+        raw = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        st = self._L.tnsx_slab_transport_rccl(raw, int(rank), int(world), int(device), C.byref(self.t))
+        if st != 0:
+            raise RuntimeError("tnsx_slab_transport_rccl failed: " + (self._L.tnsx_slab_rccl_error() or b"").decode())
+        self.kind = "rccl"
+        return self
+
+    @classmethod
+    def local(cls, group_handle, rank: int):
+        import ctypes as C
+        self = cls()
+        if self._L.tnsx_slab_transport_local(group_handle, int(rank), C.byref(self.t)) != 0:
+            raise RuntimeError("tnsx_slab_transport_local failed")
+        self.kind = "local"
+        return self
+
+    @staticmethod
+    def local_group(world: int):
+        import ctypes as C
+        from . import api as A
+        h = C.c_void_p()
+        if A.load_library().tnsx_slab_local_group_create(int(world), C.byref(h)) != 0:
+            raise RuntimeError("tnsx_slab_local_group_create failed")
+        return h
+
+    @staticmethod
+    def local_group_release(h) -> None:
+        from . import api as A
+        A.load_library().tnsx_slab_local_group_release(h)
+
+    def release(self) -> None:
+        import ctypes as C
+        if self.kind is not None:
+            self._L.tnsx_slab_transport_release(C.byref(self.t))
+            self.kind = None
+
+
+def balanced_cuts_c(engine, transport: Optional[SlabTransportC], rank: int, world: int, point_sets: Sequence[torch.Tensor], plane_width: float,
+                    n_slabs: Optional[int] = None) -> np.ndarray:
+    """tnsx_slab_balanced_cuts: collective over the transport; -> float32[n_slabs + 1] with -inf / +inf at the ends."""
+    import ctypes as C
+    L = engine._L
+    n = len(point_sets)
+    ns = int(n_slabs) if n_slabs else int(world)
+    ptrs = (C.c_void_p * n)(*[p.data_ptr() if p.shape[0] else None for p in point_sets])
+    cnts = (C.c_int * n)(*[int(p.shape[0]) for p in point_sets])
+    out = (C.c_float * (ns + 1))()
+    engine._wait_for_producers_of(point_sets)
+    st = L.tnsx_slab_balanced_cuts(engine._h, C.byref(transport.t) if transport is not None else None, int(rank), int(world), n, ptrs, cnts,
+                                   C.c_float(float(plane_width)), ns, out)
+    if st != 0:
+        raise ValueError(f"tnsx_slab_balanced_cuts failed with status {st} (5: more than 32768 x planes, or fewer planes than slabs)")
+    return np.array(list(out), np.float32)
+
+
+class SlabSearchC:
+    """SlabSearch on the C entry points (tnsx_slab_create / tnsx_slab_step).  Same calling convention as SlabSearch:
+    step(pts, gids[, radii]) or step((pts, gids[, radii]), ...); the lists are read from `engine` with the set ids of `set_id(k)`."""
+
+    def __init__(self, slab_lo: float, slab_hi: float, radius: Optional[float], engine, transport: Optional[SlabTransportC], rank: int, world: int,
+                 halo_margin: float = 1.0e-3, max_radius: Optional[float] = None, speculative: bool = True):
+        import ctypes as C
+        self.engine = engine
+        self._L = engine._L
+        self.transport = transport
+        self.rank, self.world = int(rank), int(world)
+        self.variable = radius is None
+        if self.variable and max_radius is None:
+            raise ValueError("per-point radii: max_radius (an upper bound of every search radius) is needed to size the halo")
+        h = C.c_void_p()
+        st = self._L.tnsx_slab_create(engine._h, C.byref(transport.t) if transport is not None else None, self.rank, self.world, C.c_float(float(slab_lo)),
+                                      C.c_float(float(slab_hi)), C.c_float(-1.0 if self.variable else float(radius)),
+                                      C.c_float(float(max_radius) if self.variable else float(radius)), C.c_float(float(halo_margin)), int(bool(speculative)), C.byref(h))
+        if st != 0:
+            raise RuntimeError(f"tnsx_slab_create failed with status {st}")
+        self._h = h
+        self._keep = None
+        self.n_sets = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.tnsx_slab_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def set_symmetric_search(self, active: bool) -> None:
+        self.engine.set_symmetric_search(active)
+
+    def set_active_search(self, i: int, j: int, active: bool = True) -> None:
+        self._check(self._L.tnsx_slab_set_active_search(self._h, int(i), int(j), int(bool(active))))
+
+    def _check(self, st):
+        if st != 0:
+            raise RuntimeError(f"slab layer error {st}: " + (self._L.tnsx_slab_last_error(self._h) or b"").decode())
+
+    def step(self, *sets):
+        import ctypes as C
+        if sets and torch.is_tensor(sets[0]):
+            sets = (tuple(sets),)
+        sets = [tuple(s) + (None,) * (3 - len(s)) for s in sets]
+        n = len(sets)
+        for (p, g, r) in sets:
+            assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.dtype == torch.int64 and g.is_contiguous()
+            assert (r is not None) == self.variable, "per-point radii must be given for every set, or for none (fixed radius)"
+        xyz = (C.c_void_p * n)(*[p.data_ptr() if p.shape[0] else None for (p, g, r) in sets])
+        gid = (C.c_void_p * n)(*[g.data_ptr() if g.shape[0] else None for (p, g, r) in sets])
+        rad = (C.c_void_p * n)(*[(r.data_ptr() if (r is not None and r.shape[0]) else None) for (p, g, r) in sets])
+        cnt = (C.c_int * n)(*[int(p.shape[0]) for (p, g, r) in sets])
+        self._keep = sets
+        self.n_sets = n
+        self.engine._views = {}
+        self.engine._wait_for_producers_of([t for s in sets for t in s if t is not None])
+        self._check(self._L.tnsx_slab_step(self._h, n, xyz, gid, rad if self.variable else None, cnt))
+
+    def set_id(self, k: int = 0) -> int:
+        return int(self._L.tnsx_slab_engine_set(self._h, int(k)))
+
+    def info(self):
+        import ctypes as C
+        from . import api as A
+        inf = A.SlabInfo()
+        self._check(self._L.tnsx_slab_get_info(self._h, C.byref(inf)))
+        return inf
+
+    @property
+    def n_owned(self) -> int:
+        return int(self.info().n_owned)
+
+    def neighbors_device(self, i: int = 0, j: int = 0):
+        return self.engine.pair_view(self.set_id(i), self.set_id(j))
+
+    def debug_set_capacity(self, side: int, rows: int) -> None:
+        self._check(self._L.tnsx_slab_debug_set_capacity(self._h, int(side), int(rows)))
