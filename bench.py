@@ -175,6 +175,38 @@ def secondary_ceilings(insts, launch_ms, n_queries):
     return out
 
 
+def dropin_mode(n, seed, arith_const):
+    """What a CPU consumer of the C++ shim sees: host arrays in, neighbour lists mirrored into pinned host
+    memory, every run.  PCIe-inclusive, so it is reported beside the headline number and is never `value`."""
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    try:
+        pts = D.uniform_cloud(n, seed)
+        ns = T.TreeNSearch(arith=arith_const, mirror_to_host=True, collect_stage_times=True)
+        ns.set_search_radius(D.radius_for_neighbors(n))
+        ns.add_point_set(pts)
+        ns.set_active_search(0, 0, True)
+        for _ in range(2):
+            ns.run()
+        t0 = time.perf_counter()
+        steps = 3
+        for k in range(steps):
+            pts[k::97, 1] += np.float32(1e-6)
+            ns.run()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        st = ns.get_stats()
+        v = ns.pair_view(0, 0)
+        out = {"ms_per_run": round(ms, 2), "value": round(n / ms / 1e3, 1), "unit": "Mpoints/s", "upload_ms": round(st["ms_upload"], 2),
+               "device_ms": round(st["ms_total"] - st["ms_upload"] - st["ms_mirror"], 2), "mirror_ms": round(st["ms_mirror"], 2),
+               "mirror_gb": round(v.n_records * 4 / 1e9, 2), "mirror_gbs": round(v.n_records * 4 / 1e6 / max(st["ms_mirror"], 1e-9), 1),
+               "note": "host pointers in, lists in pinned host memory out (the reference's calling convention through include/TreeNSearch): bound by "
+                       "ONE PCIe link moving the records; never `value`"}
+        del ns
+        return out
+    except Exception as e:  # pragma: no cover
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def secondary_workload(name, points, arith):
     """Another BASELINE config as a reduced bench run of its own (a fresh process: 10 timed steps, its own two PMC passes, no CPU
     leg) -> the fields the judge compares with profiles/."""
@@ -532,6 +564,7 @@ def main():
             # the other single-GPU configs of BASELINE.json next to the headline one (c4 at a fifth of its size: its 50 M-point
             # instance takes minutes to generate; `bench.py --workload c4` runs it in full)
             out["secondary"] = {"c3": secondary_workload("c3", 10_000_000, args.arith), "c4_10M": secondary_workload("c4", 10_000_000, args.arith)}
+            out["dropin_mode"] = dropin_mode(10_000_000, args.seed, arith)
         out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(workload, args.seed)
         print(json.dumps(out), flush=True)
 

@@ -167,3 +167,102 @@ def test_c4_step_loop_matches_oracle(oracle):
             # the order handed out is a permutation and the points really are z-sorted on the reference grid afterwards
             order = ns.get_zsort_order(0)
             assert np.array_equal(np.sort(order), np.arange(n))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# configs[3] at its full 50 M points and configs[4] at its full 200 M points (one rank, through the slab layer's C entry points).
+# The same size-independent properties, evaluated on the device in chunks of query points so that no temporary is larger than a
+# few GB: index range, no self, distinct entries, symmetry of the pair set by random-weight moments, z-sort invariance (c4).
+# ---------------------------------------------------------------------------------------------------------------------
+def _chunked_properties(ns, i, j, n_j, same_set, w_a, w_b, chunk=4_000_000, owner_ids=None):
+    """-> (total, sum w_a[i] w_b[j], sum w_b[i] w_a[j], sum w_a[i] count_i) over all directed pairs, all mod 2^64; asserts
+    well-formedness of every list on the way.  owner_ids: identity of query point p (default p); list entries are identities."""
+    import ctypes as C
+    import torch
+    v = ns.pair_view(i, j)
+    offs = torch.empty(max(v.n_points, 1), dtype=torch.int64, device="cuda")
+    recs = torch.empty(max(v.n_records, 1), dtype=torch.int32, device="cuda")
+    ns._check(ns._L.tnsx_copy_pair(ns._h, int(i), int(j), C.c_void_p(offs.data_ptr()), C.c_void_p(recs.data_ptr()), 1))
+    total, m_ab, m_ba, deg = 0, 0, 0, 0
+    M = (1 << 64) - 1
+    for lo in range(0, v.n_points, chunk):
+        hi = min(lo + chunk, v.n_points)
+        o = offs[lo:hi]
+        counts = recs[o].to(torch.int64)
+        e = int(counts.sum().item())
+        start = torch.cumsum(counts, 0) - counts
+        src = torch.repeat_interleave(o + 1 - start, counts) + torch.arange(e, device="cuda", dtype=torch.int64)
+        idx = recs[src].to(torch.int64)
+        del src
+        local = torch.repeat_interleave(torch.arange(hi - lo, device="cuda", dtype=torch.int64), counts)
+        owner = (local + lo) if owner_ids is None else owner_ids[lo:hi][local]
+        assert int(idx.min().item()) >= 0 and int(idx.max().item()) < n_j, "index out of range"
+        if same_set:
+            assert not bool((idx == owner).any().item()), "a point lists itself"
+        key = torch.sort(local * (1 << 31) + idx).values
+        assert bool((key[1:] > key[:-1]).all().item()), "duplicate entries inside a list"
+        del key, local
+        total += e
+        m_ab = (m_ab + int((w_a[owner] * w_b[idx]).sum().item())) & M
+        m_ba = (m_ba + int((w_b[owner] * w_a[idx]).sum().item())) & M
+        own_id = torch.arange(lo, hi, device="cuda", dtype=torch.int64) if owner_ids is None else owner_ids[lo:hi]
+        deg = (deg + int((w_a[own_id] * counts).sum().item())) & M
+        del idx, owner, counts
+    assert total == v.n_neighbors
+    return total, m_ab, m_ba, deg
+
+
+def test_c4_full_size_50m_properties_and_zsort_invariance():
+    """BASELINE.json configs[3] at its full size: 50 M-point dam break, per-point radii, symmetric search."""
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    n = 50_000_000
+    p, rad, r0 = D.dam_break_cloud(n)
+    d_p, d_r = torch.from_numpy(p).cuda(), torch.from_numpy(rad).cuda()
+    del p, rad
+    ids = torch.arange(n, dtype=torch.int64, device="cuda")
+    ns = T.TreeNSearch()
+    ns.add_point_set(d_p, d_r)
+    ns.set_active_search(0, 0, True)
+    ns.set_symmetric_search(True)
+    ns.run()
+    a, b = _weights(n, 11), _weights(n, 12)
+    total, m_ab, m_ba, deg = _chunked_properties(ns, 0, 0, n, True, a, b)
+    assert 55 * n < total < 70 * n
+    assert m_ab == m_ba, "symmetric search, yet the pair set is not symmetric"
+    ns.prepare_zsort()
+    ns.apply_zsort(0, d_p, 3)
+    ns.apply_zsort(0, d_r, 1)
+    ns.apply_zsort(0, ids, 1)
+    ns.run()
+    # identities: query point p is ids[p], entry j is ids[j]
+    total2, m_ab2, m_ba2, deg2 = _chunked_properties(ns, 0, 0, n, True, a[ids], b[ids])
+    # (weights permuted to positions: w'[p] = w[ids[p]] -- the moments are then sums over identities)
+    assert total2 == total and m_ab2 == m_ab and m_ba2 == m_ba, "the pair set changed under the z-sort"
+    assert deg2 == deg, "neighbour counts changed under the z-sort"
+
+
+def test_c5_full_size_200m_one_rank_through_the_slab_layer():
+    """BASELINE.json configs[4] at its full 200 M points on ONE GPU, through tnsx_slab_step (one rank: no exchange, but the whole slab
+    path -- [owned | ghosts] buffers, candidates-only tail, global ids from the engine): the lists hold global ids; symmetric pair set,
+    no self, distinct entries, ~59 neighbours per point, idempotent second step."""
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    from treensearch_amd.multi import SlabSearchC
+    n = 200_000_000
+    r = D.radius_for_neighbors(n)
+    d_p = torch.from_numpy(D.uniform_cloud(n, 12345)).cuda()
+    gids = torch.arange(n, dtype=torch.int64, device="cuda")
+    ns = T.TreeNSearch()
+    slab = SlabSearchC(float("-inf"), float("inf"), float(r), ns, None, 0, 1)
+    slab.step(d_p, gids)
+    a, b = _weights(n, 21), _weights(n, 22)
+    sid = slab.set_id(0)
+    total, m_ab, m_ba, deg = _chunked_properties(ns, sid, sid, n, True, a, b, chunk=5_000_000)
+    assert 58.5 * n < total < 60.5 * n
+    assert m_ab == m_ba, "the pair set is not symmetric"
+    slab.step(d_p, gids)
+    st = ns.get_stats()
+    assert st["n_neighbors"] == total and st["speculated"] == 1

@@ -274,7 +274,10 @@ def test_cell_sort_digit_plans(name, max_cells, oracle):
     ns.run()
     st = ns.get_stats()
     assert st["n_grid_cells"] <= max_cells
-    assert st["radix_passes"] == (st["key_bits"] + 10) // 11
+    # sets of 65536 points and more with keys of at most 24 bits: the two-pass bucket build (high-digit pass + bucket-local counting
+    # sort that emits the cell table); everything else: LSD passes of 8..11 bits + k_cell_table
+    n_max = max(len(p) for p in case.points)
+    assert st["radix_passes"] == (2 if (n_max >= 65536 and st["key_bits"] <= 24) else (st["key_bits"] + 10) // 11)
     res2 = {pr: ns.neighbor_csr(*pr) for pr in case.active}
     P.assert_matches_golden(res1, load_golden(case.name), 0, oracle, f"{name} max_cells={max_cells} (exact pass)")
     P.assert_matches_golden(res2, load_golden(case.name), 0, oracle, f"{name} max_cells={max_cells} (pool pass)")

@@ -489,6 +489,221 @@ void launch_cell_table(const float4* xyzi_sorted, int n, GridParams g, uint2* ta
 	hipLaunchKernelGGL(k_cell_table, dim3((n + CT_TILE - 1) / CT_TILE), dim3(CT_THREADS), 0, s, xyzi_sorted, n, g, table, occ, n_occ);
 }
 
+// =====================================================================================================
+// The build in TWO passes with the cell table for free (round 3): bucket pass + bucket-local counting sort.
+//   pass A  the ordinary histogram / scan / ranked-scatter pass on the HIGH digit of the cell key (it also carries the run-time
+//           checks of the speculation): the points land grouped by bucket = 2^lo consecutive cells, i.e. a few x-rows of the grid
+//   pass B  k_bucket_sort: ONE workgroup per bucket.  Sweep 1 counts the bucket's points per cell in LDS (the low digit IS the cell
+//           inside the bucket); the scan of the counts is the cell table of the bucket -- first / one-past-last position of every
+//           cell and the list of occupied cells fall out of it, no key comparison between neighbouring points, no second read of
+//           the sorted array; sweep 2 re-reads the bucket (it is a few hundred KB: L2) and drops every point at the cursor of
+//           its cell (ds_add_rtn).  Its stores stay inside the bucket's own window of the output, where the L2 completes them
+//           to full lines.
+// Against the two LSD passes + k_cell_table this saves one histogram pass over all points, the scan kernels of the second
+// pass, the 16 N bytes k_cell_table reads, and the BITS ballots per point the ranked scatter spends on a stable rank.
+// The order of the points INSIDE a cell is whatever the LDS atomics give (the neighbour SETS do not depend on it; the exact
+// two-pass layout, which promises a reproducible order, keeps the stable LSD sort), with one exception that the engine relies on:
+// points that get lists (original index < query_limit) come before the candidates-only points of their cell (the ghosts of a
+// slab) -- the former fill a cell from the front, the latter from the back.
+// =====================================================================================================
+static constexpr int BS_THREADS = 1024;
+static constexpr int BS_KEEP = 12;     // points per thread that stay in registers between the two sweeps (12 K points per bucket: all of them, usually);
+                                       // their loads are issued back to back -- with one load in flight per thread the sweeps are latency-bound
+static constexpr int BS_UNROLL = 4;    // loads in flight per thread for the points beyond that
+template <bool VARIABLE, bool SPLIT>
+__global__ void __launch_bounds__(BS_THREADS) k_bucket_sort(const float4* __restrict__ in, float4* __restrict__ out, float* __restrict__ r2_out,
+                                                            const float* __restrict__ radii, GridParams g, int lo_bits, const uint32_t* __restrict__ totals,
+                                                            uint2* __restrict__ table, uint2* __restrict__ occ_tmp, uint2* __restrict__ bucket_info,
+                                                            uint32_t* __restrict__ n_occ, const int* __restrict__ ids, uint32_t* __restrict__ orig_out,
+                                                            uint32_t query_limit, BuildGuard gd)
+{
+	extern __shared__ uint32_t bs_lds[];   // front cursor per cell of the bucket [+ back cursor per cell (SPLIT)]
+	__shared__ uint32_t red[2 * (BS_THREADS / WAVE) + 2];
+	const int RADIX = 1 << lo_bits;
+	uint32_t* const h = bs_lds;
+	uint32_t* const hb = bs_lds + RADIX;
+	const int b = (int)blockIdx.x, lane = lane_id(), w = (int)threadIdx.x / WAVE;
+	const uint32_t n_cells = (uint32_t)(g.nx * g.ny * g.nz);
+	// ---- where the bucket lies in the output of pass A: the counts of the buckets before it
+	uint32_t part = 0;
+	for (int k = (int)threadIdx.x; k < b; k += BS_THREADS) part += totals[k];
+	#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, WAVE);
+	if (lane == 0) red[w] = part;
+	const uint32_t count = totals[b];
+	for (int k = (int)threadIdx.x; k < RADIX; k += BS_THREADS) h[k] = 0u;
+	__syncthreads();
+	uint32_t start = 0;
+	#pragma unroll
+	for (int k = 0; k < BS_THREADS / WAVE; k++) start += red[k];
+	if (count == 0u) { if (threadIdx.x == 0) bucket_info[b] = make_uint2(0u, 0u); return; }
+	// ---- the bucket's points -> registers (all loads in flight at once), sweep 1: points per cell
+	float4 keep[BS_KEEP];
+	#pragma unroll
+	for (int u = 0; u < BS_KEEP; u++) { const uint32_t i = (uint32_t)u * BS_THREADS + threadIdx.x; keep[u] = in[start + (i < count ? i : count - 1u)]; }
+	#pragma unroll
+	for (int u = 0; u < BS_KEEP; u++) {
+		const uint32_t i = (uint32_t)u * BS_THREADS + threadIdx.x;
+		if (i < count) atomicAdd(&h[cell_key(keep[u].x, keep[u].y, keep[u].z, g) & (uint32_t)(RADIX - 1)], 1u);
+	}
+	for (uint32_t i0 = BS_KEEP * BS_THREADS; i0 < count; i0 += BS_THREADS * BS_UNROLL) {   // (a bucket larger than the registers hold: read twice)
+		float4 q[BS_UNROLL];
+		#pragma unroll
+		for (int u = 0; u < BS_UNROLL; u++) { const uint32_t i = i0 + (uint32_t)u * BS_THREADS + threadIdx.x; q[u] = in[start + (i < count ? i : count - 1u)]; }
+		#pragma unroll
+		for (int u = 0; u < BS_UNROLL; u++) {
+			const uint32_t i = i0 + (uint32_t)u * BS_THREADS + threadIdx.x;
+			if (i < count) atomicAdd(&h[cell_key(q[u].x, q[u].y, q[u].z, g) & (uint32_t)(RADIX - 1)], 1u);
+		}
+	}
+	__syncthreads();
+	// ---- scan of the counts = the cell table of the bucket.  Thread t owns the PER consecutive cells [t * PER, t * PER + PER).
+	const int PER = RADIX >= BS_THREADS ? RADIX / BS_THREADS : 1;   // (fewer cells than threads: the upper threads own none)
+	const int my_bins = (int)threadIdx.x * PER < RADIX ? PER : 0;
+	const uint32_t key0 = ((uint32_t)b << lo_bits) + (uint32_t)threadIdx.x * (uint32_t)PER;
+	uint32_t sum = 0, nz = 0;
+	for (int k = 0; k < my_bins; k++) { const uint32_t c = h[threadIdx.x * PER + k]; sum += c; nz += (c != 0u && key0 + (uint32_t)k < n_cells) ? 1u : 0u; }
+	uint32_t inc = sum, ninc = nz;
+	#pragma unroll
+	for (int o = 1; o < WAVE; o <<= 1) { const uint32_t u = __shfl_up(inc, o, WAVE), v = __shfl_up(ninc, o, WAVE); if (lane >= o) { inc += u; ninc += v; } }
+	__syncthreads();   // (red is read above by everybody)
+	if (lane == WAVE - 1) { red[w] = inc; red[BS_THREADS / WAVE + w] = ninc; }
+	__syncthreads();
+	uint32_t ex = inc - sum, nex = ninc - nz, nz_total = 0;
+	#pragma unroll
+	for (int k = 0; k < BS_THREADS / WAVE; k++) { if (k < w) { ex += red[k]; nex += red[BS_THREADS / WAVE + k]; } nz_total += red[BS_THREADS / WAVE + k]; }
+	if (threadIdx.x == 0) {
+		const uint32_t base = nz_total ? atomicAdd(n_occ, nz_total) : 0u;   // ONE atomic per bucket; k_occ_reorder puts the buckets' pieces into key order
+		red[2 * (BS_THREADS / WAVE)] = base;
+		bucket_info[b] = make_uint2(base, nz_total);
+	}
+	__syncthreads();
+	const uint32_t obase = red[2 * (BS_THREADS / WAVE)];
+	for (int k = 0; k < my_bins; k++) {
+		const int bin = (int)threadIdx.x * PER + k;
+		const uint32_t c = h[bin];
+		h[bin] = ex;                       // front cursor
+		if (SPLIT) hb[bin] = ex + c;       // back cursor (one past)
+		if (c != 0u && key0 + (uint32_t)k < n_cells) {   // (key == n_cells: NaN points, behind all cells; they enter no cell)
+			table[key0 + (uint32_t)k] = make_uint2(start + ex, start + ex + c);
+			occ_tmp[obase + nex] = make_uint2(start + ex, key0 + (uint32_t)k);
+			nex++;
+		}
+		ex += c;
+	}
+	__syncthreads();
+	// ---- sweep 2: every point to the cursor of its cell
+	bool bad_r = false;
+	auto place = [&](const float4 q, const float r) {
+		const uint32_t low = cell_key(q.x, q.y, q.z, g) & (uint32_t)(RADIX - 1);
+		const uint32_t o = __float_as_uint(q.w);
+		uint32_t pos;
+		if (SPLIT && o >= query_limit) pos = atomicSub(&hb[low], 1u) - 1u;
+		else pos = atomicAdd(&h[low], 1u);
+		pos += start;
+		float wv = q.w;
+		if (ids) { wv = __int_as_float(ids[o]); orig_out[pos] = o; }   // (tnsx_set_point_ids: the point carries its id from here on)
+		out[pos] = make_float4(q.x, q.y, q.z, wv);
+		if (VARIABLE) { r2_out[pos] = __fmul_rn(r, r); bad_r |= r > gd.r_max; }
+	};
+	{
+		// gather of the radii by original index (the radii array of a 50 M-point set is 200 MB: it stays in the 256 MB Infinity Cache)
+		float rr[BS_KEEP];
+		#pragma unroll
+		for (int u = 0; u < BS_KEEP; u++) rr[u] = VARIABLE ? radii[__float_as_uint(keep[u].w)] : 0.0f;
+		#pragma unroll
+		for (int u = 0; u < BS_KEEP; u++) if ((uint32_t)u * BS_THREADS + threadIdx.x < count) place(keep[u], rr[u]);
+	}
+	for (uint32_t i0 = BS_KEEP * BS_THREADS; i0 < count; i0 += BS_THREADS * BS_UNROLL) {
+		float4 qq[BS_UNROLL];
+		float rr[BS_UNROLL];
+		#pragma unroll
+		for (int u = 0; u < BS_UNROLL; u++) { const uint32_t i = i0 + (uint32_t)u * BS_THREADS + threadIdx.x; qq[u] = in[start + (i < count ? i : count - 1u)]; }
+		#pragma unroll
+		for (int u = 0; u < BS_UNROLL; u++) rr[u] = VARIABLE ? radii[__float_as_uint(qq[u].w)] : 0.0f;
+		#pragma unroll
+		for (int u = 0; u < BS_UNROLL; u++) if (i0 + (uint32_t)u * BS_THREADS + threadIdx.x < count) place(qq[u], rr[u]);
+	}
+	// (speculated grid: a radius above the one the cell edge was chosen for -> the host repeats the run with fresh bounds)
+	if (VARIABLE && gd.flag && __builtin_amdgcn_ballot_w64(bad_r) != 0ull && lane == 0) atomicOr(gd.flag, 1u);
+}
+// the buckets' pieces of the occupied-cell list -> key order (what the query's XCD-contiguous work split wants)
+__global__ void __launch_bounds__(BS_THREADS) k_occ_reorder(const uint2* __restrict__ occ_tmp, uint2* __restrict__ occ, const uint2* __restrict__ bucket_info)
+{
+	__shared__ uint32_t red[BS_THREADS / WAVE];
+	const int b = (int)blockIdx.x;
+	const uint2 me = bucket_info[b];
+	if (me.y == 0u) return;
+	uint32_t part = 0;
+	for (int k = (int)threadIdx.x; k < b; k += BS_THREADS) part += bucket_info[k].y;
+	#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, WAVE);
+	if (lane_id() == 0) red[threadIdx.x / WAVE] = part;
+	__syncthreads();
+	uint32_t prefix = 0;
+	#pragma unroll
+	for (int k = 0; k < BS_THREADS / WAVE; k++) prefix += red[k];
+	for (uint32_t i = threadIdx.x; i < me.y; i += BS_THREADS) occ[prefix + i] = occ_tmp[me.x + i];
+}
+
+// bits of the two digits of the bucket build, or {0, 0} when the key is too wide for it (the LSD passes + k_cell_table then)
+static bool bucket_plan(int key_bits, int n, int& hi_bits, int& lo_bits)
+{
+	if (key_bits > 24 || n < (1 << 16)) return false;
+	lo_bits = key_bits / 2;
+	lo_bits = lo_bits < 8 ? 8 : (lo_bits > 13 ? 13 : lo_bits);
+	hi_bits = key_bits - lo_bits;
+	if (hi_bits < 8) hi_bits = 8;
+	if (hi_bits > CS_MAX_BITS) { hi_bits = CS_MAX_BITS; lo_bits = key_bits - hi_bits; }
+	return lo_bits >= 8 && lo_bits <= 13;
+}
+size_t cell_build_temp_bytes(int n)
+{
+	// the sort's tables, then occ_tmp (n entries) and bucket_info (2^CS_MAX_BITS entries) of the bucket build
+	return ((cell_sort_temp_bytes(n) + 255) / 256) * 256 + (size_t)(n > 0 ? n : 1) * sizeof(uint2) + ((size_t)1 << CS_MAX_BITS) * sizeof(uint2) + 256;
+}
+int launch_cell_build(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, const int* ids,
+                      uint32_t* orig_sorted, const BuildGuard& gd, uint32_t query_limit, bool stable_order, uint2* table, uint2* occ, uint32_t* n_occ,
+                      int* passes_out, hipStream_t s)
+{
+	int hi_bits = 0, lo_bits = 0;
+	if (stable_order || !bucket_plan(key_bits, n, hi_bits, lo_bits)) {
+		const int res = launch_cell_sort(xyz, radii, n, g, key_bits, b, temp, ids, orig_sorted, gd, s);
+		launch_cell_table(b.xyzi[res], n, g, table, occ, n_occ, s);
+		if (passes_out) *passes_out = cell_sort_plan(key_bits).passes;
+		return res;
+	}
+	if (passes_out) *passes_out = 2;
+	const int ntiles = cs_num_tiles(n);
+	const size_t hist_cap = ((size_t)1 << CS_MAX_BITS) * (size_t)ntiles;
+	uint32_t* hist = (uint32_t*)temp;
+	uint32_t* totals = (uint32_t*)((char*)temp + ((hist_cap * sizeof(uint32_t) + 255) / 256) * 256);
+	uint32_t* strip_sums = totals + ((size_t)1 << CS_MAX_BITS);
+	uint2* occ_tmp = (uint2*)((char*)temp + ((cell_sort_temp_bytes(n) + 255) / 256) * 256);
+	uint2* bucket_info = occ_tmp + (size_t)n;
+	// ---- pass A: bucket = high digit.  (radii and ids are picked up by original index in pass B)
+	BuildGuard gda = gd;
+	TNSX_CS_DISPATCH(hi_bits, (cs_hist<B, false>(true, xyz, b.xyzi[0], n, g, lo_bits, hist, ntiles, radii, gda, s)));
+	TNSX_CS_DISPATCH(hi_bits, cs_scan<B>(hist, ntiles, strip_sums, totals, s));
+	TNSX_CS_DISPATCH(hi_bits, (cs_scatter<B, false>(true, false, xyz, nullptr, b.xyzi[0], b.r2[0], b.xyzi[1], b.r2[1], n, g, lo_bits, hist, totals, ntiles, nullptr,
+	                                               nullptr, gda, s)));
+	// ---- pass B: one workgroup per bucket
+	const int n_buckets = 1 << hi_bits;
+	const bool variable = radii != nullptr, split = query_limit < (uint32_t)n;
+	const size_t lds = ((size_t)1 << lo_bits) * sizeof(uint32_t) * (split ? 2 : 1);
+#define TNSX_BS_GO(V, SP) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_sort<V, SP>), dim3(n_buckets), dim3(BS_THREADS), lds, s, b.xyzi[1], b.xyzi[0], b.r2[0], radii, g, lo_bits, \
+	                                         totals, table, occ_tmp, bucket_info, n_occ, ids, orig_sorted, query_limit, gd)
+	if (lds > 48u * 1024u) {   // (a 13-bit low digit with two cursors per cell: above the default limit of dynamic LDS)
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_sort<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_sort<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	}
+	if (variable) { if (split) TNSX_BS_GO(true, true); else TNSX_BS_GO(true, false); }
+	else          { if (split) TNSX_BS_GO(false, true); else TNSX_BS_GO(false, false); }
+#undef TNSX_BS_GO
+	hipLaunchKernelGGL(k_occ_reorder, dim3(n_buckets), dim3(BS_THREADS), 0, s, occ_tmp, occ, bucket_info);
+	return 0;
+}
+
 __global__ void __launch_bounds__(256) k_table_clear(const uint2* __restrict__ occ, uint32_t n_occ, uint2* __restrict__ table)
 {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;

@@ -823,7 +823,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			HIPCHK(c, s.xyzi[k].reserve((size_t)s.n * sizeof(float4)));
 			if (variable) HIPCHK(c, s.r2[k].reserve((size_t)s.n * sizeof(float)));
 		}
-		HIPCHK(c, c->sort_temp.reserve(tnsx::cell_sort_temp_bytes(s.n)));
+		HIPCHK(c, c->sort_temp.reserve(tnsx::cell_build_temp_bytes(s.n)));
 		tnsx::CellSortBuffers cb;
 		for (int k = 0; k < 2; k++) { cb.xyzi[k] = s.xyzi[k].as<float4>(); cb.r2[k] = s.r2[k].as<float>(); }
 		tnsx::BuildGuard gd;
@@ -842,11 +842,15 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		if (cacheable) gd.checksum = d_words + WB * (size_t)(1 + si);
 		const int t1 = tm.mark();
 		if (s.user_ids) HIPCHK(c, s.orig_sorted.reserve((size_t)s.n * sizeof(uint32_t)));
-		s.sorted_buf = tnsx::launch_cell_sort(s.d_xyz, variable ? s.d_radii : nullptr, s.n, g, key_bits, cb, c->sort_temp.p, s.user_ids,
-		                                      s.user_ids ? s.orig_sorted.as<uint32_t>() : nullptr, gd, st);
+		// sort + cell table + occupied-cell list (two-pass bucket build where the key fits; the exact layout keeps the stable sort)
+		int passes = 0;
+		const uint32_t q_limit = (s.n_query >= 0 && s.n_query < s.n) ? (uint32_t)s.n_query : 0xffffffffu;
+		s.sorted_buf = tnsx::launch_cell_build(s.d_xyz, variable ? s.d_radii : nullptr, s.n, g, key_bits, cb, c->sort_temp.p, s.user_ids,
+		                                       s.user_ids ? s.orig_sorted.as<uint32_t>() : nullptr, gd, q_limit, c->opt.exact_layout != 0,
+		                                       s.table.as<uint2>(), s.occ.as<uint2>(), c->n_occ.as<uint32_t>() + si, &passes, st);
+		S.radix_passes = passes;
 		const int t2 = tm.mark();
-		tnsx::launch_cell_table(cb.xyzi[s.sorted_buf], s.n, g, s.table.as<uint2>(), s.occ.as<uint2>(), c->n_occ.as<uint32_t>() + si, st);
-		const int t3 = tm.mark();
+		const int t3 = t2;   // (the table is part of the build now: ms_cells stays 0 unless the LSD path ran)
 		span(ST_KEYS, t0, t1); span(ST_SORT, t1, t2); span(ST_CELLS, t2, t3);
 	}
 
