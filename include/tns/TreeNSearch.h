@@ -21,7 +21,20 @@ namespace tns
 	class TreeNSearch
 	{
 	public:
-		TreeNSearch()
+		TreeNSearch() { create_(); }
+		~TreeNSearch() { tnsx_destroy(ctx_); }
+		// Copyable like the reference (TreeNSearch.h:36-37 declares neither copy operation): a copy is a NEW engine context with the same
+		// configuration -- point sets (the same user pointers), radius / cell size, symmetric flag, active searches.  Results are not
+		// carried over: run() on the copy produces them.  (The reference's implicit copy shares its executor pointer with the original.)
+		TreeNSearch(const TreeNSearch& o) { create_(); replay_(o); }
+		TreeNSearch& operator=(const TreeNSearch& o)
+		{
+			if (this != &o) { tnsx_destroy(ctx_); ctx_ = nullptr; views_.clear(); n_sets_at_run_ = 0; zsort_.clear(); zsort_fetched_.clear(); log_ = Log(); create_(); replay_(o); }
+			return *this;
+		}
+
+	private:
+		void create_()
 		{
 			tnsx_options opt;
 			tnsx_default_options(&opt);
@@ -44,26 +57,53 @@ namespace tns
 				exit(-1);
 			}
 		}
-		~TreeNSearch() { tnsx_destroy(ctx_); }
-		TreeNSearch(const TreeNSearch&) = delete;
-		TreeNSearch& operator=(const TreeNSearch&) = delete;
+		// what a copy replays (the engine keeps the same state; the shim keeps it too, in the order the calls were made)
+		struct SetRec { const void* xyz; const void* radii; int n; unsigned flags_xyz, flags_radii; };
+		struct Log { std::vector<SetRec> sets; bool radius_set = false; float radius = 0.f; bool cell_set = false; float cell = 0.f; bool symmetric = true; };
+		int add_(const void* xyz, const void* radii, const int n, const unsigned flags)
+		{
+			const int id = id_(tnsx_add_point_set(ctx_, xyz, radii, n, flags));
+			log_.sets.push_back({ xyz, radii, n, flags, flags });
+			return id;
+		}
+		void resize_(const int set_id, const void* xyz, const void* radii, const int n, const unsigned flags)
+		{
+			ok_(tnsx_resize_point_set(ctx_, set_id, xyz, radii, n, flags));
+			SetRec& r = log_.sets[(size_t)set_id];
+			r.xyz = xyz; r.n = n; r.flags_xyz = flags;
+			if (radii || (flags & TNSX_VARIABLE)) { r.radii = radii; r.flags_radii = flags; }
+		}
+		void replay_(const TreeNSearch& o)
+		{
+			if (o.log_.radius_set) set_search_radius(o.log_.radius);
+			if (o.log_.cell_set) set_cell_size(o.log_.cell);
+			for (const SetRec& r : o.log_.sets) {
+				const int id = add_(r.xyz, r.radii, r.n, r.flags_radii);
+				if (r.flags_xyz != r.flags_radii) resize_(id, r.xyz, nullptr, r.n, r.flags_xyz & ~TNSX_VARIABLE);   // (points of another element type than the radii)
+			}
+			set_symmetric_search(o.log_.symmetric);
+			const int ns = o.get_n_sets();
+			for (int i = 0; i < ns; i++) for (int j = 0; j < ns; j++) if (o.is_search_active(i, j)) set_active_search(i, j, true);
+			n_threads_ = o.n_threads_;
+		}
 
+	public:
 		// ----------------------------------------------------------------------------- main interface
 		// fixed-radius sets (TreeNSearch.h:50, :63)
-		int add_point_set(const float* points_begin, const int n_points) { return id_(tnsx_add_point_set(ctx_, points_begin, nullptr, n_points, TNSX_F32 | TNSX_HOST)); }
-		int add_point_set(const double* points_begin, const int n_points) { return id_(tnsx_add_point_set(ctx_, points_begin, nullptr, n_points, TNSX_F64 | TNSX_HOST)); }
-		void resize_point_set(const int set_id, const float* points_begin, const int n_points) { ok_(tnsx_resize_point_set(ctx_, set_id, points_begin, nullptr, n_points, TNSX_F32 | TNSX_HOST)); }
-		void resize_point_set(const int set_id, const double* points_begin, const int n_points) { ok_(tnsx_resize_point_set(ctx_, set_id, points_begin, nullptr, n_points, TNSX_F64 | TNSX_HOST)); }
-		void set_search_radius(const float search_radius) { ok_(tnsx_set_search_radius(ctx_, search_radius)); }
+		int add_point_set(const float* points_begin, const int n_points) { return add_(points_begin, nullptr, n_points, TNSX_F32 | TNSX_HOST); }
+		int add_point_set(const double* points_begin, const int n_points) { return add_(points_begin, nullptr, n_points, TNSX_F64 | TNSX_HOST); }
+		void resize_point_set(const int set_id, const float* points_begin, const int n_points) { resize_(set_id, points_begin, nullptr, n_points, TNSX_F32 | TNSX_HOST); }
+		void resize_point_set(const int set_id, const double* points_begin, const int n_points) { resize_(set_id, points_begin, nullptr, n_points, TNSX_F64 | TNSX_HOST); }
+		void set_search_radius(const float search_radius) { ok_(tnsx_set_search_radius(ctx_, search_radius)); log_.radius_set = true; log_.radius = search_radius; }
 		void set_search_radius(const double search_radius) { set_search_radius((float)search_radius); }
 
 		// variable-radius sets (TreeNSearch.h:112, :126)
-		int add_point_set(const float* points_begin, const float* radii_begin, const int n_points) { return id_(tnsx_add_point_set(ctx_, points_begin, radii_begin, n_points, TNSX_F32 | TNSX_HOST | TNSX_VARIABLE)); }
-		int add_point_set(const double* points_begin, const double* radii_begin, const int n_points) { return id_(tnsx_add_point_set(ctx_, points_begin, radii_begin, n_points, TNSX_F64 | TNSX_HOST | TNSX_VARIABLE)); }
-		void resize_point_set(const int set_id, const float* points_begin, const float* radii_begin, const int n_points) { ok_(tnsx_resize_point_set(ctx_, set_id, points_begin, radii_begin, n_points, TNSX_F32 | TNSX_HOST | TNSX_VARIABLE)); }
-		void resize_point_set(const int set_id, const double* points_begin, const double* radii_begin, const int n_points) { ok_(tnsx_resize_point_set(ctx_, set_id, points_begin, radii_begin, n_points, TNSX_F64 | TNSX_HOST | TNSX_VARIABLE)); }
+		int add_point_set(const float* points_begin, const float* radii_begin, const int n_points) { return add_(points_begin, radii_begin, n_points, TNSX_F32 | TNSX_HOST | TNSX_VARIABLE); }
+		int add_point_set(const double* points_begin, const double* radii_begin, const int n_points) { return add_(points_begin, radii_begin, n_points, TNSX_F64 | TNSX_HOST | TNSX_VARIABLE); }
+		void resize_point_set(const int set_id, const float* points_begin, const float* radii_begin, const int n_points) { resize_(set_id, points_begin, radii_begin, n_points, TNSX_F32 | TNSX_HOST | TNSX_VARIABLE); }
+		void resize_point_set(const int set_id, const double* points_begin, const double* radii_begin, const int n_points) { resize_(set_id, points_begin, radii_begin, n_points, TNSX_F64 | TNSX_HOST | TNSX_VARIABLE); }
 
-		void set_cell_size(const float cell_size) { ok_(tnsx_set_cell_size(ctx_, cell_size)); }
+		void set_cell_size(const float cell_size) { ok_(tnsx_set_cell_size(ctx_, cell_size)); log_.cell_set = true; log_.cell = cell_size; }
 		void set_cell_size(const double cell_size) { set_cell_size((float)cell_size); }
 
 		/** Build + query on the GPU; lists are complete (and mirrored to the host) on return. */
@@ -129,7 +169,7 @@ namespace tns
 				for (size_t j = 0; j < st; j++) data_ptr[(size_t)k * st + j] = old[src + j];
 			}
 		}
-		void set_symmetric_search(const bool activate) { ok_(tnsx_set_symmetric_search(ctx_, activate ? 1 : 0)); }
+		void set_symmetric_search(const bool activate) { ok_(tnsx_set_symmetric_search(ctx_, activate ? 1 : 0)); log_.symmetric = activate; }
 
 		// ----------------------------------------------------------------------------- secondary methods
 		void print_state() const
@@ -180,6 +220,10 @@ namespace tns
 		// host copy of one set's z-order, fetched from the engine on first use (the engine itself keeps it on the device)
 		const std::vector<int>& order_of_(const int set_i) const
 		{
+			if (set_i < 0 || (size_t)set_i >= zsort_.size()) {   // (get_zsort_order before prepare_zsort: the reference indexes an empty vector)
+				std::cout << "tns::TreeNSearch::apply_zsort error: no zsort order ready for set_i (" << set_i << ")." << std::endl;
+				exit(-1);
+			}
 			if (!zsort_fetched_[(size_t)set_i]) {
 				#pragma omp critical(tnsx_zsort_fetch)
 				if (!zsort_fetched_[(size_t)set_i]) {
@@ -212,5 +256,6 @@ namespace tns
 		mutable std::vector<std::vector<int>> zsort_;
 		mutable std::vector<char> zsort_fetched_;
 		int n_threads_ = -1;
+		Log log_;
 	};
 }

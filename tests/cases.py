@@ -150,15 +150,19 @@ def small_cases() -> List[Case]:
     ]
 
 
+# Digest-only fixtures (generated once from the real reference): scaled / full BASELINE configs.  Built one at a time, on demand
+# (the 10 M-point cloud takes a while to generate: nobody who asks for another case should pay for it)
+_LARGE = {
+    "uniform_fixed_1000000": lambda: uniform_fixed(1000000, size_class="medium"),
+    "uniform_fixed_2000000": lambda: uniform_fixed(2000000, size_class="medium"),          # the scaled instance of configs[4] (slab tests)
+    "two_set_asym_800000_200000": lambda: two_set_asymmetric(800000, 200000, size_class="medium"),
+    "dam_break_sym_1000000": lambda: dam_break(1000000, True, size_class="medium"),
+    "uniform_fixed_10000000": lambda: uniform_fixed(10000000, size_class="large"),
+}
+
+
 def large_cases() -> List[Case]:
-    """Digest-only fixtures (generated once from the real reference): scaled / full BASELINE configs."""
-    return [
-        uniform_fixed(1000000, size_class="medium"),
-        uniform_fixed(2000000, size_class="medium"),          # the scaled instance of configs[4] (slab tests)
-        two_set_asymmetric(800000, 200000, size_class="medium"),
-        dam_break(1000000, True, size_class="medium"),
-        uniform_fixed(10000000, size_class="large"),
-    ]
+    return [make() for make in _LARGE.values()]
 
 
 _SMALL_CACHE: List[Case] = []
@@ -171,7 +175,8 @@ def by_name(name: str) -> Case:
     for c in _SMALL_CACHE:
         if c.name == name:
             return c
-    for c in large_cases():
-        if c.name == name:
-            return c
+    if name in _LARGE:
+        c = _LARGE[name]()
+        assert c.name == name
+        return c
     raise KeyError(name)

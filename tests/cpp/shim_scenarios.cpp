@@ -86,6 +86,17 @@ void one_set_fixed_radius(int n_points)
 	int visited = 0;
 	ns.for_each_neighbor(s, s, 0, [&](int) { visited++; });
 	if (visited != ns.get_neighborlist(s, s, 0).size()) { std::printf("\tfor_each_neighbor xxxxxxx FAILED! xxxxxxx\n"); g_failures++; }
+	// the class is copyable like the reference's (TreeNSearch.h:36-37): a copy carries the configuration and runs on its own
+	{
+		tns::TreeNSearch copy(ns);
+		copy.run();
+		expect_equal(copy, s, s, all_pairs(c.p[0].data(), r.data(), c.n(), c.p[0].data(), r.data(), c.n(), true, false), "copy constructed + run");
+		tns::TreeNSearch assigned;
+		assigned = copy;
+		assigned.run();
+		expect_equal(assigned, s, s, all_pairs(c.p[0].data(), r.data(), c.n(), c.p[0].data(), r.data(), c.n(), true, false), "copy assigned + run");
+		expect_equal(ns, s, s, all_pairs(c.p[0].data(), r.data(), c.n(), c.p[0].data(), r.data(), c.n(), true, false), "original after the copies");
+	}
 }
 
 void two_sets_variable(int n_points, bool second_as_double)

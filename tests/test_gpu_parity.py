@@ -11,7 +11,7 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 SMALL = CS.small_cases()
-LARGE = CS.large_cases()
+MEDIUM = ["uniform_fixed_1000000", "uniform_fixed_2000000", "two_set_asym_800000_200000", "dam_break_sym_1000000"]   # (built on demand, CS.by_name)
 
 
 @pytest.mark.parametrize("case", SMALL, ids=[c.name for c in SMALL])
@@ -26,9 +26,10 @@ def test_small_cases_match_oracle_and_golden(case, mode, oracle):
     assert st["n_neighbors"] == sum(int(ora[pr][0][-1]) for pr in case.active)
 
 
-@pytest.mark.parametrize("case", [c for c in LARGE if c.size_class == "medium"], ids=[c.name for c in LARGE if c.size_class == "medium"])
+@pytest.mark.parametrize("case", MEDIUM)
 @pytest.mark.parametrize("mode", [0, 1], ids=["strict", "contracted"])
 def test_medium_cases_match_golden_digest(case, mode, oracle):
+    case = CS.by_name(case)
     res, _ = P.run_engine_case(case, mode, device_inputs=True)
     P.assert_matches_golden(res, load_golden(case.name), mode, oracle, case.name)
 

@@ -29,8 +29,12 @@ namespace tnsx {
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 #ifndef TNSX_CULL_FROM
-#define TNSX_CULL_FROM 448   // cells with more candidates than this are culled first (measured: 512 / 448 / 384 -> C2 1.775 / 1.766 / 2.003 ms,
+#define TNSX_CULL_FROM 448   // fixed radius: cells with more candidates than this are culled first (measured: 512 / 448 / 384 -> C2 1.775 / 1.766 / 2.003 ms,
                              // C3 2.54 / 2.44 / 2.61 ms, C4 at 20 M 5.77 / 5.68 / 5.58 ms)
+#endif
+#ifndef TNSX_CULL_FROM_VARIABLE
+#define TNSX_CULL_FROM_VARIABLE 320   // per-point radii (a cell edge of r_max, most radii well below it: the cull removes more): round 3, with the LDS deal table,
+                                      // 0 / 320 / 448 -> C4 at 10 M 2.54 / 2.44 / 2.50 ms (profiles/r3_query_ab_cull_threshold.txt); fixed radius: 1.86 / 1.87 / 1.58
 #endif
 #ifndef TNSX_CULL
 #define TNSX_CULL 1   // first tier: cells with 513..1024 candidates are culled against the bounding box of their query points (fast_cell_culled)
@@ -1280,7 +1284,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 
 		const uint32_t nq = cur_q.y - cur_q.x;
 		bool pass_on = RR.total > 2u * (uint32_t)Q_SLOTS || nq > (uint32_t)WAVE;
-		if (!pass_on && !FAT && RR.total > (uint32_t)TNSX_CULL_FROM) {
+		if (!pass_on && !FAT && RR.total > (uint32_t)(VARIABLE ? TNSX_CULL_FROM_VARIABLE : TNSX_CULL_FROM)) {
 			// more candidates than the loop holds: cull them against the bounding box of the query points; the cell is done
 			// here if at most 512 survive
 			pass_on = !(TNSX_CULL && fast_cell_culled<ARITH, VARIABLE, SYM, SELF>(a, RR, lane, cur_q, ps, wave_hits, my_slots));
@@ -1291,7 +1295,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 			if ((uint32_t)lane == rej_n) rej = make_uint2(p0, key);
 			if (++rej_n == (uint32_t)WAVE) { flush_rejects(); rej_n = 0; }
 		}
-		else if (!FAT && RR.total > (uint32_t)TNSX_CULL_FROM) { /* done by the culled path above */ }
+		else if (!FAT && RR.total > (uint32_t)(VARIABLE ? TNSX_CULL_FROM_VARIABLE : TNSX_CULL_FROM)) { /* done by the culled path above */ }
 		else if (RR.total == 0u && a.shared_empty != 0u) {
 			// no candidate at all, and the offsets of this pair were pre-set to the shared empty record: nothing to do.  (The fluid of an
 			// SPH scene searched in its boundary: most fluid cells are nowhere near it.)
