@@ -96,7 +96,9 @@ typedef struct tnsx_options {
 	int query_blocks_per_cu;  /* tuning: workgroups per CU of the general query kernel (1..16); 0 = default (7) */
 	int fast_blocks_per_cu;   /* tuning: workgroups per CU of the fast pool kernels (1..16); 0 = default (8).  Both are fixed at tnsx_create:
 	                             nothing in the launch path reads the environment */
-	int reserved[2];
+	int bucket_build_min_points; /* sets with at least this many points are built with the two-pass bucket build where
+	                             their key allows it; 0 = default (65536), < 0: never (always the stable LSD passes + k_cell_table) */
+	int reserved[1];
 } tnsx_options;
 
 /* Neighbour lists of one active (set_i -> set_j) pair.  Record layout == the reference's chunk storage

@@ -399,3 +399,38 @@ def test_c_abi_two_sets_asymmetric_searches(oracle):
         assert int(g_offs[-1]) == fx["total"]
     for k in range(3):
         assert log[k][1] == (True, False, 1)
+
+
+def test_rccl_transport_on_one_rank():
+    """The RCCL transport of the slab layer on the only GPU there is: RCCL refuses two ranks on one device, so a world of ONE rank is all
+    a single-GPU box can run -- it still goes through everything tnsx_slab_transport_rccl does (dlopen of librccl, every symbol,
+    ncclGetUniqueId, ncclCommInitRank, one group of ncclSend + ncclRecv to itself on the caller's stream, ncclAllReduce of all three
+    kinds, ncclCommDestroy), with the payload checked."""
+    import ctypes as C
+    import torch
+    from treensearch_amd import api as A
+    L = A.load_library()
+    raw = (C.c_ubyte * 128)()
+    assert L.tnsx_slab_rccl_unique_id(raw) == 0, (L.tnsx_slab_rccl_error() or b"").decode()
+    tr = A.SlabTransport()
+    assert L.tnsx_slab_transport_rccl(raw, 0, 1, 0, C.byref(tr)) == 0, (L.tnsx_slab_rccl_error() or b"").decode()
+
+    class Op(C.Structure):
+        _fields_ = [("peer", C.c_int), ("send", C.c_void_p), ("send_bytes", C.c_size_t), ("recv", C.c_void_p), ("recv_bytes", C.c_size_t)]
+    exchange = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(Op), C.c_int, C.c_void_p)(tr.exchange)
+    allreduce = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p)(tr.allreduce)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        src = torch.arange(100003, dtype=torch.float32, device="cuda") * 0.5
+        dst = torch.zeros_like(src)
+        op = Op(0, src.data_ptr(), src.numel() * 4, dst.data_ptr(), dst.numel() * 4)
+        assert exchange(tr.user, 0, 1, C.byref(op), 1, C.c_void_p(stream.cuda_stream)) == 0
+        u = torch.tensor([3, 5, 7], dtype=torch.int32, device="cuda")
+        f = torch.tensor([1.5, -2.0], dtype=torch.float32, device="cuda")
+        assert allreduce(tr.user, 0, 1, u.data_ptr(), 3, 0, C.c_void_p(stream.cuda_stream)) == 0      # sum of u32
+        assert allreduce(tr.user, 0, 1, f.data_ptr(), 2, 1, C.c_void_p(stream.cuda_stream)) == 0      # min of f32
+        assert allreduce(tr.user, 0, 1, f.data_ptr(), 2, 2, C.c_void_p(stream.cuda_stream)) == 0      # max of f32
+    stream.synchronize()
+    assert torch.equal(src, dst) and u.tolist() == [3, 5, 7] and f.tolist() == [1.5, -2.0]
+    L.tnsx_slab_transport_release(C.byref(tr))
+    assert not tr.user

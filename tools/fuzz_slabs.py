@@ -53,7 +53,11 @@ while time.time() < t_end:
     desc = f"n {n} {kind} world {world} variable {variable} ratio {ratio} r0 {r0:.4g} symmetric {case.symmetric}"
     try:
         s_offs, s_idx = TS._single_device(case)
-        (g_offs, g_idx), log, sizes, _ = TS._run_slabs(case, world, n_steps=int(rng.integers(1, 4)), speculative=bool(rng.random() < 0.8))
+        if rng.random() < 0.5:     # the C entry points of the slab layer (tnsx_slab_step, in-process transport) ...
+            unions, log, sizes, _ = TS._run_slabs_c(case, world, n_steps=int(rng.integers(1, 4)), speculative=bool(rng.random() < 0.8))
+            g_offs, g_idx = unions[(0, 0)]
+        else:                      # ... or the Python layer over the same protocol
+            (g_offs, g_idx), log, sizes, _ = TS._run_slabs(case, world, n_steps=int(rng.integers(1, 4)), speculative=bool(rng.random() < 0.8))
     except ValueError as e:
         if "planes" in str(e) or "slabs asked" in str(e):
             continue            # fewer x planes than slabs: the decomposition refuses, as documented

@@ -86,6 +86,26 @@ __global__ void __launch_bounds__(256) k(float* out, float seed)
 			             "v_pk_add_f32 %4, %8, %4 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %5, %8, %5 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %6, %8, %6 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %7, %8, %7 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]"
 			             : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7) : "v"(b0));
 		}
+		else if (MODE == 19) {  // 8 x v_cndmask_b32 e64 with an sgpr-pair mask
+			asm volatile("v_cndmask_b32_e64 %0, %0, %8, s[20:21]\n v_cndmask_b32_e64 %1, %1, %8, s[20:21]\n v_cndmask_b32_e64 %2, %2, %8, s[20:21]\n v_cndmask_b32_e64 %3, %3, %8, s[20:21]\n v_cndmask_b32_e64 %4, %4, %8, s[20:21]\n v_cndmask_b32_e64 %5, %5, %8, s[20:21]\n v_cndmask_b32_e64 %6, %6, %8, s[20:21]\n v_cndmask_b32_e64 %7, %7, %8, s[20:21]"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c) : "s20", "s21");
+		}
+		else if (MODE == 20) {  // 8 x v_cndmask_b32 vcc on INDEPENDENT destinations (mode 9 chains nothing either, but reuses its sources)
+			asm volatile("v_cndmask_b32 %0, %8, %9, vcc\n v_cndmask_b32 %1, %8, %9, vcc\n v_cndmask_b32 %2, %8, %9, vcc\n v_cndmask_b32 %3, %8, %9, vcc\n v_cndmask_b32 %4, %8, %9, vcc\n v_cndmask_b32 %5, %8, %9, vcc\n v_cndmask_b32 %6, %8, %9, vcc\n v_cndmask_b32 %7, %8, %9, vcc"
+			             : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3), "=v"(a4), "=v"(a5), "=v"(a6), "=v"(a7) : "v"(c), "v"(b0.x) : "vcc");
+		}
+		else if (MODE == 21) {  // 4 x (v_cmp -> vcc, v_cndmask vcc): the compare + select pair of a clamp
+			asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %0, %0, %8, vcc\n v_cmp_lt_f32 vcc, %1, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %2, %2, %8, vcc\n v_cmp_lt_f32 vcc, %3, %8\n v_cndmask_b32 %3, %3, %8, vcc"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c) : "vcc");
+		}
+		else if (MODE == 22) {  // 8 x v_min_f32 (select-free clamp)
+			asm volatile("v_min_f32 %0, %0, %8\n v_min_f32 %1, %1, %8\n v_min_f32 %2, %2, %8\n v_min_f32 %3, %3, %8\n v_min_f32 %4, %4, %8\n v_min_f32 %5, %5, %8\n v_min_f32 %6, %6, %8\n v_min_f32 %7, %7, %8"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+		}
+		else if (MODE == 23) {  // 8 x ds_bpermute_b32
+			asm volatile("ds_bpermute_b32 %0, %8, %0\n ds_bpermute_b32 %1, %8, %1\n ds_bpermute_b32 %2, %8, %2\n ds_bpermute_b32 %3, %8, %3\n ds_bpermute_b32 %4, %8, %4\n ds_bpermute_b32 %5, %8, %5\n ds_bpermute_b32 %6, %8, %6\n ds_bpermute_b32 %7, %8, %7\n s_waitcnt lgkmcnt(0)"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+		}
 		else if (MODE == 12) {  // 8 x v_add_f32 vgpr operands
 			asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8"
 			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
@@ -113,5 +133,6 @@ int main()
 	run<7>("v_cmp_ge_f32 e32 -> vcc", d); run<8>("v_mbcnt_lo/hi (per instr)", d); run<9>("v_cndmask_b32 vcc", d); run<10>("v_readlane_b32", d); run<11>("v_add_u32", d); run<12>("v_add_f32 vgpr", d);
 	run<13>("v_addc_co_u32 sgpr carry-in", d); run<14>("v_add_u32_dpp row_shr:1", d); run<15>("v_cmpx_ge_f32 + s_mov exec", d); run<16>("v_alignbit_b32", d);
 	run<17>("v_writelane_b32", d); run<18>("v_pk_add_f32 vgpr bcast operand", d);
+	run<19>("v_cndmask_b32_e64 sgpr mask", d); run<20>("v_cndmask_b32 vcc, indep dst", d); run<21>("v_cmp->vcc + v_cndmask (per pair /2)", d); run<22>("v_min_f32", d); run<23>("ds_bpermute_b32", d);
 	return 0;
 }

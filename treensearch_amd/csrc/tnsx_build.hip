@@ -647,9 +647,10 @@ __global__ void __launch_bounds__(BS_THREADS) k_occ_reorder(const uint2* __restr
 }
 
 // bits of the two digits of the bucket build, or {0, 0} when the key is too wide for it (the LSD passes + k_cell_table then)
-static bool bucket_plan(int key_bits, int n, int& hi_bits, int& lo_bits)
+static bool bucket_plan(int key_bits, int n, int min_points, int& hi_bits, int& lo_bits)
 {
-	if (key_bits > 24 || n < (1 << 16)) return false;
+	if (min_points < 0) return false;
+	if (key_bits > 24 || n < (min_points > 0 ? min_points : (1 << 16))) return false;
 	lo_bits = key_bits / 2;
 	lo_bits = lo_bits < 8 ? 8 : (lo_bits > 13 ? 13 : lo_bits);
 	hi_bits = key_bits - lo_bits;
@@ -663,11 +664,11 @@ size_t cell_build_temp_bytes(int n)
 	return ((cell_sort_temp_bytes(n) + 255) / 256) * 256 + (size_t)(n > 0 ? n : 1) * sizeof(uint2) + ((size_t)1 << CS_MAX_BITS) * sizeof(uint2) + 256;
 }
 int launch_cell_build(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, const int* ids,
-                      uint32_t* orig_sorted, const BuildGuard& gd, uint32_t query_limit, bool stable_order, uint2* table, uint2* occ, uint32_t* n_occ,
-                      int* passes_out, hipStream_t s)
+                      uint32_t* orig_sorted, const BuildGuard& gd, uint32_t query_limit, bool stable_order, int bucket_min_points, uint2* table, uint2* occ,
+                      uint32_t* n_occ, int* passes_out, hipStream_t s)
 {
 	int hi_bits = 0, lo_bits = 0;
-	if (stable_order || !bucket_plan(key_bits, n, hi_bits, lo_bits)) {
+	if (stable_order || !bucket_plan(key_bits, n, bucket_min_points, hi_bits, lo_bits)) {
 		const int res = launch_cell_sort(xyz, radii, n, g, key_bits, b, temp, ids, orig_sorted, gd, s);
 		launch_cell_table(b.xyzi[res], n, g, table, occ, n_occ, s);
 		if (passes_out) *passes_out = cell_sort_plan(key_bits).passes;

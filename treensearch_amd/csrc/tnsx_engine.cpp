@@ -847,7 +847,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		const uint32_t q_limit = (s.n_query >= 0 && s.n_query < s.n) ? (uint32_t)s.n_query : 0xffffffffu;
 		s.sorted_buf = tnsx::launch_cell_build(s.d_xyz, variable ? s.d_radii : nullptr, s.n, g, key_bits, cb, c->sort_temp.p, s.user_ids,
 		                                       s.user_ids ? s.orig_sorted.as<uint32_t>() : nullptr, gd, q_limit, c->opt.exact_layout != 0,
-		                                       s.table.as<uint2>(), s.occ.as<uint2>(), c->n_occ.as<uint32_t>() + si, &passes, st);
+		                                       c->opt.bucket_build_min_points, s.table.as<uint2>(), s.occ.as<uint2>(), c->n_occ.as<uint32_t>() + si, &passes, st);
 		S.radix_passes = passes;
 		const int t2 = tm.mark();
 		const int t3 = t2;   // (the table is part of the build now: ms_cells stays 0 unless the LSD path ran)

@@ -58,8 +58,8 @@ struct BuildGuard {
 // come behind the others inside a cell; stable_order: keep the input order inside a cell (exact layout).  temp: cell_build_temp_bytes(n).
 size_t cell_build_temp_bytes(int n);
 int launch_cell_build(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, const int* ids,
-                      uint32_t* orig_sorted, const BuildGuard& gd, uint32_t query_limit, bool stable_order, uint2* table, uint2* occ, uint32_t* n_occ,
-                      int* passes_out, hipStream_t s);
+                      uint32_t* orig_sorted, const BuildGuard& gd, uint32_t query_limit, bool stable_order, int bucket_min_points, uint2* table, uint2* occ,
+                      uint32_t* n_occ, int* passes_out, hipStream_t s);
 int launch_cell_sort(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, const int* ids,
                      uint32_t* orig_sorted, const BuildGuard& gd, hipStream_t s);
 // the same checksum on its own (sets whose build is skipped)

@@ -36,6 +36,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define TNSX_CULL_FROM_VARIABLE 320   // per-point radii (a cell edge of r_max, most radii well below it: the cull removes more): round 3, with the LDS deal table,
                                       // 0 / 320 / 448 -> C4 at 10 M 2.54 / 2.44 / 2.50 ms (profiles/r3_query_ab_cull_threshold.txt); fixed radius: 1.86 / 1.87 / 1.58
 #endif
+#ifndef TNSX_FAT_CULL
+#define TNSX_FAT_CULL 1   // the second tier repeats the cull (its cells are those of which > 512 candidates survive) and loops over the survivors only
+#endif
 #ifndef TNSX_CULL
 #define TNSX_CULL 1   // first tier: cells with 513..1024 candidates are culled against the bounding box of their query points (fast_cell_culled)
 #endif
@@ -556,6 +559,8 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 		const uint2 oc_nn = ci_nn < hi ? a.occ_i[ci_nn] : make_uint2(0u, 0u);
 
 		// ---- merge the 27 lookups of the CURRENT cell into 9 x-runs (lanes 0,3,..,24)
+		// (four ds_bpermute, 24 cycles each by tools/ubench/valu_rate.hip; wave_shl:1 DPP moves in their place measured 3 % SLOWER
+		//  on the whole query in three interleaved A/Bs of rotating order, profiles/r3_query_ab_micro.txt)
 		const uint32_t s1 = __shfl_down(s, 1, WAVE), e1 = __shfl_down(e, 1, WAVE);
 		const uint32_t s2 = __shfl_down(s, 2, WAVE), e2 = __shfl_down(e, 2, WAVE);
 		RunRef RR;
@@ -776,6 +781,9 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 
 	for (uint32_t t = 0; t < nq; t++) {
 		if (spos + max_len > STAGE) flush(t);   // (cells with many query points: the block leaves in pieces)
+		// (three v_readlane, 4.3 cycles each.  The point through a scalar load instead: -0.5 %; through the LDS -- parked once per cell,
+		//  one broadcast ds_read per query -- +8 %: the 4 KB per workgroup it needs take the staging area to the LDS limit of five
+		//  workgroups per CU.  profiles/r3_query_ab_micro.txt)
 		const float qx = readlane_f32(qv.x, (int)t), qy = readlane_f32(qv.y, (int)t), qz = readlane_f32(qv.z, (int)t);
 		const float r2q = VARIABLE ? readlane_f32(qr2, (int)t) : a.r2_fixed;
 		uint64_t m[NC];
@@ -1017,7 +1025,8 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 // ---------------------------------------------------------------------------------------------------------------------
 template <int ARITH, bool SYM, bool OWN_FIRST>
 __device__ __forceinline__ uint32_t cull_round(const QueryArgs& a, const Runs R, int lane, uint32_t base, uint32_t kept, float lox, float loy, float loz,
-                                               float hix, float hiy, float hiz, float r2q_max, uint16_t* __restrict__ lds_slots, const uint32_t* __restrict__ tbl)
+                                               float hix, float hiy, float hiz, float r2q_max, uint16_t* __restrict__ lds_slots, const uint32_t* __restrict__ tbl,
+                                               uint32_t slot_cap)
 {
 	const uint32_t nc = (R.total - base + WAVE - 1) / WAVE;   // chunks of this round that hold candidates (the rest is skipped)
 	float4 craw[Q_MAXPAIRS * 2];
@@ -1050,7 +1059,7 @@ __device__ __forceinline__ uint32_t cull_round(const QueryArgs& a, const Runs R,
 			const bool keep = slot < R.total && (slot < R.p1 || d2lb <= lim);
 			const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
 			const uint32_t pos = kept + mbcnt64(m);
-			if (keep && pos < (uint32_t)Q_SLOTS) lds_slots[pos] = (uint16_t)slot;
+			if (keep && pos < slot_cap) lds_slots[pos] = (uint16_t)slot;
 			kept += (uint32_t)__popcll(m);
 		}
 	}
@@ -1106,11 +1115,15 @@ __device__ __forceinline__ void fast_cell_from_slots(const QueryArgs& a, const R
 	fast_query_loop<ARITH, VARIABLE, SYM, SELF, NC>(a, RR, lane, cur_q, ps, wave_hits, cx, cy, cz, cid, cr2, qv, qr2, qorig);
 }
 
-// -> false: more than Q_SLOTS candidates survive; nothing has been written
-template <int ARITH, bool VARIABLE, bool SYM, bool SELF>
+// -> false: more candidates survive than the tier's loop holds (first tier: 512, fat tier: 1024); nothing has been written.
+// Round 3: the fat tier culls too.  Its cells are the ones of which more than 512 candidates survived the first tier's cull; the
+// cull's result is not kept (the survivors' slot numbers live in the first-tier wave's LDS), so the fat wave repeats it -- and then
+// runs its query loop on the ~2/3 of the candidates that survive instead of all of them (C4: the dense column of the dam break).
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF, bool FAT>
 __device__ __forceinline__ bool fast_cell_culled(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits,
                                                  uint16_t* __restrict__ lds_slots)
 {
+	constexpr uint32_t SLOT_CAP = FAT ? 2u * (uint32_t)Q_SLOTS : (uint32_t)Q_SLOTS;
 	const uint32_t nq = cur_q.y - cur_q.x;
 	constexpr bool OWN_FIRST = SELF;
 	const Runs R = extract_runs_t<OWN_FIRST>(RR.run_start, RR.run_len, cur_q.x);
@@ -1124,26 +1137,43 @@ __device__ __forceinline__ bool fast_cell_culled(const QueryArgs& a, const RunRe
 	wave_bbox(lox, loy, loz, hix, hiy, hiz);
 	const float r2q_max = VARIABLE ? wave_max_dpp(qr2) : a.r2_fixed;
 
-	const uint32_t* const tbl = record_stage<(int)StageSize<8>::ints>();
+	const uint32_t* const tbl = record_stage<(int)StageSize<(FAT ? 16 : 8)>::ints>();
 #if TNSX_DEAL_LDS
 	deal_table<OWN_FIRST>(readfirstlane_u32((uint32_t)(uintptr_t)tbl), R, (uint32_t)lane);   // up to 1024 slots: inside the staging area
 #endif
 	uint32_t kept = 0;
 	for (uint32_t base = 0; base < R.total; base += (uint32_t)Q_SLOTS)
-		kept = readfirstlane_u32(cull_round<ARITH, SYM, OWN_FIRST>(a, R, lane, base, kept, lox, loy, loz, hix, hiy, hiz, r2q_max, lds_slots, tbl));
-	if (kept > (uint32_t)Q_SLOTS) return false;
+		kept = readfirstlane_u32(cull_round<ARITH, SYM, OWN_FIRST>(a, R, lane, base, kept, lox, loy, loz, hix, hiy, hiz, r2q_max, lds_slots, tbl, SLOT_CAP));
+	if (kept > SLOT_CAP) return false;
+	if (FAT && kept <= (uint32_t)Q_SLOTS) return false;   // (cannot happen: the first tier would have taken the cell; the plain fat path is correct anyway)
 	wave_lds_fence();
-	switch ((kept + WAVE - 1) / WAVE) {
-	case 0:
-	case 1: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 1>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2, qorig); break;
-	case 2: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 2>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2, qorig); break;
-	case 3: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 3>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2, qorig); break;
-	case 4: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 4>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2, qorig); break;
-	case 5: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 5>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2, qorig); break;
-	case 6: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 6>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2, qorig); break;
-	case 7: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 7>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2, qorig); break;
-	default: fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, 8>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2, qorig); break;
+#define TNSX_FROM_SLOTS(N) fast_cell_from_slots<ARITH, VARIABLE, SYM, SELF, N>(a, RR, R, lane, cur_q, ps, wave_hits, lds_slots, kept, qv, qr2, qorig)
+	if (!FAT) {
+		switch ((kept + WAVE - 1) / WAVE) {
+		case 0:
+		case 1: TNSX_FROM_SLOTS(1); break;
+		case 2: TNSX_FROM_SLOTS(2); break;
+		case 3: TNSX_FROM_SLOTS(3); break;
+		case 4: TNSX_FROM_SLOTS(4); break;
+		case 5: TNSX_FROM_SLOTS(5); break;
+		case 6: TNSX_FROM_SLOTS(6); break;
+		case 7: TNSX_FROM_SLOTS(7); break;
+		default: TNSX_FROM_SLOTS(8); break;
+		}
 	}
+	else {
+		switch ((kept + WAVE - 1) / WAVE) {
+		case 9: TNSX_FROM_SLOTS(9); break;
+		case 10: TNSX_FROM_SLOTS(10); break;
+		case 11: TNSX_FROM_SLOTS(11); break;
+		case 12: TNSX_FROM_SLOTS(12); break;
+		case 13: TNSX_FROM_SLOTS(13); break;
+		case 14: TNSX_FROM_SLOTS(14); break;
+		case 15: TNSX_FROM_SLOTS(15); break;
+		default: TNSX_FROM_SLOTS(16); break;
+		}
+	}
+#undef TNSX_FROM_SLOTS
 	wave_lds_fence();   // the next culled cell of this wave overwrites the staging buffer
 	return true;
 }
@@ -1202,8 +1232,9 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 	uint32_t* reject_count = FAT ? a.n_heavy2 : a.n_heavy;
 	uint32_t* tickets = FAT ? a.tickets2 : a.tickets;
 	// staging buffer of the bounding-box cull (slot numbers of the survivors), one slice per wave
-	__shared__ uint16_t s_slots[(!FAT && TNSX_CULL) ? Q_WAVES * Q_SLOTS : 2];
-	uint16_t* const my_slots = s_slots + ((!FAT && TNSX_CULL) ? (threadIdx.x / WAVE) * Q_SLOTS : 0);
+	constexpr int SLOT_CAP = FAT ? 2 * Q_SLOTS : Q_SLOTS;
+	__shared__ uint16_t s_slots[TNSX_CULL ? Q_WAVES * SLOT_CAP : 2];
+	uint16_t* const my_slots = s_slots + (TNSX_CULL ? (threadIdx.x / WAVE) * SLOT_CAP : 0);
 	const int lane = lane_id();
 	const uint32_t n_occ = FAT ? *a.n_heavy : *a.n_occ_i;
 	const uint32_t xcd = blockIdx.x & 7u;
@@ -1267,6 +1298,8 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 		oc_next = entry(first_next2);
 
 		// ---- current cell: merge the x-triples of its 27 lookups into 9 runs
+		// (four ds_bpermute, 24 cycles each by tools/ubench/valu_rate.hip; wave_shl:1 DPP moves in their place measured 3 % SLOWER
+		//  on the whole query in three interleaved A/Bs of rotating order, profiles/r3_query_ab_micro.txt)
 		const uint32_t s1 = __shfl_down(s, 1, WAVE), e1 = __shfl_down(e, 1, WAVE);
 		const uint32_t s2 = __shfl_down(s, 2, WAVE), e2 = __shfl_down(e, 2, WAVE);
 		RunRef RR;
@@ -1284,10 +1317,14 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 
 		const uint32_t nq = cur_q.y - cur_q.x;
 		bool pass_on = RR.total > 2u * (uint32_t)Q_SLOTS || nq > (uint32_t)WAVE;
+		bool fat_culled = false;
 		if (!pass_on && !FAT && RR.total > (uint32_t)(VARIABLE ? TNSX_CULL_FROM_VARIABLE : TNSX_CULL_FROM)) {
 			// more candidates than the loop holds: cull them against the bounding box of the query points; the cell is done
 			// here if at most 512 survive
-			pass_on = !(TNSX_CULL && fast_cell_culled<ARITH, VARIABLE, SYM, SELF>(a, RR, lane, cur_q, ps, wave_hits, my_slots));
+			pass_on = !(TNSX_CULL && fast_cell_culled<ARITH, VARIABLE, SYM, SELF, false>(a, RR, lane, cur_q, ps, wave_hits, my_slots));
+		}
+		else if (!pass_on && FAT && TNSX_CULL && TNSX_FAT_CULL && RR.total > (uint32_t)Q_SLOTS) {
+			fat_culled = fast_cell_culled<ARITH, VARIABLE, SYM, SELF, true>(a, RR, lane, cur_q, ps, wave_hits, my_slots);
 		}
 		if (pass_on) {
 			// not for this tier: goes to the next tier's worklist.  Collected one entry per lane and appended 64 at a time: the
@@ -1296,6 +1333,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 			if (++rej_n == (uint32_t)WAVE) { flush_rejects(); rej_n = 0; }
 		}
 		else if (!FAT && RR.total > (uint32_t)(VARIABLE ? TNSX_CULL_FROM_VARIABLE : TNSX_CULL_FROM)) { /* done by the culled path above */ }
+		else if (fat_culled) { /* done by the culled path above */ }
 		else if (RR.total == 0u && a.shared_empty != 0u) {
 			// no candidate at all, and the offsets of this pair were pre-set to the shared empty record: nothing to do.  (The fluid of an
 			// SPH scene searched in its boundary: most fluid cells are nowhere near it.)
