@@ -896,7 +896,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		a.heavy = pr.heavy.as<uint2>();
 		a.heavy2 = pr.heavy2.as<uint2>();
 		a.pool_slab = pr.pool_slab;
-		a.pool_slab_heavy = std::max<uint32_t>(pr.pool_slab, 4096u);
+		a.pool_slab_heavy = std::max<uint32_t>(pr.pool_slab, 8192u);
 		a.shared_empty = jb.pool && jb.i != jb.j ? 1u : 0u;
 		if (a.shared_empty && pr.n_query > 0) {
 			// the query walks the cells that have candidates at all (launch_mark_cells + launch_filter_marked, enqueued by launch_pool)
@@ -972,12 +972,14 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		for (int r = 0; r < PairResult::NR; r++) total += payload[r];
 		const uint64_t expect = total + total / 8 + 1024;
 		// a wave's last slab stays half empty on average: slabs of 1/8 of a wave's share keep the holes at ~6 % of the pool
-		uint64_t slab = std::min<uint64_t>(16384, std::max<uint64_t>(256, expect / ((uint64_t)query_waves * 8)));
+		// (round 3: the unit of allocation is the block of a whole cell -- some hundred ints to a few thousand -- so a slab is at least 4096
+		//  ints: with the 256-int slabs a small set used to get, every cell would be an allocation of its own)
+		uint64_t slab = std::min<uint64_t>(16384, std::max<uint64_t>(4096, expect / ((uint64_t)query_waves * 8)));
 		// (the holes depend on the slab size: the previous size is kept while it is within an eighth of the ideal one)
 		if (asked && slab >= (uint64_t)pr.pool_slab - pr.pool_slab / 8 && slab <= (uint64_t)pr.pool_slab + pr.pool_slab / 8) slab = pr.pool_slab;
 		if (asked && slab != pr.pool_slab) asked = nullptr;
 		pr.pool_slab = (uint32_t)slab;
-		const uint64_t slab_heavy = std::max<uint64_t>(slab, 4096);
+		const uint64_t slab_heavy = std::max<uint64_t>(slab, 8192);
 		// (a wave takes a slab only if it gets a cell: small sets keep small pools)
 		const uint64_t waves_all = std::min<uint64_t>((uint64_t)query_waves, (uint64_t)pr.n_i + 8);
 		const uint64_t waves_x = std::min<uint64_t>((uint64_t)query_waves / tnsx::POOL_REGIONS, (uint64_t)pr.n_i / tnsx::POOL_REGIONS + 2);

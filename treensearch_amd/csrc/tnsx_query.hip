@@ -744,19 +744,25 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 	// the block [0, spos) = the records of queries [t0, t1) -> the pool
 	auto flush = [&](uint32_t t1) {
 		const uint32_t block = spos;
+		uint64_t dst = base;        // where this block goes
+		uint32_t dst_ok = ok;
+		bool from_slab = true;
 		if (block > left) {
-			// rare: new slab (one atomic on the cursor of this XCD's region)
-			pool_waste(ps, left);
+			// rare: one atomic on the cursor of this XCD's region.  A block of more than half a slab gets an allocation of exactly its
+			// size and the wave keeps what is left of its slab for the blocks to come (blocks are whole cells now, hundreds of ints: throwing
+			// the rest of a slab away for each of them left the pools of small sets half empty); a smaller block opens a new slab.
 			const uint32_t slab = NC > 8 ? a.pool_slab_heavy : a.pool_slab;
-			const uint32_t sz = block > slab ? block : slab;
+			const bool exact = 2u * block > slab;
+			if (!exact) pool_waste(ps, left);
+			const uint32_t sz = exact ? block : slab;
 			const unsigned long long first = pool_take_slab(a.pool_cursor, a.pool_regions, sz, NC > 8 ? 1u : 0u);   // (more than 8 chunks: the fat tier)
-			base = ((uint64_t)readfirstlane_u32((uint32_t)(first >> 32)) << 32) | readfirstlane_u32((uint32_t)first);
-			ok = base != POOL_NONE ? 1u : 0u;
-			if (ok == 0u) base = 0;
-			left = sz;
+			const uint64_t got = ((uint64_t)readfirstlane_u32((uint32_t)(first >> 32)) << 32) | readfirstlane_u32((uint32_t)first);
+			const uint32_t got_ok = got != POOL_NONE ? 1u : 0u;
+			if (exact) { dst = got_ok ? got : 0; dst_ok = got_ok; from_slab = false; }
+			else { base = got_ok ? got : 0; ok = got_ok; left = sz; dst = base; dst_ok = ok; }
 		}
-		if (ok != 0u) {
-			v4i rsrc = record_rsrc(a.records + base);
+		if (dst_ok != 0u) {
+			v4i rsrc = record_rsrc(a.records + dst);
 			rsrc.z = (int)block;   // NUM_RECORDS: the hardware drops the lanes of the last store that lie beyond the block
 			// four reads in flight per round trip to the LDS (STAGE is a multiple of 256: the reads stay inside the wave's area)
 			for (uint32_t f = 0; f < block; f += 4u * (uint32_t)WAVE) {
@@ -770,11 +776,10 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 				             : : [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [i0] "v"(i), [i1] "v"(i + 64u), [i2] "v"(i + 128u), [i3] "v"(i + 192u),
 				                 [rsrc] "s"(rsrc) : "memory");
 			}
-			if ((uint32_t)lane >= t0 && (uint32_t)lane < t1) a.offs_by_orig[qidx] = base + v_pos;
+			if ((uint32_t)lane >= t0 && (uint32_t)lane < t1) a.offs_by_orig[qidx] = dst + v_pos;
 		}
 		hits += block - (t1 - t0);
-		base += block;
-		left -= block;
+		if (from_slab) { base += block; left -= block; }
 		t0 = t1;
 		spos = 0;
 	};
