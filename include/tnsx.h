@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TNSX_VERSION 300
+#define TNSX_VERSION 301
 
 typedef struct tnsx_context tnsx_context;
 
@@ -98,7 +98,11 @@ typedef struct tnsx_options {
 	                             nothing in the launch path reads the environment */
 	int bucket_build_min_points; /* sets with at least this many points are built with the two-pass bucket build where
 	                             their key allows it; 0 = default (65536), < 0: never (always the stable LSD passes + k_cell_table) */
-	int reserved[1];
+	int query_formulation;    /* 0 = default: the cell kernels (candidates in the lanes).  1 = experiment of round 3, measured
+	                             SLOWER: a fixed-radius search of a set in itself first runs the group formulation --
+	                             16 query points of a cell per batch in the lanes, the tests as 16x16x4 fp32 MFMAs with an exact re-test
+	                             inside the rounding band -- and the cell kernels take the cells it passes on; a pair that passes on more
+	                             than a quarter of its cells goes back to the cell kernels alone.  Results are identical either way */
 } tnsx_options;
 
 /* Neighbour lists of one active (set_i -> set_j) pair.  Record layout == the reference's chunk storage
@@ -149,6 +153,9 @@ typedef struct tnsx_stats {
 	                                 reference's tree path), the cell size halved down to < 2^21 steps per axis otherwise (its no-tree path) */
 	int grid_trimmed;             /* 1: cells of one search radius over the bounding box of all points would not fit (far outliers): the grid of the last
 	                                 run covers the bulk of the points, the rest sits in its border cells (exact all the same) */
+	uint32_t n_group_pairs;       /* pairs of the last run that ran the group formulation */
+	uint32_t n_group_passed_cells; /* occupied cells it passed on to the cell kernels (too many candidates or query points, a list overflow, a point
+	                                 far outside its cell), summed over those pairs */
 } tnsx_stats;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */

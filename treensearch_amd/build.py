@@ -15,8 +15,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libtnsx.so")
-SOURCES = ["tnsx_kernels.hip", "tnsx_build.hip", "tnsx_query.hip", "tnsx_engine.cpp", "tnsx_multi.cpp", "tnsx_slab.cpp"]
-HEADERS = ["tnsx_kernels.h", "tnsx_device.h", "tnsx_multi.h", os.path.join(ROOT, "include", "tnsx.h")]
+SOURCES = ["tnsx_kernels.hip", "tnsx_build.hip", "tnsx_query.hip", "tnsx_query_group.hip", "tnsx_engine.cpp", "tnsx_multi.cpp", "tnsx_slab.cpp"]
+HEADERS = ["tnsx_kernels.h", "tnsx_device.h", "tnsx_pool.h", "tnsx_multi.h", os.path.join(ROOT, "include", "tnsx.h")]
 
 # -ffp-contract=off: the neighbour predicate must not be re-associated or fused behind our back
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -47,7 +47,8 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
         extra = os.environ.get("TNSX_EXTRA_FLAGS", "").split()     # experiments, e.g. -DTNSX_FAST_WAVES_PER_EU=5
-        cmd = [hipcc()] + FLAGS + extra + ["-I" + os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, src), "-o", obj]
+        per_file = ["-mllvm", "-amdgpu-mfma-vgpr-form"] if src == "tnsx_query_group.hip" else []   # MFMA results straight into VGPRs (no v_accvgpr_read)
+        cmd = [hipcc()] + FLAGS + per_file + extra + ["-I" + os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

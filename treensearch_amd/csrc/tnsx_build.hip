@@ -57,14 +57,7 @@ size_t cell_sort_temp_bytes(int n)
 
 struct F3 { float x, y, z; };   // 12-byte AoS point of the user array (4-byte aligned)
 
-__device__ __forceinline__ int bin_coord(float p, float o, float inv_h, int n)
-{
-	// fp32 sub, mul, truncate, clamp -- the quantisation form of TreeNSearch.cpp:713-715
-	const float f = __fmul_rn(__fsub_rn(p, o), inv_h);
-	int c = (int)f;
-	c = c < 0 ? 0 : c;
-	return c > n - 1 ? n - 1 : c;
-}
+// (bin_coord: tnsx_device.h -- the query kernels recompute cell coordinates with the very same operations)
 // row-major cell key, x fastest: the three x-neighbours of a row are contiguous in sorted order.
 // A point whose x is NaN is NO POINT (the padding rows of a fixed-capacity ghost message, treensearch_amd/multi.py): it gets the
 // key one past the last cell, is sorted behind everything and enters no cell; every comparison with it is false anyway.

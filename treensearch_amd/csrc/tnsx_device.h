@@ -24,6 +24,16 @@ __device__ __forceinline__ void wave_lds_fence()
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// cell coordinate of a point along one axis: the one quantisation every kernel uses (build, query), so a point is always found
+// in the cell it was sorted into
+__device__ __forceinline__ int bin_coord(float p, float o, float inv_h, int n)
+{
+	// fp32 sub, mul, truncate, clamp -- the quantisation form of TreeNSearch.cpp:713-715
+	const float f = __fmul_rn(__fsub_rn(p, o), inv_h);
+	int c = (int)f;
+	c = c < 0 ? 0 : c;
+	return c > n - 1 ? n - 1 : c;
+}
 // spreads the low 21 bits of v to every third bit (libmorton's 3-D encoding: x -> bit 0, y -> bit 1, z -> bit 2)
 __device__ __forceinline__ uint64_t spread3(uint64_t v)
 {

@@ -122,6 +122,8 @@ struct PairResult {
 	uint64_t region_base[NR] = { 0 }, region_cap[NR] = { 0 }, region_used[NR] = { 0 };
 	bool shared_empty = false;   // int 0 of `records` is the empty record every list without a candidate points at
 	bool dry = false;            // this pass only counts (first run of a pair: nothing is known about its size yet)
+	bool groups_off = false;     // the group formulation sent too much of this pair to its leftover kernel: cell kernels from now on
+	bool groups_now = false;     // this attempt runs the group formulation
 	DevBuf counts, offs_sorted, offs_orig, records, heavy, heavy2, filtered;
 	PinnedBuf h_offs, h_records;
 	bool mirrored = false;
@@ -867,6 +869,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	uint32_t* h_nocc = reinterpret_cast<uint32_t*>(h_words + WB * ((size_t)n_sets + 1));
 	uint32_t* h_filt = h_nocc + n_sets + 1;                             // per job: cells that passed the candidate-presence filter
 	for (size_t k = 0; k < jobs.size(); k++) h_filt[k] = 0;
+	std::vector<uint32_t> h_left(jobs.size() + 1, 0u);                  // per job: cells the group kernel passed on to the cell tiers
 	HIPCHK(c, c->pool_ctrl.reserve(tnsx::CTRL_BYTES * (jobs.size() + 1)));   // per job: cursor, hit_total, 2 x (8 tickets, n_heavy), spread out
 	auto ctrl_slot = [&](size_t k, int slot) { return c->pool_ctrl.as<uint32_t>() + (k * tnsx::CTRL_SLOTS + (size_t)slot) * tnsx::CTRL_STRIDE_U32; };
 	const int query_waves = c->n_cus * 8 * 4;
@@ -882,6 +885,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		a.table_j = B.table.as<uint2>(); a.xyzi_j = B.xyzi[B.sorted_buf].as<float4>(); a.r2_j = B.r2[B.sorted_buf].as<float>();
 		a.r2_fixed = c->radius_sq;
 		a.query_limit = A.n_query < 0 ? 0xffffffffu : (uint32_t)A.n_query;
+		a.n_points_i = (uint32_t)A.n;
 		a.g = g;
 		a.counts = pr.counts.as<uint32_t>();
 		a.offs_sorted = pr.offs_sorted.as<uint64_t>();
@@ -895,6 +899,10 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		a.n_heavy2 = ctrl_slot(k, tnsx::CTRL_NHEAVY2);
 		a.heavy = pr.heavy.as<uint2>();
 		a.heavy2 = pr.heavy2.as<uint2>();
+		// (the worklist of the group formulation shares buffer and counter with the candidate-presence filter: that one is for pairs of two
+		//  different sets, the group formulation for a set searched in itself)
+		a.heavy0 = pr.filtered.as<uint2>();
+		a.n_heavy0 = ctrl_slot(k, tnsx::CTRL_NFILTERED);
 		a.pool_slab = pr.pool_slab;
 		a.pool_slab_heavy = std::max<uint32_t>(pr.pool_slab, 8192u);
 		a.shared_empty = jb.pool && jb.i != jb.j ? 1u : 0u;
@@ -946,7 +954,14 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		const int t0 = tm.mark();
 		if (pr.n_i > 0) {
 			qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_POOL;
+			// opt-in (tnsx_options.query_formulation = 1), fixed radius, a set searched in itself: the group formulation (tnsx_query_group.hip)
+			// in front of the cell kernels, unless it was switched off for this pair
+			pr.groups_now = !variable && jb.i == jb.j && c->opt.query_formulation == 1 && !pr.groups_off && c->grid_h * c->grid_h > 1e-30f;
+			qc.groups = pr.groups_now;
+			if (pr.groups_now) HIPCHK(c, pr.filtered.reserve((size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pr.n_i, n_cells)) * sizeof(uint2)));
 			tnsx::launch_query(make_args(jb, pr, k), qc, c->n_cus, st);
+			qc.groups = false;
+			if (pr.groups_now) HIPCHK(c, hipMemcpyAsync(&h_left[k], ctrl_slot(k, tnsx::CTRL_NFILTERED), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 		}
 		const int t1 = tm.mark();
 		span(ST_FILL, t0, t1);
@@ -1138,6 +1153,13 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		S.n_neighbors += n_neighbors;
 		if (jb.pool) S.n_pool_pairs++;
 		S.n_filtered_cells += h_filt[k];
+		if (jb.pool && pr.groups_now) {
+			S.n_group_pairs++;
+			S.n_group_passed_cells += h_left[k];
+			// more than a quarter of the occupied cells passed on (dense cells, lists longer than the lanes' capacity): the cell kernels
+			// alone are the better tool for this pair
+			if ((uint64_t)h_left[k] * 4u > (uint64_t)h_nocc[jb.i] + 64u) pr.groups_off = true;
+		}
 	}
 	for (int si = 0; si < n_sets; si++) S.n_occupied_cells += h_nocc[si];
 

@@ -84,6 +84,7 @@ struct QueryArgs {
 	const uint2* table_j; const float4* xyzi_j; const float* r2_j;
 	float r2_fixed;
 	uint32_t shared_empty;  // pool pass: offs_by_orig was pre-set to 0 and records[0] == 0 is THE empty record (cells without candidates write nothing)
+	uint32_t n_points_i;    // points of set i (length of xyzi_i; group formulation)
 	uint32_t query_limit;   // only query points with original index < query_limit get lists (the rest of set i are candidates only)
 	GridParams g;
 	// count pass: counts[p] = n_neighbours + 1 (record length), by sorted position of set i
@@ -103,6 +104,7 @@ struct QueryArgs {
 	uint2* heavy;                      // worklist {first sorted position, key} of the cells the fast kernel skipped
 	uint32_t* n_heavy;                 // its length (zeroed before the launch)
 	uint32_t* tickets2; uint2* heavy2; uint32_t* n_heavy2;   // the same for the second tier (fat kernel -> general kernel)
+	uint2* heavy0; uint32_t* n_heavy0;   // group formulation (tnsx_query_group.hip): worklist of the cells it passes on to the three cell tiers (zeroed before)
 };
 // Control block of one pool pass.  Every hot counter sits CTRL_STRIDE_U32 words (4352 B) from the next: the L2 serialises
 // atomics that hit the same cache line (measured: ~88 atomics/us per line, whatever the word), and the stride also spreads
@@ -125,9 +127,14 @@ struct QueryConfig {
 	bool symmetric;  // d2 <= r_i^2 || d2 <= r_j^2 (only meaningful with variable)
 	bool self;       // set_i == set_j: exclude the point itself
 	int mode;        // QUERY_COUNT / QUERY_FILL (exact two-pass layout) / QUERY_POOL (single pass)
+	bool groups = false;   // QUERY_POOL with a fixed radius: the group formulation (tnsx_query_group.hip) instead of the three cell tiers
+	int group_waves_per_cu = 0;   // its launch width (waves per CU); 0 = default
 	int blocks_per_cu = 0, fast_blocks_per_cu = 0;   // launch widths (workgroups per CU) of the general / the fast kernels; 0 = default
 };
 void launch_query(const QueryArgs& a, const QueryConfig& c, int n_compute_units, hipStream_t s);
+// group formulation of a pool pass with a fixed radius (tnsx_query_group.hip): k_query_groups over the occupied cells, then the three cell tiers
+// over what it passed on (a.heavy0 / a.n_heavy0: at most one entry per occupied cell)
+void launch_query_groups(const QueryArgs& a, const QueryConfig& c, int n_compute_units, hipStream_t s);
 // pool pass over two different sets, candidate-presence filter: launch_mark_cells writes `value` into the byte of every grid cell
 // that has an occupied cell of set j among its 27 (value 1 before the filter, 0 afterwards: the map is all zero between uses);
 // launch_filter_marked compacts the occupied cells of set i whose byte is set into out / *n_out (zeroed before)
