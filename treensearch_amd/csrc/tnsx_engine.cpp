@@ -122,6 +122,7 @@ struct PairResult {
 	uint64_t region_base[NR] = { 0 }, region_cap[NR] = { 0 }, region_used[NR] = { 0 };
 	bool shared_empty = false;   // int 0 of `records` is the empty record every list without a candidate points at
 	bool dry = false;            // this pass only counts (first run of a pair: nothing is known about its size yet)
+	uint32_t n_cells_i = 0;      // occupied cells of set i in the previous run
 	bool groups_off = false;     // the group formulation sent too much of this pair to its leftover kernel: cell kernels from now on
 	bool groups_now = false;     // this attempt runs the group formulation
 	DevBuf counts, offs_sorted, offs_orig, records, heavy, heavy2, filtered;
@@ -1006,10 +1007,20 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			uint64_t cap;
 			// steady state: what was asked for last time + 6 % (the common region: + 6 % of everything, for what the others cannot hold);
 			// after a dry pass: the records + a quarter (the common region: a half) + a slab per wave that can get a cell
-			if (asked) cap = asked[r] + asked[r] / 16 + 1024 + (common ? expect / 16 + 4096 : 0);
+			if (asked) {
+				cap = asked[r] + asked[r] / 16 + 1024 + (common ? expect / 16 + 4096 : 0);
+				// (the common region of a small dense set: how many waves of the heavy tiers get a cell -- and open a slab of their own, to leave
+				//  it mostly empty -- is decided by the race for the tickets and moved `asked` by 17 % between two runs of a 10 000-point set;
+				//  every wave that can get a cell may open one, up to twice what was asked for last time)
+				if (common) cap += std::min<uint64_t>(std::min<uint64_t>((uint64_t)query_waves + (uint64_t)query_waves / 4, (uint64_t)std::max(pr.n_cells_i, 1u)),
+				                                      std::max<uint64_t>(asked[r] / slab_heavy, 64)) * slab_heavy;
+			}
 			else cap = payload[r] + payload[r] / (common ? 2 : 4) + 1024 + (common ? expect / 16 + waves_heavy * slab_heavy : waves_x * slab);
 			if (generous && common) cap += expect + waves_all * slab_heavy;
 			pr.region_base[r] = first; pr.region_cap[r] = cap;
+#ifdef TNSX_BUILD_DEBUG_POOL
+			fprintf(stderr, "[tnsx] size_pool region %d: payload %llu asked %lld cap %llu slab %llu n_i %d cells_prev %u\n", r, (unsigned long long)payload[r], asked ? (long long)asked[r] : -1ll, (unsigned long long)cap, (unsigned long long)slab, pr.n_i, pr.n_cells_i);
+#endif
 			first = (first + cap + 63) & ~(uint64_t)63;
 		}
 		HIPCHK(c, pr.records.reserve(first * sizeof(int)));
@@ -1153,6 +1164,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		S.n_neighbors += n_neighbors;
 		if (jb.pool) S.n_pool_pairs++;
 		S.n_filtered_cells += h_filt[k];
+		pr.n_cells_i = h_nocc[jb.i];
 		if (jb.pool && pr.groups_now) {
 			S.n_group_pairs++;
 			S.n_group_passed_cells += h_left[k];
