@@ -473,15 +473,17 @@ def main():
         extra["zsort_ms_per_step"].clear()
     sync_all()
     t0 = time.perf_counter()
+    raw_stats = []
     for k in range(args.warmup, args.warmup + args.steps):
         step(k)
-        st = ns.get_stats()
-        for key in STAGES:
-            acc[key] += st[key]
-        for key in counts:
-            counts[key] += st[key]
+        raw_stats.append(ns.get_stats_raw())          # (the struct as it is; it is read after the clock has stopped)
     sync_all()
     elapsed = time.perf_counter() - t0
+    for rs in raw_stats:
+        for key in STAGES:
+            acc[key] += getattr(rs, key)
+        for key in counts:
+            counts[key] += getattr(rs, key)
     if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

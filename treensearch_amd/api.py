@@ -387,9 +387,13 @@ class TreeNSearch:
         return int(self._L.tnsx_get_neighborlist_n_bytes(self._h))
 
     def get_stats(self) -> dict:
+        return self.get_stats_raw().as_dict()
+
+    def get_stats_raw(self) -> "Stats":
+        """the ctypes mirror of tnsx_stats itself (fields by attribute): for loops that must not spend time building a dict per step"""
         st = Stats()
         self._check(self._L.tnsx_get_stats(self._h, C.byref(st)))
-        return st.as_dict()
+        return st
 
     # ------------------------------------------------------------------ multi-GPU support
     @staticmethod

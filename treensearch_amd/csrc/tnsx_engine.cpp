@@ -787,7 +787,6 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	// ---- device words of this attempt (64-bit each): block 0 = the guard flag, block 1 + si = the partial checksums of set si
 	constexpr size_t WB = (size_t)tnsx::CHK_SLOTS * tnsx::CHK_STRIDE;   // words per block
 	HIPCHK(c, c->run_words.reserve(sizeof(uint64_t) * WB * (size_t)(n_sets + 1)));
-	HIPCHK(c, hipMemsetAsync(c->run_words.p, 0, sizeof(uint64_t) * WB * (size_t)(n_sets + 1), st));
 	unsigned long long* const d_words = c->run_words.as<unsigned long long>();
 
 	// ---- per set: cell sort -> cell table (or nothing: a set that did not change keeps what it has)
@@ -797,11 +796,22 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		if (c->n_occ.p != old) for (PointSet& s : c->sets) s.built_gen = 0;   // the occupied-cell counts of cached sets lived in the old buffer
 	}
 	std::vector<char> skipped((size_t)n_sets, 0);
-	for (int si = 0; si < n_sets; si++) {
-		PointSet& s = c->sets[si];
+	auto keeps_its_build = [&](const PointSet& s) {
 		const bool same_input = s.chk_valid && s.chk_xyz == s.user_xyz && s.chk_radii == s.user_radii && s.chk_n == s.n && s.chk_double == s.is_double;
 		const bool cacheable = !s.user_ids && s.n > 0;
-		if (speculate && cacheable && s.predicted_static && same_input && s.built_gen == c->grid_gen && s.table_state == 1) {
+		return speculate && cacheable && s.predicted_static && same_input && s.built_gen == c->grid_gen && s.table_state == 1;
+	};
+	{
+		// one launch zeroes the words of this attempt and the occupied-cell counts of the sets that are built (fill commands between kernels cost
+		// a bubble each)
+		unsigned long long built = 0;
+		for (int si = 0; si < std::min(n_sets, 64); si++) if (!keeps_its_build(c->sets[si])) built |= 1ull << si;
+		tnsx::launch_run_begin(d_words, WB * (size_t)(n_sets + 1), c->n_occ.as<uint32_t>(), built, st);
+	}
+	for (int si = 0; si < n_sets; si++) {
+		PointSet& s = c->sets[si];
+		const bool cacheable = !s.user_ids && s.n > 0;
+		if (keeps_its_build(s)) {
 			// taken to be unchanged: only its checksum is computed (and compared after the run)
 			tnsx::launch_set_checksum(s.d_xyz, variable ? s.d_radii : nullptr, s.n, d_words + WB * (size_t)(1 + si), st);
 			skipped[(size_t)si] = 1;
@@ -810,7 +820,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		}
 		// the table is needed even for empty sets (they can be searched into)
 		const int t0 = tm.mark();
-		HIPCHK(c, hipMemsetAsync(c->n_occ.as<uint32_t>() + si, 0, sizeof(uint32_t), st));
+		if (si >= 64) HIPCHK(c, hipMemsetAsync(c->n_occ.as<uint32_t>() + si, 0, sizeof(uint32_t), st));   // (the others: launch_run_begin above)
 		{
 			const void* old_table = s.table.p;
 			HIPCHK(c, s.table.reserve(n_cells * sizeof(uint2)));
@@ -924,7 +934,6 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	auto launch_pool = [&](size_t k) -> tnsx_status {
 		const Job& jb = jobs[k];
 		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
-		HIPCHK(c, hipMemsetAsync(ctrl_slot(k, 0), 0, tnsx::CTRL_BYTES, st));
 		{
 			// the region table of this pass (all capacities 0: nothing is written, everything is counted).
 			// A pair of two different sets: most query cells may have no candidate at all (a fluid searched in its boundary).  Int 0 of
@@ -933,7 +942,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			unsigned long long regions[2 * PairResult::NR];
 			const bool count_only = c->debug_nostore || pr.dry;
 			for (int r = 0; r < PairResult::NR; r++) { regions[2 * r] = pr.region_base[r]; regions[2 * r + 1] = count_only ? 0ull : pr.region_cap[r]; }
-			tnsx::launch_pool_begin(regions, reinterpret_cast<unsigned long long*>(ctrl_slot(k, tnsx::CTRL_REGIONS)), pr.offs_orig.as<uint64_t>(),
+			tnsx::launch_pool_begin(regions, ctrl_slot(k, 0), pr.offs_orig.as<uint64_t>(),
 			                        pr.shared_empty ? (size_t)pr.n_query : 0, pr.records.as<int>(), st);
 		}
 		if (pr.shared_empty) {

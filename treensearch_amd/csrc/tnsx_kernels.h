@@ -158,9 +158,12 @@ void launch_slab_ids(const long long* gids, int n, int* ids, unsigned int* flag,
 void launch_slab_flag_gt(const float* v, int n, float limit, unsigned int* flag, hipStream_t s);         // *flag = 1 if any v[i] > limit
 void launch_slab_x_range(const float* xyz, int n, float* minmax, hipStream_t s);                          // minmax[0] = min(.., x), minmax[1] = max(.., x) (NaN skipped)
 
-// ---- start of a pool pass: regions[2 * (POOL_REGIONS + 1)] = {first int, capacity} of every region -> the device table the query reads;
+// ---- start of a pool pass: the hot words of the pass's control block `ctrl` (CTRL_SLOTS slots) are zeroed and
+//      regions[2 * (POOL_REGIONS + 1)] = {first int, capacity} of every region -> the device table the query reads (slot CTRL_REGIONS);
 //      n_shared_empty > 0 (a pair of two different sets): offs[0..n) = 0 and records[0] = 0, the shared empty record at int 0 of the pool
-void launch_pool_begin(const unsigned long long* regions, unsigned long long* table, uint64_t* offs, size_t n_shared_empty, int* records, hipStream_t s);
+void launch_pool_begin(const unsigned long long* regions, uint32_t* ctrl, uint64_t* offs, size_t n_shared_empty, int* records, hipStream_t s);
+// start of a run: words[0..n_words) = 0 (guard flag, partial checksums) and n_occ[si] = 0 for every set si whose bit is set in `sets` (si < 64)
+void launch_run_begin(unsigned long long* words, size_t n_words, uint32_t* n_occ, unsigned long long sets, hipStream_t s);
 
 // ---- ascending order inside every record of the first n_query points (tnsx_options.sorted_lists), in place
 void launch_sort_records(int* records, const uint64_t* offs_by_orig, int n_query, int n_cus, hipStream_t s);

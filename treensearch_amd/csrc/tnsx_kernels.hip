@@ -457,9 +457,20 @@ void launch_translate_records(int* records, const uint64_t* offs_by_orig, int n_
 // (int 0 of the pool, count 0) -- one launch instead of a copy and three memsets
 // =====================================================================================================
 struct PoolRegionTable { unsigned long long v[2 * (POOL_REGIONS + 1)]; };
-__global__ void __launch_bounds__(256) k_pool_begin(PoolRegionTable t, unsigned long long* __restrict__ table, uint64_t* __restrict__ offs, size_t n, int* __restrict__ records)
+__global__ void __launch_bounds__(256) k_pool_begin(PoolRegionTable t, uint32_t* __restrict__ ctrl, uint64_t* __restrict__ offs, size_t n, int* __restrict__ records)
 {
-	if (blockIdx.x == 0 && threadIdx.x < 2 * (POOL_REGIONS + 1)) table[threadIdx.x] = t.v[threadIdx.x];
+	if (blockIdx.x == 0) {
+		// the control block of the pass: the hot words of every slot (cursor + neighbour / waste counters: 18 64-bit words; ticket counters and
+		// worklist lengths: the first word) start at zero -- 141 x 144 bytes instead of a memset of the whole 600 KB block, and no fill
+		// command (with the bubble it brings) between the build and the query
+		if (threadIdx.x < CTRL_SLOTS) {
+			uint32_t* slot = ctrl + (size_t)threadIdx.x * CTRL_STRIDE_U32;
+			for (int w = 0; w < 2 * POOL_CTRL_WORDS; w++) slot[w] = 0u;
+		}
+		__syncthreads();
+		unsigned long long* table = reinterpret_cast<unsigned long long*>(ctrl + (size_t)CTRL_REGIONS * CTRL_STRIDE_U32);
+		if (threadIdx.x < 2 * (POOL_REGIONS + 1)) table[threadIdx.x] = t.v[threadIdx.x];
+	}
 	if (n == 0) return;
 	if (blockIdx.x == 0 && threadIdx.x == 0) records[0] = 0;
 	ulonglong2* o2 = reinterpret_cast<ulonglong2*>(offs);
@@ -467,13 +478,27 @@ __global__ void __launch_bounds__(256) k_pool_begin(PoolRegionTable t, unsigned 
 	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) o2[i] = make_ulonglong2(0ull, 0ull);
 	if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) offs[n - 1] = 0ull;
 }
-void launch_pool_begin(const unsigned long long* regions, unsigned long long* table, uint64_t* offs, size_t n_shared_empty, int* records, hipStream_t s)
+void launch_pool_begin(const unsigned long long* regions, uint32_t* ctrl, uint64_t* offs, size_t n_shared_empty, int* records, hipStream_t s)
 {
+	static_assert(CTRL_SLOTS <= 256, "one thread per slot");
 	PoolRegionTable t;
 	for (int k = 0; k < 2 * (POOL_REGIONS + 1); k++) t.v[k] = regions[k];
 	size_t blocks = (n_shared_empty / 2 + 256 * 8 - 1) / (256 * 8);
 	blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
-	hipLaunchKernelGGL(k_pool_begin, dim3((unsigned)blocks), dim3(256), 0, s, t, table, offs, n_shared_empty, records);
+	hipLaunchKernelGGL(k_pool_begin, dim3((unsigned)blocks), dim3(256), 0, s, t, ctrl, offs, n_shared_empty, records);
+}
+
+// start of a run: the words the build kernels add to (guard flag, partial checksums: `words`, 64-bit) and the occupied-cell counts of the sets
+// that are built in this run (bit si of `sets`; at most 64 sets) start at zero -- one launch instead of one fill command per buffer
+__global__ void __launch_bounds__(256) k_run_begin(unsigned long long* __restrict__ words, size_t n_words, uint32_t* __restrict__ n_occ, unsigned long long sets)
+{
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (size_t)gridDim.x * 256) words[i] = 0ull;
+	if (blockIdx.x == 0 && threadIdx.x < 64 && ((sets >> threadIdx.x) & 1ull)) n_occ[threadIdx.x] = 0u;
+}
+void launch_run_begin(unsigned long long* words, size_t n_words, uint32_t* n_occ, unsigned long long sets, hipStream_t s)
+{
+	const unsigned blocks = (unsigned)std::min<size_t>(64, (n_words + 255) / 256 + 1);
+	hipLaunchKernelGGL(k_run_begin, dim3(blocks), dim3(256), 0, s, words, n_words, n_occ, sets);
 }
 
 // =====================================================================================================
