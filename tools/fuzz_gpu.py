@@ -81,7 +81,7 @@ while time.time() < t_end:
     pairs = [(i, j) for i in range(n_sets) for j in range(n_sets) if rng.random() < 0.6] or [(0, 0)]
     # bucket_build_min_points: 1 = the two-pass bucket build for every set whose key fits (round 3), -1 = never, 0 = the default threshold
     opts_a = dict(arith=arith, sorted_lists=bool(rng.random() < 0.3), temporal_reuse=bool(rng.random() < 0.8),
-                  bucket_build_min_points=int(rng.choice([1, 1, 0, -1])))
+                  bucket_build_min_points=int(rng.choice([1, 1, 0, -1])), query_formulation=int(rng.random() < 0.5))
     A = T.TreeNSearch(**opts_a, devices=[0] * args.devices) if args.devices > 1 else T.TreeNSearch(**opts_a)
     B = T.TreeNSearch(arith=arith, exact_layout=True, temporal_reuse=False)
     pts, rad = [], []
