@@ -874,13 +874,18 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	std::vector<Job> jobs;
 	for (int i = 0; i < n_sets; i++) for (int j = 0; j < n_sets; j++) if (c->active[i][j]) jobs.push_back({ i, j, false });
 	constexpr size_t HC = (size_t)PairResult::NR * tnsx::POOL_CTRL_WORDS;   // per job: cursor / neighbours / unused ints of every pool region (exact layout: word 0 = total)
-	HIPCHK(c, c->h_small.reserve(sizeof(uint64_t) * (HC * jobs.size() + 2 + WB * ((size_t)n_sets + 1)) + sizeof(uint32_t) * (size_t)(n_sets + 1 + jobs.size() + 1) + 64));
+	HIPCHK(c, c->h_small.reserve(sizeof(uint64_t) * (HC * jobs.size() + 2 + WB * ((size_t)n_sets + 1)) + sizeof(uint32_t) * (size_t)(n_sets + 1 + 2 * (jobs.size() + 1)) + 64));
 	uint64_t* h_ctrl = c->h_small.as<uint64_t>();
 	uint64_t* h_words = h_ctrl + HC * jobs.size() + 2;                  // guard flag, partial checksums
 	uint32_t* h_nocc = reinterpret_cast<uint32_t*>(h_words + WB * ((size_t)n_sets + 1));
 	uint32_t* h_filt = h_nocc + n_sets + 1;                             // per job: cells that passed the candidate-presence filter
 	for (size_t k = 0; k < jobs.size(); k++) h_filt[k] = 0;
-	std::vector<uint32_t> h_left(jobs.size() + 1, 0u);                  // per job: cells the group kernel passed on to the cell tiers
+	uint32_t* h_left = h_filt + jobs.size() + 1;                        // per job: cells the group kernel passed on to the cell tiers
+	for (size_t k = 0; k < jobs.size(); k++) h_left[k] = 0;
+	// the words of the pool passes go to the host with the ONE kernel at the end of the attempt (launch_run_end); the repeat of a pass that
+	// overflowed, and attempts with more pool passes than that kernel takes, copy them pass by pass
+	tnsx::RunEndArgs run_end{};
+	bool defer_readback = true;
 	HIPCHK(c, c->pool_ctrl.reserve(tnsx::CTRL_BYTES * (jobs.size() + 1)));   // per job: cursor, hit_total, 2 x (8 tickets, n_heavy), spread out
 	auto ctrl_slot = [&](size_t k, int slot) { return c->pool_ctrl.as<uint32_t>() + (k * tnsx::CTRL_SLOTS + (size_t)slot) * tnsx::CTRL_STRIDE_U32; };
 	const int query_waves = c->n_cus * 8 * 4;
@@ -971,13 +976,19 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			if (pr.groups_now) HIPCHK(c, pr.filtered.reserve((size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pr.n_i, n_cells)) * sizeof(uint2)));
 			tnsx::launch_query(make_args(jb, pr, k), qc, c->n_cus, st);
 			qc.groups = false;
-			if (pr.groups_now) HIPCHK(c, hipMemcpyAsync(&h_left[k], ctrl_slot(k, tnsx::CTRL_NFILTERED), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 		}
 		const int t1 = tm.mark();
 		span(ST_FILL, t0, t1);
+		uint32_t* const h_count = pr.shared_empty ? h_filt + k : (pr.groups_now && pr.n_i > 0 ? h_left + k : nullptr);   // (the two worklists share a counter, see make_args)
+		if (defer_readback && run_end.n_jobs < tnsx::RUN_END_MAX_JOBS) {
+			tnsx::RunEndJob& rj = run_end.job[run_end.n_jobs++];
+			rj.ctrl_cursor = ctrl_slot(k, tnsx::CTRL_CURSOR); rj.h_ctrl = reinterpret_cast<unsigned long long*>(h_ctrl + HC * k);
+			rj.d_count = ctrl_slot(k, tnsx::CTRL_NFILTERED); rj.h_count = h_count;
+			return TNSX_OK;
+		}
 		HIPCHK(c, hipMemcpy2DAsync(h_ctrl + HC * k, tnsx::POOL_CTRL_WORDS * sizeof(uint64_t), ctrl_slot(k, tnsx::CTRL_CURSOR), tnsx::CTRL_STRIDE_U32 * sizeof(uint32_t),
 		                           tnsx::POOL_CTRL_WORDS * sizeof(uint64_t), PairResult::NR, hipMemcpyDeviceToHost, st));
-		if (pr.shared_empty) HIPCHK(c, hipMemcpyAsync(h_filt + k, ctrl_slot(k, tnsx::CTRL_NFILTERED), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+		if (h_count) HIPCHK(c, hipMemcpyAsync(h_count, ctrl_slot(k, tnsx::CTRL_NFILTERED), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 		return TNSX_OK;
 	};
 
@@ -1073,8 +1084,10 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			span(ST_COUNT, t0, t1); span(ST_SCAN, t1, t2);
 		}
 	}
-	HIPCHK(c, hipMemcpyAsync(h_nocc, c->n_occ.p, sizeof(uint32_t) * (size_t)std::max(n_sets, 1), hipMemcpyDeviceToHost, st));
-	HIPCHK(c, hipMemcpyAsync(h_words, c->run_words.p, sizeof(uint64_t) * WB * (size_t)(n_sets + 1), hipMemcpyDeviceToHost, st));
+	run_end.n_occ = c->n_occ.as<uint32_t>(); run_end.h_nocc = h_nocc; run_end.n_sets = n_sets;
+	run_end.words = d_words; run_end.h_words = reinterpret_cast<unsigned long long*>(h_words); run_end.n_words = WB * (size_t)(n_sets + 1);
+	tnsx::launch_run_end(run_end, st);
+	defer_readback = false;
 	HIPCHK(c, hipStreamSynchronize(st));   // record totals / pool cursors / what was speculated on are needed on the host
 
 	// ---- were the assumptions of this attempt right?

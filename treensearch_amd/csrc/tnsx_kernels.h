@@ -165,6 +165,13 @@ void launch_pool_begin(const unsigned long long* regions, uint32_t* ctrl, uint64
 // start of a run: words[0..n_words) = 0 (guard flag, partial checksums) and n_occ[si] = 0 for every set si whose bit is set in `sets` (si < 64)
 void launch_run_begin(unsigned long long* words, size_t n_words, uint32_t* n_occ, unsigned long long sets, hipStream_t s);
 
+// ---- end of a run: what the host reads after its one synchronisation, written into pinned host memory by one kernel (h_* are host pointers
+//      of hipHostMalloc'ed memory; d_count / h_count may be nullptr)
+static constexpr int RUN_END_MAX_JOBS = 8;
+struct RunEndJob { const uint32_t* ctrl_cursor; unsigned long long* h_ctrl; const uint32_t* d_count; uint32_t* h_count; };
+struct RunEndArgs { RunEndJob job[RUN_END_MAX_JOBS]; int n_jobs; const uint32_t* n_occ; uint32_t* h_nocc; int n_sets; const unsigned long long* words; unsigned long long* h_words; size_t n_words; };
+void launch_run_end(const RunEndArgs& a, hipStream_t s);
+
 // ---- ascending order inside every record of the first n_query points (tnsx_options.sorted_lists), in place
 void launch_sort_records(int* records, const uint64_t* offs_by_orig, int n_query, int n_cus, hipStream_t s);
 

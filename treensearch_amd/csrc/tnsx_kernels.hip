@@ -488,6 +488,28 @@ void launch_pool_begin(const unsigned long long* regions, uint32_t* ctrl, uint64
 	hipLaunchKernelGGL(k_pool_begin, dim3((unsigned)blocks), dim3(256), 0, s, t, ctrl, offs, n_shared_empty, records);
 }
 
+// end of a run: everything the host needs to judge it -- per pool pass the cursor / neighbour / waste words of every region and the length of its
+// candidate-presence (or group) worklist, the occupied-cell counts, the guard and checksum words -- goes straight into pinned host memory from ONE
+// small kernel (three copy commands with the bubbles between them were ~30 us of a 2 ms run)
+__global__ void __launch_bounds__(256) k_run_end(RunEndArgs a)
+{
+	const uint32_t tid = threadIdx.x;
+	for (int j = 0; j < a.n_jobs; j++) {
+		const RunEndJob& jb = a.job[j];
+		for (uint32_t t = tid; t < (uint32_t)((POOL_REGIONS + 1) * POOL_CTRL_WORDS); t += 256u) {
+			const uint32_t r = t / (uint32_t)POOL_CTRL_WORDS, w = t % (uint32_t)POOL_CTRL_WORDS;
+			jb.h_ctrl[t] = reinterpret_cast<const unsigned long long*>(jb.ctrl_cursor + (size_t)r * CTRL_STRIDE_U32)[w];
+		}
+		if (tid == 0 && jb.h_count) *jb.h_count = *jb.d_count;
+	}
+	for (uint32_t t = tid; t < (uint32_t)a.n_sets; t += 256u) a.h_nocc[t] = a.n_occ[t];
+	for (size_t t = tid; t < a.n_words; t += 256u) a.h_words[t] = a.words[t];
+}
+void launch_run_end(const RunEndArgs& a, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_run_end, dim3(1), dim3(256), 0, s, a);
+}
+
 // start of a run: the words the build kernels add to (guard flag, partial checksums: `words`, 64-bit) and the occupied-cell counts of the sets
 // that are built in this run (bit si of `sets`; at most 64 sets) start at zero -- one launch instead of one fill command per buffer
 __global__ void __launch_bounds__(256) k_run_begin(unsigned long long* __restrict__ words, size_t n_words, uint32_t* __restrict__ n_occ, unsigned long long sets)
