@@ -796,6 +796,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		if (c->n_occ.p != old) for (PointSet& s : c->sets) s.built_gen = 0;   // the occupied-cell counts of cached sets lived in the old buffer
 	}
 	std::vector<char> skipped((size_t)n_sets, 0);
+	int t_first = -1;   // the event in front of k_run_begin: start of the first built set's stages
 	auto keeps_its_build = [&](const PointSet& s) {
 		const bool same_input = s.chk_valid && s.chk_xyz == s.user_xyz && s.chk_radii == s.user_radii && s.chk_n == s.n && s.chk_double == s.is_double;
 		const bool cacheable = !s.user_ids && s.n > 0;
@@ -804,6 +805,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	{
 		// one launch zeroes the words of this attempt and the occupied-cell counts of the sets that are built (fill commands between kernels cost
 		// a bubble each)
+		t_first = tm.mark();   // (in front of the launch: every event record between two kernels costs a bubble of 6-9 us)
 		unsigned long long built = 0;
 		for (int si = 0; si < std::min(n_sets, 64); si++) if (!keeps_its_build(c->sets[si])) built |= 1ull << si;
 		tnsx::launch_run_begin(d_words, WB * (size_t)(n_sets + 1), c->n_occ.as<uint32_t>(), built, st);
@@ -819,7 +821,8 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			continue;
 		}
 		// the table is needed even for empty sets (they can be searched into)
-		const int t0 = tm.mark();
+		const int t0 = t_first >= 0 ? t_first : tm.mark();
+		t_first = -1;
 		if (si >= 64) HIPCHK(c, hipMemsetAsync(c->n_occ.as<uint32_t>() + si, 0, sizeof(uint32_t), st));   // (the others: launch_run_begin above)
 		{
 			const void* old_table = s.table.p;
@@ -939,6 +942,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	auto launch_pool = [&](size_t k) -> tnsx_status {
 		const Job& jb = jobs[k];
 		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
+		const int t0 = tm.mark();   // (in front of k_pool_begin, next to the event that ends the build: one bubble instead of two)
 		{
 			// the region table of this pass (all capacities 0: nothing is written, everything is counted).
 			// A pair of two different sets: most query cells may have no candidate at all (a fluid searched in its boundary).  Int 0 of
@@ -966,7 +970,6 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 				tnsx::launch_mark_cells(B.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.j, g, map, 0, max_cells_j, st);
 			}
 		}
-		const int t0 = tm.mark();
 		if (pr.n_i > 0) {
 			qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_POOL;
 			// opt-in (tnsx_options.query_formulation = 1), fixed radius, a set searched in itself: the group formulation (tnsx_query_group.hip)
