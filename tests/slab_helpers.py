@@ -64,7 +64,7 @@ class LocalTransport:
     """Moves the messages of SlabExchange between the emulated ranks of one process: a FIFO per (source, destination).  The
     receiver's buffer must have exactly the shape of the message -- that IS the agreement the wire protocol promises."""
 
-    def __init__(self, world: int, timeout: float = 120.0):
+    def __init__(self, world: int, timeout: float = 400.0):   # (generous: on a box whose host is busy with other jobs a step of the 1 M-point dam break has been seen to take > 120 s)
         import queue
         import threading
         self.q = {(s, d): queue.Queue() for s in range(world) for d in range(world) if abs(s - d) == 1}
