@@ -99,11 +99,23 @@ def run_slabs_in_threads(world, make_slab, step_fn, n_steps=2):
     tr = LocalTransport(world)
     slabs, errors = [None] * world, []
 
+    import time
+    times = [[] for _ in range(world)]     # per rank: (step, seconds, engine stats of the step) -- evidence when a step stalls
+
     def work(k):
         try:
             slabs[k] = make_slab(k, tr)
             for s in range(n_steps):
-                step_fn(k, slabs[k], s)
+                t0 = time.perf_counter()
+                try:
+                    step_fn(k, slabs[k], s)
+                finally:
+                    try:
+                        st = slabs[k].engine.get_stats()
+                        brief = {key: st[key] for key in ("ms_total", "pool_retries", "cold_passes", "speculation_redos", "grid_trimmed", "n_neighbors")}
+                    except Exception:   # noqa: BLE001
+                        brief = None
+                    times[k].append((s, round(time.perf_counter() - t0, 2), brief))
         except BaseException as e:   # noqa: BLE001 - reported to the main thread
             errors.append((k, e))
 
@@ -113,7 +125,7 @@ def run_slabs_in_threads(world, make_slab, step_fn, n_steps=2):
     for t in threads:
         t.join()
     if errors:
-        raise errors[0][1]
+        raise RuntimeError(f"rank {errors[0][0]} failed: {errors[0][1]!r}; all errors: {[(k, repr(e)) for k, e in errors]}; step times per rank: {times}") from errors[0][1]
     return slabs
 
 
