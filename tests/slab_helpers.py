@@ -116,6 +116,9 @@ def run_slabs_in_threads(world, make_slab, step_fn, n_steps=2):
                     except Exception:   # noqa: BLE001
                         brief = None
                     times[k].append((s, round(time.perf_counter() - t0, 2), brief))
+                    if times[k][-1][1] > 30.0:
+                        import warnings
+                        warnings.warn(f"slab rank {k} step {s} took {times[k][-1][1]} s: {brief}")
         except BaseException as e:   # noqa: BLE001 - reported to the main thread
             errors.append((k, e))
 

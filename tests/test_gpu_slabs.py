@@ -54,6 +54,13 @@ def _run_slabs(case, world, n_steps=2, speculative=True, shrink_caps_before_step
     max_r = float(rad_h.max()) if variable else float(case.radius)
     halo = max_r * 1.001
     d_all = torch.from_numpy(pts_h).cuda()
+    # The torch kernels the slab step uses, once, HERE: on a fresh box the first launch of a torch kernel family pages its code in from the
+    # image, which has been seen to take minutes -- inside a step that is a rank that keeps the others waiting at the transport's barrier.
+    _w = torch.rand(1024, device="cuda")
+    _flag = (_w.max() > 2.0) | (_w.min() > 2.0)
+    _i = torch.arange(1024, device="cuda", dtype=torch.int64)
+    _j = torch.empty(1024, dtype=torch.int32, device="cuda"); _j.copy_(_i)
+    assert not bool(_flag.item())
     dec = SlabDecomposition(engine=_engine_factory())
     cuts = dec.balanced_cuts([d_all], plane_width=halo * 1.001, n_slabs=world)
     owner = SlabDecomposition.owner_of(d_all[:, 0], cuts).cpu().numpy()
