@@ -329,7 +329,8 @@ def _pair_moments(offs, idx):
         return np.sum(a[nz] * sb, dtype=np.uint64), np.sum(b[nz] * sa, dtype=np.uint64)
 
 
-@pytest.mark.parametrize("n", [1_000_000, 4_000_000])   # (the 10 M cloud is checked against the reference itself above)
+@pytest.mark.parametrize("n", [1_000_000])   # (the 10 M cloud is checked against the reference itself above, 20 M / 50 M / 200 M clouds through the same properties on the
+                                            #  device in tests/test_gpu_fullsize.py; a 4 M instance of this host-side check took 117 s of the suite's budget)
 def test_full_size_properties_symmetry_idempotence_self_exclusion(n):
     """Fixed radius, one set: (i, j) is a pair <=> (j, i) is (the fp32 predicate is symmetric under negation of the
     difference vector); no point is its own neighbour; list entries are distinct; a second run() returns the same sets."""
