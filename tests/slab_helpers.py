@@ -123,10 +123,15 @@ def run_slabs_in_threads(world, make_slab, step_fn, n_steps=2):
             errors.append((k, e))
 
     threads = [threading.Thread(target=work, args=(k,)) for k in range(world)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    import faulthandler
+    faulthandler.dump_traceback_later(40, repeat=True)      # a stalled step: where every thread is, every 40 s (stderr; visible with -s or on failure)
+    try:
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        faulthandler.cancel_dump_traceback_later()
     if errors:
         raise RuntimeError(f"rank {errors[0][0]} failed: {errors[0][1]!r}; all errors: {[(k, repr(e)) for k, e in errors]}; step times per rank: {times}") from errors[0][1]
     return slabs
