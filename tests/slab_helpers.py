@@ -1,6 +1,8 @@
 """Test infrastructure of the slab tests: a TreeNSearch-shaped stand-in backed by the CPU oracle (the product has no CPU search
 path, so the gloo tests of treensearch_amd/multi.py inject this as their per-rank search backend) and the single-process truth
 the unions of the slabs are compared with."""
+import os
+
 import numpy as np
 
 
@@ -112,7 +114,7 @@ def run_slabs_in_threads(world, make_slab, step_fn, n_steps=2):
                 finally:
                     try:
                         st = slabs[k].engine.get_stats()
-                        brief = {key: st[key] for key in ("ms_total", "pool_retries", "cold_passes", "speculation_redos", "grid_trimmed", "n_neighbors")}
+                        brief = {key: st[key] for key in ("ms_total", "ms_fill", "ms_sort", "ms_bounds", "pool_retries", "cold_passes", "speculation_redos", "grid_trimmed", "n_neighbors", "grid_dims", "n_occupied_cells")}
                     except Exception:   # noqa: BLE001
                         brief = None
                     times[k].append((s, round(time.perf_counter() - t0, 2), brief))
@@ -132,6 +134,8 @@ def run_slabs_in_threads(world, make_slab, step_fn, n_steps=2):
             t.join()
     finally:
         faulthandler.cancel_dump_traceback_later()
+    if os.environ.get("TNSX_TEST_VERBOSE"):
+        print("slab step times per rank:", times, flush=True)
     if errors:
         raise RuntimeError(f"rank {errors[0][0]} failed: {errors[0][1]!r}; all errors: {[(k, repr(e)) for k, e in errors]}; step times per rank: {times}") from errors[0][1]
     return slabs

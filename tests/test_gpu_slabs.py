@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 def _engine_factory():
     import torch
     import treensearch_amd as T
-    return T.TreeNSearch(stream=torch.cuda.current_stream().cuda_stream)
+    return T.TreeNSearch(stream=torch.cuda.current_stream().cuda_stream, collect_stage_times=bool(os.environ.get("TNSX_TEST_VERBOSE")))
 
 
 def _single_device(case):
@@ -199,6 +199,42 @@ def test_query_count_point_ids_and_nan_points(oracle):
     ns.run()
     offs, idx = ns.neighbor_csr(s, s)
     assert np.array_equal(offs, ro) and np.array_equal(idx, ri)
+
+
+def test_nan_points_count_for_nothing_whatever_else_they_hold(oracle):
+    """The rows of a ghost message past the real count become NaN-x points whose y, z and radius are whatever the buffer held.  They must not
+    widen the bounds, raise the radius the cells are cut for (a stale radius there once made the grid of a slab 5 x too coarse: exact, and 100 x
+    slower) or trip the guards of a reused grid -- in the first run (fresh bounds) and in the following ones (speculated grid) alike."""
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    n = 40000
+    pts = D.uniform_cloud(n, 77)
+    r0 = D.radius_for_neighbors(n, 20.0)
+    rng = np.random.default_rng(5)
+    radii = (r0 * (1.0 + rng.random(n))).astype(np.float32)
+    junk = pts.copy(); junk_r = radii.copy()
+    absent = np.arange(n - 700, n)
+    junk[absent, 0] = np.nan
+    junk[absent, 1] = 1.0e4 * rng.standard_normal(len(absent)).astype(np.float32)     # far outside the cloud
+    junk[absent[::3], 2] = np.float32(np.inf)
+    junk[absent[1::3], 2] = np.float32(np.nan)
+    junk_r[absent] = np.float32(50.0) * r0                                            # far above every real radius
+    ref = T.TreeNSearch()
+    ref.add_point_set(pts[:n - 700].copy(), radii[:n - 700].copy()); ref.set_active_search(0, 0, True); ref.set_symmetric_search(True)
+    ref.run()
+    want, dims = ref.neighbor_csr(0, 0), ref.get_stats()["grid_dims"]
+    ns = T.TreeNSearch()
+    d_pts, d_r = torch.from_numpy(junk).cuda(), torch.from_numpy(junk_r).cuda()
+    s = ns.add_point_set(d_pts, d_r); ns.set_active_search(s, s, True); ns.set_symmetric_search(True)
+    ns.set_query_count(s, n - 700)
+    for step in range(3):
+        ns.run()
+        st = ns.get_stats()
+        assert list(st["grid_dims"]) == list(dims), f"step {step}: the grid follows the real points only"
+        assert st["speculation_redos"] == 0 and (step == 0 or st["speculated"] == 1)
+        got = ns.neighbor_csr(s, s)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
 
 
 def test_translate_neighbors_kernel(oracle):

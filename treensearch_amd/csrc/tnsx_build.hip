@@ -125,12 +125,15 @@ __global__ void __launch_bounds__(CS_THREADS) k_cs_hist(const float* __restrict_
 				if (!MORTON) {
 					if (gd.flag) {
 						// v_min / v_max drop a NaN operand: a NaN x ("no point") never counts, NaN in y or z is caught below
+						// (a NaN x is NO POINT: whatever its y and z hold -- the rows of a ghost message past the real count -- counts for nothing)
+						const bool pt = q.x == q.x;
+						const float qy = pt ? q.y : q.x, qz = pt ? q.z : q.x;
 						mn[0] = fminf(mn[0], q.x); mx[0] = fmaxf(mx[0], q.x);
-						mn[1] = fminf(mn[1], q.y); mx[1] = fmaxf(mx[1], q.y);
-						mn[2] = fminf(mn[2], q.z); mx[2] = fmaxf(mx[2], q.z);
-						bad |= (q.y != q.y) | (q.z != q.z);
-						if (gd.outside) n_outside += (q.x < gd.soft_lo[0]) | (q.x > gd.soft_hi[0]) | (q.y < gd.soft_lo[1]) | (q.y > gd.soft_hi[1]) |
-						                             (q.z < gd.soft_lo[2]) | (q.z > gd.soft_hi[2]);
+						mn[1] = fminf(mn[1], qy); mx[1] = fmaxf(mx[1], qy);
+						mn[2] = fminf(mn[2], qz); mx[2] = fmaxf(mx[2], qz);
+						bad |= pt & ((q.y != q.y) | (q.z != q.z));
+						if (gd.outside) n_outside += pt & ((q.x < gd.soft_lo[0]) | (q.x > gd.soft_hi[0]) | (q.y < gd.soft_lo[1]) | (q.y > gd.soft_hi[1]) |
+						                                   (q.z < gd.soft_lo[2]) | (q.z > gd.soft_hi[2]));
 					}
 					if (gd.checksum) chk += point_hash((uint32_t)e, q.x, q.y, q.z, radii ? radii[e] : 0.0f);
 				}
@@ -246,7 +249,7 @@ k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, con
 		if (FIRST) {
 			const F3 q = (reinterpret_cast<const F3*>(xyz) + lbase)[lc];
 			px[i] = q.x; py[i] = q.y; pz[i] = q.z; pw[i] = __uint_as_float((uint32_t)wbase + li);
-			if (VARIABLE) { const float r = (radii + lbase)[lc]; rr[i] = __fmul_rn(r, r); bad_r |= r > gd.r_max; }   // single pass: index = position
+			if (VARIABLE) { const float r = (radii + lbase)[lc]; rr[i] = __fmul_rn(r, r); bad_r |= (r > gd.r_max) & (q.x == q.x); }   // single pass: index = position; the radius of a NaN x (no point) counts for nothing
 		}
 		else {
 			const float4 q = (xyzi_in + lbase)[lc];
@@ -256,7 +259,7 @@ k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, con
 	if (VARIABLE && !FIRST) {
 		// gather by original index (the radii array of a 50 M-point set is 200 MB: it stays in the 256 MB Infinity Cache)
 		#pragma unroll
-		for (int i = 0; i < CS_ITEMS; i++) { const float r = radii[__float_as_uint(pw[i])]; rr[i] = __fmul_rn(r, r); bad_r |= r > gd.r_max; }
+		for (int i = 0; i < CS_ITEMS; i++) { const float r = radii[__float_as_uint(pw[i])]; rr[i] = __fmul_rn(r, r); bad_r |= (r > gd.r_max) & (px[i] == px[i]); }
 	}
 	// (speculated grid: a radius above the one the cell edge was chosen for -> the host repeats the run with fresh bounds)
 	if (VARIABLE && gd.flag && __builtin_amdgcn_ballot_w64(bad_r) != 0ull && lane == 0) atomicOr(gd.flag, 1u);
@@ -597,7 +600,7 @@ __global__ void __launch_bounds__(BS_THREADS) k_bucket_sort(const float4* __rest
 		float wv = q.w;
 		if (ids) { wv = __int_as_float(ids[o]); orig_out[pos] = o; }   // (tnsx_set_point_ids: the point carries its id from here on)
 		out[pos] = make_float4(q.x, q.y, q.z, wv);
-		if (VARIABLE) { r2_out[pos] = __fmul_rn(r, r); bad_r |= r > gd.r_max; }
+		if (VARIABLE) { r2_out[pos] = __fmul_rn(r, r); bad_r |= (r > gd.r_max) & (q.x == q.x); }
 	};
 	{
 		// gather of the radii by original index (the radii array of a 50 M-point set is 200 MB: it stays in the 256 MB Infinity Cache)

@@ -73,7 +73,11 @@ __global__ void __launch_bounds__(BOUNDS_THREADS) k_bounds_partial(const float* 
                                                                    float* __restrict__ partials)
 {
 	float v[8] = { FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX, FLT_MAX, -FLT_MAX };
+	// (fminf / fmaxf drop a NaN operand.  A NaN x is NO POINT -- the rows of a ghost message past the real count -- and then its y, z and radius,
+	//  whatever they hold, count for nothing either: a stale radius there once made the cells five times too wide)
 	auto take = [&](float x, float y, float z) {
+		const bool pt = x == x;
+		y = pt ? y : x; z = pt ? z : x;
 		v[0] = fminf(v[0], x); v[1] = fminf(v[1], y); v[2] = fminf(v[2], z);
 		v[3] = fmaxf(v[3], x); v[4] = fmaxf(v[4], y); v[5] = fmaxf(v[5], z);
 	};
@@ -91,7 +95,7 @@ __global__ void __launch_bounds__(BOUNDS_THREADS) k_bounds_partial(const float* 
 	}
 	for (int i = first_scalar + t0; i < n; i += stride) take(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]);
 	if (radii) {
-		for (int i = t0; i < n; i += stride) { const float r = radii[i]; v[6] = fminf(v[6], r); v[7] = fmaxf(v[7], r); }
+		for (int i = t0; i < n; i += stride) { const float x = xyz[3 * (size_t)i]; const float r = x == x ? radii[i] : x; v[6] = fminf(v[6], r); v[7] = fmaxf(v[7], r); }
 	}
 	block_reduce_write8(v, partials + 8 * (size_t)blockIdx.x);
 }
