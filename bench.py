@@ -109,7 +109,7 @@ def _pmc_pass(argv_workload, counters, tmp):
     env = dict(os.environ, TMPDIR="/tmp", TNSX_BENCH_INNER="1")
     d = os.path.join(tmp, "_".join(counters)[:60])
     cmd = [exe, "--pmc"] + list(counters) + ["--kernel-include-regex", QUERY_KERNEL, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
-           sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--no-pmc"] + argv_workload
+           sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--no-pmc", "--no-stage-pass"] + argv_workload
     subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420, check=False)
     vals = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -118,6 +118,44 @@ def _pmc_pass(argv_workload, counters, tmp):
                 vals.setdefault(r["Counter_Name"], {}).setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
     # the first tier (FAT = false) is the kernel with the largest mean
     return {c: max(sum(v) / len(v) for v in per_kernel.values()) for c, per_kernel in vals.items()}
+
+
+def kernel_trace_pass(argv_workload):
+    """one rocprofv3 --kernel-trace run of THIS script (3 warm-up + 10 timed steps, no events in the loop) -> what the trace says about the steady
+    state: average duration of the first query tier, and how much of a step's period its kernels fill.  A step starts at every k_run_begin."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or os.environ.get("TNSX_BENCH_NO_PMC") == "1":
+        return None
+    tmp = tempfile.mkdtemp(prefix="tnsx_kt_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp", TNSX_BENCH_INNER="1")
+        cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "kt", "--",
+               sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-pmc", "--no-stage-pass"] + argv_workload
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420, check=False)
+        rows = []
+        for f in glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+        rows.sort()
+        starts = [i for i, r in enumerate(rows) if "k_run_begin" in r[2]]
+        if len(starts) < 6:
+            return {"note": "kernel trace produced no steps"}
+        steps = [(rows[a:b], rows[b][0]) for a, b in zip(starts[:-1], starts[1:])]
+        pure = [(st, nxt) for st, nxt in steps if all("tnsx::" in r[2] for r in st)]           # (c2 / c3: a step holds engine kernels only)
+        steps = (pure or steps)[-8:]                                                              # steady state: the last steps
+        q = [e - s0 for st, _ in steps for s0, e, n in st if QUERY_KERNEL in n]
+        first_tier = [d for d in q if d > 0.5 * max(q)] if q else []
+        ker = sum(e - s0 for st, _ in steps for s0, e, _ in st)
+        period = sum(nxt - st[0][0] for st, nxt in steps)
+        return {"kernel_us": round(sum(first_tier) / max(len(first_tier), 1) / 1e3, 2), "launches_seen": len(first_tier),
+                "kernels_per_step": round(sum(len(st) for st, _ in steps) / len(steps), 1),
+                "sum_kernel_us_per_step": round(ker / len(steps) / 1e3, 1), "period_us": round(period / len(steps) / 1e3, 1),
+                "kernel_time_over_period": round(ker / period, 4) if period else None,
+                "source": "rocprofv3 --kernel-trace of this script started by this bench run (10 steps, the last 8 evaluated)"}
+    except Exception as e:  # pragma: no cover
+        return {"note": f"kernel-trace pass failed: {e}"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def pmc_traffic(argv_workload, with_ceilings=False):
@@ -260,6 +298,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
     ap.add_argument("--slab-backend", choices=["abi", "torch"], default="abi", help="c5: who moves the halos -- libtnsx.so itself (tnsx_slab_step over RCCL, default) "
                     "or treensearch_amd/multi.py over torch.distributed")
+    ap.add_argument("--no-stage-pass", action="store_true", help="skip the extra steps with hipEvents around every stage (stage_ms and the roofline's launch time are then 0)")
     ap.add_argument("--no-secondary", action="store_true", help="c2 only: do not append the reduced runs of c3 and c4 (`secondary`)")
     ap.add_argument("--exact-layout", action="store_true", help="two-pass count/scan/fill result layout instead of the single pass")
     ap.add_argument("--static-input", action="store_true", help="do not move the points between steps (the engine then reuses everything it may)")
@@ -280,7 +319,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     workload = args.workload or ("c5" if args.gpus > 1 else "c2")
     if args.zsort_input is None:
-        args.zsort_input = workload == "c5"
+        # c2 / c5: z-order, the protocol of the reference's own benchmark (tests/tests.cpp:254-256: prepare_zsort + apply_zsort, then time run())
+        # and what the cpu_baseline leg is given; the same cloud in the order it was generated in is timed beside it (`random_order_input`)
+        args.zsort_input = workload in ("c2", "c5")
     # TNSX_BENCH_FORCE_SLAB=1: exercise the process-group path with a single rank (a 1-GPU box can check it)
     distributed = world > 1 or (os.environ.get("TNSX_BENCH_FORCE_SLAB") == "1" and "RANK" in os.environ)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU path)"
@@ -297,7 +338,9 @@ def main():
     torch.cuda.set_stream(stream)
 
     def make_engine():
-        return T.TreeNSearch(arith=arith, stream=stream.cuda_stream, collect_stage_times=True, exact_layout=args.exact_layout)
+        # no hipEvents around the stages in the timed loop (each record between two kernels is a bubble of 6-10 us: 22 us of a 2 ms step in round 3);
+        # the stage times come from extra steps after it (stage_pass)
+        return T.TreeNSearch(arith=arith, stream=stream.cuda_stream, collect_stage_times=False, exact_layout=args.exact_layout)
 
     def osc(base: "torch.Tensor", amp: float, seed: int):
         """two copies of the positions, base +- d with |d_k| <= amp / sqrt(3) per coordinate: step k uses copy k % 2"""
@@ -328,6 +371,7 @@ def main():
         n = points_total or 10_000_000
         radius = D.radius_for_neighbors(n)
         base = torch.from_numpy(D.uniform_cloud(n, args.seed)).cuda()
+        base_unsorted = base.clone() if args.zsort_input else None
         zsorted(base, radius)
         copies = osc(base, 0.1 * float(radius), 1)
         ns = make_engine()
@@ -340,12 +384,16 @@ def main():
             ns.resize_point_set(0, copies[k % 2])
             ns.run()
 
-        def zsorted_variant():
-            """the same cloud handed over in z-order (how an SPH code that calls zsort every so many steps holds it)"""
-            zb = base.clone()
-            zsorted(zb, radius, force=True)
+        def other_order_variant():
+            """the same cloud in the other input order: z-order (how an SPH code that calls zsort every so many steps holds it) when the main line
+            ran on the points as generated, and vice versa"""
+            if args.zsort_input:
+                zb = base_unsorted
+            else:
+                zb = base.clone()
+                zsorted(zb, radius, force=True)
             zc = osc(zb, 0.1 * float(radius), 1)
-            for k in range(3):
+            for k in range(4):
                 ns.resize_point_set(0, zc[k % 2]); ns.run()
             torch.cuda.synchronize()
             t_z = time.perf_counter()
@@ -353,8 +401,7 @@ def main():
                 ns.resize_point_set(0, zc[k % 2]); ns.run()
             torch.cuda.synchronize()
             return (time.perf_counter() - t_z) / 10 * 1e3
-        if not args.zsort_input:
-            extra["_zsorted_variant"] = zsorted_variant
+        extra["_other_order_variant"] = other_order_variant
         desc = (f"{n} uniform-random points in a unit cube, single set, fixed radius r={float(radius):.6f}, BASELINE.json configs[1]")
     elif workload == "c3":
         n = points_total or 10_000_000
@@ -404,7 +451,7 @@ def main():
         desc = (f"{n}-point SPH dam break (70 % dense column, 25 % floor layer, 5 % spray), per-point radii r0*(1+u) with r0={float(r0):.6f}, "
                 f"symmetric search; every step: perturb <= 0.1 r0, prepare_zsort, apply_zsort(xyz), apply_zsort(radii), run; BASELINE.json configs[3]")
     else:   # c5
-        from treensearch_amd.multi import SlabDecomposition, SlabSearch, SlabSearchC, SlabTransportC, balanced_cuts_c
+        from treensearch_amd.multi import SlabDecomposition, SlabSearch, SlabSearchC, SlabTransportC, balanced_cuts_c, redistribute_c
         n_total = points_total or 200_000_000
         radius = D.radius_for_neighbors(n_total)
         lo_i, hi_i = (n_total * rank) // world, (n_total * (rank + 1)) // world            # generated: a contiguous index range per rank
@@ -423,10 +470,12 @@ def main():
         dec = SlabDecomposition(engine=make_engine())
         t_dec = time.perf_counter()
         if backend == "abi":
+            # decomposition entirely behind the C ABI: cuts (two all-reduces) and the all-to-all that moves every point to its owner
             cuts = balanced_cuts_c(dec.engine, transport, rank, world, [mine], float(radius) * 1.15)
+            owned, owned_gids = redistribute_c(dec.engine, transport, rank, world, cuts, mine, gids)
         else:
             cuts = dec.balanced_cuts([mine], plane_width=float(radius) * 1.15)
-        owned, owned_gids, _ = dec.redistribute(mine, gids, None, cuts)
+            owned, owned_gids, _ = dec.redistribute(mine, gids, None, cuts)
         torch.cuda.synchronize()
         extra["decomposition_s"] = round(time.perf_counter() - t_dec, 3)
         del mine, gids, dec
@@ -437,6 +486,7 @@ def main():
         if backend == "abi":
             ns = make_engine()
             slab = SlabSearchC(float(cuts[rank]), float(cuts[rank + 1]), float(radius), ns, transport, rank, world, halo_margin=0.11)
+            slab.set_watchdog(60.0)      # a step that does not complete in a minute fails with a message naming the link (instead of hanging the job)
             extra["slab_backend"] = "C ABI: tnsx_slab_step (" + ("RCCL ncclSend / ncclRecv issued by libtnsx.so" if transport is not None else "one slab, no exchange") + ")"
         else:
             slab = SlabSearch(float(cuts[rank]), float(cuts[rank + 1]), float(radius), make_engine, halo_margin=0.11)
@@ -459,16 +509,32 @@ def main():
         torch.cuda.synchronize()
 
     # ------------------------------------------------------------------------------------------------ timing
+    # the streaming ceiling of THIS box first (every rank; best of its rounds): it is needed for the line anyway, and measured here it also
+    # takes the GPU out of its idle clocks before the first step instead of after the last
+    peak = measured_copy_peak(torch) if os.environ.get("TNSX_BENCH_INNER") != "1" else None
     sync_all()
     t0 = time.perf_counter()
     step(0)                                           # the cold run: allocations, the dry (count-only) pass of every pair, first grid
     torch.cuda.synchronize()
     cold_ms = (time.perf_counter() - t0) * 1e3
     cold_stats = ns.get_stats()
-    for k in range(1, args.warmup):
-        step(k)
     acc = {k: 0.0 for k in STAGES}
-    counts = {"pool_retries": 0, "speculation_redos": 0, "speculated": 0, "n_cached_sets": 0}
+    # ---- stage pass: steps with hipEvents around every stage (on the engine's stream; the query's bracket holds its kernels only), BEFORE the timed
+    #      loop: the stage times of the roofline come from here, the timed loop itself records no events
+    stage_steps = 0 if args.no_stage_pass else min(max(args.steps, 1), 10)
+    if stage_steps:
+        ns.set_collect_stage_times(True)
+        step(1)                                           # (the first run with events creates them)
+        for k in range(2, 2 + stage_steps):
+            step(k)
+            rs = ns.get_stats_raw()
+            for key in STAGES:
+                acc[key] += getattr(rs, key)
+        ns.set_collect_stage_times(False)
+        torch.cuda.synchronize()
+    for k in range(args.warmup):                          # W untimed warm-up steps, then exactly K timed ones
+        step(k)
+    counts = {"pool_retries": 0, "speculation_redos": 0, "speculated": 0, "n_cached_sets": 0, "heavy_catchups": 0, "one_read_builds": 0}
     if "zsort_ms_per_step" in extra:
         extra["zsort_ms_per_step"].clear()
     sync_all()
@@ -480,8 +546,6 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     for rs in raw_stats:
-        for key in STAGES:
-            acc[key] += getattr(rs, key)
         for key in counts:
             counts[key] += getattr(rs, key)
     if distributed:
@@ -503,10 +567,10 @@ def main():
     pooled = st.get("n_pool_pairs", 0) > 0
     n_launches = max(st.get("n_pool_pairs", 0), 1)
     fill_bytes = 16 * n_pts + 4 * (E + Q) + 8 * Q + (0 if pooled else 8 * Q)
-    fill_ms = acc["ms_fill"] / steps
+    fill_ms = acc["ms_fill"] / max(stage_steps, 1)
     achieved = fill_bytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0
     run_bytes = st["bytes_build"] + st["bytes_query"]
-    dev_ms = acc["ms_total"] / steps
+    dev_ms = ms_per_step                                  # the whole run: the step as the wall clock saw it (no events inside)
     out = {
         "metric": "Mpoints/sec neighbor build+query", "value": round(value, 3), "unit": "Mpoints/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -520,25 +584,33 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_detail": None,
                      "bytes_per_launch": int(fill_bytes // n_launches), "avg_launch_ms": round(fill_ms / n_launches, 4), "launches_per_step": n_launches,
                      "whole_run": {"algorithmic_bytes": int(run_bytes), "bytes_per_point": round(run_bytes / max(n_pts, 1), 1),
-                                   "device_ms": round(dev_ms, 4),
+                                   "ms": round(dev_ms, 4),
                                    "achieved_gbs": round(run_bytes / (dev_ms * 1e-3) / 1e9, 1) if dev_ms > 0 else 0.0,
                                    "frac": round(run_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dev_ms > 0 else 0.0}},
-        "stage_ms": {k[3:]: round(v / steps, 4) for k, v in acc.items()},
+        "stage_ms": {k[3:]: round(v / max(stage_steps, 1), 4) for k, v in acc.items()},
+        "stage_pass": {"steps": stage_steps, "note": "stage_ms and roofline.avg_launch_ms: hipEvent brackets on the engine's stream, collected in extra steps between "
+                                                     "the cold run and the warm-up steps (the timed loop records no events); roofline.kernel_trace: rocprofv3's view "
+                                                     "of the same kernels"},
         "steady_state": {"runs_that_reused_the_grid": counts["speculated"], "runs_repeated_after_a_failed_assumption": counts["speculation_redos"],
-                         "pool_retries": counts["pool_retries"], "cached_set_builds_skipped": counts["n_cached_sets"]},
+                         "pool_retries": counts["pool_retries"], "cached_set_builds_skipped": counts["n_cached_sets"],
+                         "heavy_tiers_launched_after_the_sync": counts["heavy_catchups"], "one_read_bucket_passes": counts["one_read_builds"]},
         "cold_run": {"ms": round(cold_ms, 3), "dry_passes": cold_stats["cold_passes"],
                      "note": "first step of the process: allocations + one count-only pass per pair + the sized pass"},
     }
     if "zsort_ms_per_step" in extra and extra["zsort_ms_per_step"]:
         out["stage_ms"]["zsort_prepare_and_apply"] = round(float(np.mean(extra["zsort_ms_per_step"])), 4)
     if rank == 0:
-        if os.environ.get("TNSX_BENCH_INNER") != "1" and os.environ.get("TNSX_BENCH_SECONDARY") != "1" and "_zsorted_variant" in extra:
-            z_ms = extra.pop("_zsorted_variant")()
-            out["zsorted_input"] = {"ms_per_step": round(z_ms, 4), "value": round(n_total / z_ms / 1e3, 1), "unit": "Mpoints/s",
-                                    "note": "same cloud, handed over in z-order (prepare_zsort + apply_zsort once, outside the timing): the order the "
-                                            "reference's users keep their particles in and the order the cpu_baseline leg is given; 10 steps after the main timing"}
-        if os.environ.get("TNSX_BENCH_INNER") != "1":
-            peak = measured_copy_peak(torch)
+        if os.environ.get("TNSX_BENCH_INNER") != "1" and os.environ.get("TNSX_BENCH_SECONDARY") != "1" and "_other_order_variant" in extra:
+            z_ms = extra.pop("_other_order_variant")()
+            if args.zsort_input:
+                out["random_order_input"] = {"ms_per_step": round(z_ms, 4), "value": round(n_total / z_ms / 1e3, 1), "unit": "Mpoints/s",
+                                             "note": "same cloud in the order it was generated in (random): the harder case for the build (scattered 16-byte stores of "
+                                                     "the bucket pass, scattered offset stores of the query); the main line of rounds 1-3; 10 steps after the main timing"}
+            else:
+                out["zsorted_input"] = {"ms_per_step": round(z_ms, 4), "value": round(n_total / z_ms / 1e3, 1), "unit": "Mpoints/s",
+                                        "note": "same cloud, handed over in z-order (prepare_zsort + apply_zsort once, outside the timing): the order the "
+                                                "reference's users keep their particles in and the order the cpu_baseline leg is given; 10 steps after the main timing"}
+        if peak is not None:
             out["roofline"]["peak_measured"] = peak
             out["roofline"]["frac_of_measured"] = round(achieved / peak, 4) if peak > 0 else None
             out["roofline"]["whole_run"]["frac_of_measured"] = round(out["roofline"]["whole_run"]["achieved_gbs"] / peak, 4) if peak > 0 else None
@@ -561,6 +633,7 @@ def main():
             out["roofline"]["traffic_detail"] = detail
             if main_run:
                 out["roofline"]["secondary_ceilings"] = secondary_ceilings(insts, fill_ms / n_launches, Q)
+            out["roofline"]["kernel_trace"] = kernel_trace_pass(wl_args)
         if (world == 1 and workload == "c2" and not args.points and not args.no_secondary and not args.no_pmc and not args.static_input
                 and os.environ.get("TNSX_BENCH_SECONDARY") != "1" and os.environ.get("TNSX_BENCH_INNER") != "1"):
             # the other single-GPU configs of BASELINE.json next to the headline one (c4 at a fifth of its size: its 50 M-point

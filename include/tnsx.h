@@ -40,7 +40,8 @@ typedef enum tnsx_status {
 	TNSX_ERR_CONFIG = 4,       /* _check() failures, TreeNSearch.cpp:366-392 */
 	TNSX_ERR_GRID_TOO_LARGE = 5, /* > 32768 cells per dimension, TreeNSearch.cpp:510-515 */
 	TNSX_ERR_LIST_TOO_LONG = 6,
-	TNSX_ERR_STATE = 7         /* e.g. view requested before run(), pair inactive */
+	TNSX_ERR_STATE = 7,        /* e.g. view requested before run(), pair inactive */
+	TNSX_ERR_TIMEOUT = 8       /* slab layer watchdog: the stream did not drain in time (a mismatched or stuck exchange) */
 } tnsx_status;
 
 /* Distance arithmetic (both are bit-exact restatements of a reference build):
@@ -156,6 +157,9 @@ typedef struct tnsx_stats {
 	uint32_t n_group_pairs;       /* pairs of the last run that ran the group formulation */
 	uint32_t n_group_passed_cells; /* occupied cells it passed on to the cell kernels (too many candidates or query points, a list overflow, a point
 	                                 far outside its cell), summed over those pairs */
+	int one_read_builds;          /* point sets whose bucket build read the input once in the last run (windows from the previous run) */
+	int heavy_catchups;           /* pool passes whose heavy tiers (cells with > 512 candidates or > 64 query points) were not launched with the first
+	                                 tier -- the previous run of the pair had no such cell -- and had to run after the run's synchronisation */
 } tnsx_stats;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */
@@ -179,6 +183,8 @@ tnsx_status tnsx_set_active_search(tnsx_context* ctx, int set_i, int set_j, int 
 tnsx_status tnsx_set_active_search_all(tnsx_context* ctx, int set_i, int search_in_all, int be_found_by_all); /* :223-232 */
 tnsx_status tnsx_set_all_searches(tnsx_context* ctx, int active);        /* TreeNSearch.cpp:233-240 */
 tnsx_status tnsx_set_arithmetic(tnsx_context* ctx, int arith);           /* tnsx_arith */
+tnsx_status tnsx_set_collect_stage_times(tnsx_context* ctx, int on);     /* tnsx_options.collect_stage_times from the next run on (every event record
+                                                                            between two kernels costs a bubble of 6-9 us: off in timed loops) */
 
 /* ---- getters (TreeNSearch.cpp:191-218) ---------------------------------------------------------- */
 int         tnsx_get_n_sets(const tnsx_context* ctx);
@@ -271,6 +277,8 @@ typedef struct tnsx_slab_transport {
 	int (*exchange)(void* user, int rank, int world, const tnsx_slab_op* ops, int n_ops, void* stream);   /* all ops of one round, 0 = ok */
 	int (*allreduce)(void* user, int rank, int world, void* dev_buf, int count, int op, void* stream);    /* in place, 32-bit elements */
 	void (*release)(void* user);
+	void (*abort)(void* user);   /* may be NULL.  Called by the watchdog when an exchange did not complete in time: must make the pending operations of
+	                                this rank return (RCCL: ncclCommAbort), so that the process can report the error and leave instead of hanging */
 } tnsx_slab_transport;
 typedef struct tnsx_slab_info {
 	int n_owned, n_ghost;        /* set 0 of the last step */
@@ -300,10 +308,27 @@ tnsx_status tnsx_slab_balanced_cuts(tnsx_context* engine, const tnsx_slab_transp
 /* radius > 0: fixed search radius of all sets (set on the engine here); radius <= 0: per-point radii, max_radius must bound every
  * radius of every rank (it sizes the halo; checked on the owned radii at every step).  halo_margin: the halo is
  * max_radius * (1 + halo_margin) wide (<= 0: 1e-3).  transport may be NULL when world == 1. */
+/* The one all-to-all of a decomposition (SURVEY.md section 8e "Exchange"): every point moves to the slab that owns its x, slab k owning
+ * cuts[k] <= x < cuts[k + 1] (cuts[0 .. world] as tnsx_slab_balanced_cuts writes them; world <= 64).  Collective, two rounds over the transport's
+ * exchange (the counts, then the rows [x, y, z, (r,) gid] between every pair of ranks; a rank's own share is a device copy).
+ * _begin: xyz / gids / radii (radii may be NULL) are this rank's n_points points in device memory; *n_owned = the points this rank owns afterwards.
+ * _finish: writes them to caller-allocated device arrays of n_owned points (order unspecified) and frees the handle; NULL outputs: just free. */
+typedef struct tnsx_slab_redist tnsx_slab_redist;
+tnsx_status tnsx_slab_redistribute_begin(tnsx_context* engine, const tnsx_slab_transport* transport, int rank, int world, const float* cuts,
+                                         const float* xyz, const long long* gids, const float* radii, int n_points, tnsx_slab_redist** out, int* n_owned);
+tnsx_status tnsx_slab_redistribute_finish(tnsx_slab_redist* r, float* xyz_out, long long* gids_out, float* radii_out);
+
+/* A slab with two neighbours must be at least one halo wide (ghosts come from the adjacent slabs only): TNSX_ERR_INVALID otherwise.
+ * Creation errors are described by tnsx_slab_last_error(NULL).  The engine must outlive the slab: tnsx_slab_destroy turns the engine's sets that
+ * point into the slab's buffers into empty sets before it frees them. */
 tnsx_status tnsx_slab_create(tnsx_context* engine, const tnsx_slab_transport* transport, int rank, int world, float slab_lo, float slab_hi,
                              float radius, float max_radius, float halo_margin, int speculative, tnsx_slab** out);
 void        tnsx_slab_destroy(tnsx_slab* slab);
-const char* tnsx_slab_last_error(const tnsx_slab* slab);
+const char* tnsx_slab_last_error(const tnsx_slab* slab /* NULL: the last creation / decomposition error of this thread */);
+/* Watchdog: every wait of tnsx_slab_step on the stream (the exchange, the search behind it) is bounded by `seconds` (default 120; <= 0: wait for
+ * ever).  When it expires the step names the link(s) it was waiting on in tnsx_slab_last_error, calls the transport's abort and returns
+ * TNSX_ERR_TIMEOUT -- a mismatched exchange on 8 GPUs fails with a message instead of hanging the job. */
+tnsx_status tnsx_slab_set_watchdog(tnsx_slab* slab, double seconds);
 /* searches between the slab's sets (indices as in tnsx_slab_step); default: set 0 in itself */
 tnsx_status tnsx_slab_set_active_search(tnsx_slab* slab, int set_i, int set_j, int active);
 /* One step: exchange + search.  Per set k: xyz[k] (n_points[k] x 3 floats), gids[k] (global ids, must fit 31 bits: they become the

@@ -178,3 +178,119 @@ def test_zsort_between_runs_invalidates_cached_structures(oracle):
         if step == 3:
             assert ns.get_stats()["n_cached_sets"] == 0
         P.assert_same_csr(ns.neighbor_csr(0, 0), ref, f"step {step}")
+
+
+def test_one_read_bucket_pass_and_its_overflow(oracle):
+    """Round 4: in a steady-state step the bucket build reads the input ONCE -- every bucket has a window of the intermediate array sized from
+    the previous run's count, tiles reserve their piece with one atomic per bucket.  (a) jittered points: the one-read pass runs, nothing is
+    repeated, lists exact; (b) the same number of points inside the same box, but mirrored so that every bucket's population changes: windows
+    overflow, the device raises the guard, the attempt is thrown away unseen (its sorted arrays have holes: the query kernels must not touch
+    them) and repeated with the histogram pass -- lists exact; (c) the step after that reads once again."""
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    n = 300000
+    rng = np.random.default_rng(11)
+    # a cloud that is dense at the bottom and thin at the top (z is the slowest axis of the cell key: a bucket is a few x-rows of one z-layer),
+    # with fixed corner points that pin the bounding box
+    z = rng.random(n, dtype=np.float32) ** np.float32(3.0)
+    pts = np.stack([rng.random(n, dtype=np.float32), rng.random(n, dtype=np.float32), z], axis=1).astype(np.float32)
+    pts[0] = (0.0, 0.0, 0.0)
+    pts[1] = (1.0, 1.0, 1.0)
+    r = np.float32(0.02)
+    d = torch.from_numpy(pts).cuda()
+    ns = T.TreeNSearch()
+    ns.set_search_radius(r)
+    ns.add_point_set(d)
+    ns.set_active_search(0, 0, True)
+
+    def run_and_check(tag):
+        ns.run()
+        P.assert_same_csr(ns.neighbor_csr(0, 0), oracle.pair_search(pts, pts, radius=r, same_set=True), tag)
+        return ns.get_stats()
+    st = run_and_check("first run")
+    assert st["one_read_builds"] == 0 and st["radix_passes"] == 2, "the first run has no windows yet: histogram pass"
+    for k in range(2):
+        pts[2:] += (rng.random((n - 2, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(0.1) * r
+        np.clip(pts, 0.0, 1.0, out=pts)
+        d.copy_(torch.from_numpy(pts))
+        st = run_and_check(f"jitter {k}")
+        assert st["one_read_builds"] == 1 and st["speculated"] == 1 and st["speculation_redos"] == 0, st
+    pts[:, 2] = np.float32(1.0) - pts[:, 2]            # mirror in z: same box, same n, every bucket's count changes
+    d.copy_(torch.from_numpy(pts))
+    st = run_and_check("mirrored")
+    assert st["speculation_redos"] == 1 and st["speculated"] == 0 and st["one_read_builds"] == 0, f"the overflow must be noticed and the run repeated: {st}"
+    pts[2:] += (rng.random((n - 2, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(0.1) * r
+    np.clip(pts, 0.0, 1.0, out=pts)
+    d.copy_(torch.from_numpy(pts))
+    st = run_and_check("after the repair")
+    assert st["one_read_builds"] == 1 and st["speculation_redos"] == 0
+
+
+def test_one_read_bucket_pass_leaves_nan_points_out(oracle):
+    """The layout of a slab's set: n owned points (they get lists), then candidates-only rows of which a varying number are real and the rest
+    NaN-x padding (no points).  The one-read pass drops the NaN rows instead of letting them overflow the window of the bucket behind the last
+    cell -- no repeated runs although their number changes every step -- and the lists of the owned points are exact."""
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    n, tail = 200000, 20000
+    allp = D.uniform_cloud(n + tail, 77)
+    r = D.radius_for_neighbors(n, 30.0)
+    d = torch.empty((n + tail, 3), dtype=torch.float32, device="cuda")
+    ns = T.TreeNSearch()
+    ns.set_search_radius(r)
+    ns.add_point_set(d)
+    ns.set_query_count(0, n)
+    ns.set_active_search(0, 0, True)
+    rng = np.random.default_rng(5)
+    for step, g in enumerate([tail, tail, 15000, 2000, 19900]):     # real rows in the tail; the others are NaN
+        cur = allp.copy()
+        if step:
+            cur += (rng.random(cur.shape, dtype=np.float32) - np.float32(0.5)) * np.float32(0.05) * r
+            np.clip(cur, 0.0, 1.0, out=cur)
+        cur[0] = (0.0, 0.0, 0.0); cur[1] = (1.0, 1.0, 1.0)
+        cur[n + g:, 0] = np.nan
+        cur[n + g:, 1:] = rng.random((tail - g, 2), dtype=np.float32) * np.float32(1e6)      # junk behind a NaN x counts for nothing
+        d.copy_(torch.from_numpy(cur))
+        ns.run()
+        st = ns.get_stats()
+        offs, idx = ns.neighbor_csr(0, 0)
+        ro, ri = oracle.pair_search(cur[:n + g], cur[:n + g], radius=r, same_set=True)
+        assert len(offs) == n + 1
+        P.assert_same_csr((offs, idx), (ro[:n + 1], ri[:ro[n]]), f"step {step}")
+        if step >= 2:
+            assert st["one_read_builds"] == 1 and st["speculation_redos"] == 0, f"step {step}: {st}"
+
+
+def test_heavy_tiers_are_launched_after_the_sync_when_needed(oracle):
+    """Round 4: the two heavy tiers of a pool pass (cells with more than 512 candidates or more than 64 query points) are not launched when the
+    previous run of the pair had no such cell; what the first tier passes on is counted, and when that is not zero they run after the run's
+    synchronisation (tnsx_stats.heavy_catchups).  A uniform cloud (nothing heavy), then a clump appears inside the same box."""
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    n = 120000
+    pts = D.uniform_cloud(n, 9)
+    pts[0] = (0.0, 0.0, 0.0); pts[1] = (1.0, 1.0, 1.0)
+    r = D.radius_for_neighbors(n, 30.0)
+    d = torch.from_numpy(pts).cuda()
+    ns = T.TreeNSearch()
+    ns.set_search_radius(r)
+    ns.add_point_set(d)
+    ns.set_active_search(0, 0, True)
+    for k in range(2):
+        ns.run()
+        assert ns.get_stats()["heavy_catchups"] == 0
+    P.assert_same_csr(ns.neighbor_csr(0, 0), oracle.pair_search(pts, pts, radius=r, same_set=True), "uniform")
+    rng = np.random.default_rng(2)
+    clump = np.float32(0.5) + (rng.random((3000, 3), dtype=np.float32) - np.float32(0.5)) * r      # 3000 points inside one cell edge
+    pts[1000:4000] = clump
+    d.copy_(torch.from_numpy(pts))
+    ns.run()
+    st = ns.get_stats()
+    assert st["heavy_catchups"] == 1 and st["speculation_redos"] == 0, st
+    P.assert_same_csr(ns.neighbor_csr(0, 0), oracle.pair_search(pts, pts, radius=r, same_set=True), "with a clump")
+    ns.run()
+    assert ns.get_stats()["heavy_catchups"] == 0, "the run after it launches the heavy tiers with the first"
+    P.assert_same_csr(ns.neighbor_csr(0, 0), oracle.pair_search(pts, pts, radius=r, same_set=True), "with a clump, again")

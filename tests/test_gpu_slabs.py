@@ -311,12 +311,14 @@ def test_halo_pack_asymmetric_capacities():
 # in-process transport (tnsx_slab_transport_local: a thread per slab, one GPU); on several GPUs the same code runs over
 # tnsx_slab_transport_rccl (ncclSend / ncclRecv).
 # ======================================================================================================================
-def _run_slabs_c(case, world, n_steps=2, speculative=True, shrink_link_before_step=None, shrink_link=None, sets=None, active=None):
-    """sets: [(points, radii or None)] of the WHOLE cloud (default: set 0 of the case); -> ({(i, j): union csr}, log, slabs' sizes)"""
+def _run_slabs_c(case, world, n_steps=2, speculative=True, shrink_link_before_step=None, shrink_link=None, sets=None, active=None, redistribute=False):
+    """sets: [(points, radii or None)] of the WHOLE cloud (default: set 0 of the case); -> ({(i, j): union csr}, log, slabs' sizes).
+    redistribute: every emulated rank starts with an equal INDEX share of every set and the points reach their owners through
+    tnsx_slab_redistribute_begin / _finish (the all-to-all of the decomposition) instead of being picked on the host."""
     import threading
     import torch
     import treensearch_amd as T
-    from treensearch_amd.multi import SlabSearchC, SlabTransportC, balanced_cuts_c
+    from treensearch_amd.multi import SlabSearchC, SlabTransportC, balanced_cuts_c, redistribute_c
     if sets is None:
         sets = [(case.points[0], case.radii[0] if case.radii is not None else None)]
     active = active or [(0, 0)]
@@ -344,6 +346,16 @@ def _run_slabs_c(case, world, n_steps=2, speculative=True, shrink_link_before_st
             mine = []
             for (p_h, r_h), d in zip(sets, d_sets):
                 own = np.nonzero((p_h[:, 0] >= cuts[k]) & (p_h[:, 0] < cuts[k + 1]))[0]
+                if redistribute:
+                    lo_i, hi_i = (len(p_h) * k) // world, (len(p_h) * (k + 1)) // world
+                    g_share = torch.arange(lo_i, hi_i, dtype=torch.int64, device="cuda")
+                    r_share = torch.from_numpy(np.ascontiguousarray(r_h[lo_i:hi_i])).cuda() if r_h is not None else None
+                    got = redistribute_c(eng, tr, k, world, cuts, d[lo_i:hi_i].contiguous(), g_share, r_share)
+                    g_own = got[1].cpu().numpy()
+                    assert np.array_equal(np.sort(g_own), own), f"rank {k}: the redistribution delivered other points than the cuts assign"
+                    assert np.array_equal(got[0].cpu().numpy(), p_h[g_own]) and (r_h is None or np.array_equal(got[2].cpu().numpy(), r_h[g_own])), "rows garbled on the way"
+                    mine.append((got[0], got[1], got[2] if r_h is not None else None, g_own))
+                    continue
                 mine.append((torch.from_numpy(np.ascontiguousarray(p_h[own])).cuda(), torch.from_numpy(own.astype(np.int64)).cuda(),
                              torch.from_numpy(np.ascontiguousarray(r_h[own])).cuda() if r_h is not None else None, own))
             owned[k] = mine
@@ -442,6 +454,147 @@ def test_c_abi_two_sets_asymmetric_searches(oracle):
         assert int(g_offs[-1]) == fx["total"]
     for k in range(3):
         assert log[k][1] == (True, False, 1)
+
+
+def test_c_abi_redistribute_then_search(uniform_2m, oracle):
+    """the all-to-all of the decomposition behind the C ABI (tnsx_slab_redistribute_begin / _finish): four ranks that start with index shares
+    of the 2 M-point cloud end up with exactly the points their slabs own, rows intact; the union of their searches is the reference's digest"""
+    case, single = uniform_2m
+    unions, log, sizes, _ = _run_slabs_c(case, 4, redistribute=True)
+    _check_union(case, unions[(0, 0)], single, oracle)
+    assert sum(sizes) == len(case.points[0])
+
+
+def test_c_abi_redistribute_with_radii_and_two_sets(oracle):
+    """the same with per-point radii (six-float rows, unequal cuts) in three slabs"""
+    case = CS.by_name("dam_break_sym_1000000")
+    single = _single_device(case)
+    unions, _, sizes, _ = _run_slabs_c(case, 3, redistribute=True)
+    _check_union(case, unions[(0, 0)], single, oracle)
+    assert sum(sizes) == len(case.points[0])
+
+
+def test_c_abi_thin_interior_slab_is_refused():
+    """ghosts come from the two adjacent slabs only, so a slab with two neighbours that is thinner than the halo would silently
+    lose pairs between its neighbours -- tnsx_slab_create refuses it and says why; edge slabs may be as thin as they like."""
+    import ctypes as C
+    import treensearch_amd as T
+    from treensearch_amd.multi import SlabSearchC, SlabTransportC
+    group = SlabTransportC.local_group(3)
+    try:
+        eng = T.TreeNSearch()
+        tr = SlabTransportC.local(group, 1)
+        with pytest.raises(RuntimeError, match="thinner than the halo"):
+            SlabSearchC(0.50, 0.505, 0.01, eng, tr, 1, 3)
+        tr.release()
+        tr0 = SlabTransportC.local(group, 0)
+        s0 = SlabSearchC(-np.inf, 0.001, 0.01, eng, tr0, 0, 3)     # an edge slab: fine
+        del s0
+        tr0.release()
+    finally:
+        SlabTransportC.local_group_release(group)
+
+
+def test_c_abi_watchdog_names_the_link_instead_of_hanging():
+    """A step whose exchange never completes (here: a transport that parks a multi-second kernel on the stream, standing in for a neighbour that
+    never posts its side) returns TNSX_ERR_TIMEOUT after the watchdog's bound with the link in the message; the engine and the process live on."""
+    import ctypes as C
+    import time
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import api as A
+    from treensearch_amd.multi import SlabSearchC, SlabTransportC
+    stalled = []
+    # (the spin kernel counts ticks of a clock whose rate differs between devices: calibrate it)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); torch.cuda._sleep(10_000_000); torch.cuda.synchronize()
+    ticks_per_s = 10_000_000 / max(time.perf_counter() - t0, 1e-6)
+
+    def exchange(user, rk, wd, ops, n_ops, stream):
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+            torch.cuda._sleep(int(ticks_per_s * 4.0))      # ~4 s of spinning on the engine's stream
+        stalled.append(n_ops)
+        return 0
+    EX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(A.SlabOp), C.c_int, C.c_void_p)
+    cb = EX(exchange)
+    tr = SlabTransportC()
+    tr.t.user, tr.t.exchange, tr.t.allreduce, tr.t.release, tr.t.abort = None, C.cast(cb, C.c_void_p), None, None, None
+    tr.kind = "host"
+    eng = T.TreeNSearch()
+    slab = SlabSearchC(-np.inf, 0.5, 0.05, eng, tr, 0, 2)
+    slab.set_watchdog(1.0)
+    pts = torch.rand(20000, 3, device="cuda") * 0.5
+    gid = torch.arange(20000, dtype=torch.int64, device="cuda")
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError) as ei:
+        slab.step(pts, gid)
+    dt = time.perf_counter() - t0
+    assert "slab layer error 8" in str(ei.value) and "link 0 <-> 1" in str(ei.value) and "did not drain" in str(ei.value), str(ei.value)
+    assert 0.9 < dt < 4.0, f"the watchdog should fire after ~1 s, took {dt:.2f} s"
+    assert stalled, "the stand-in exchange was never called"
+    torch.cuda.synchronize()                                # the parked kernel ends; nothing is left hanging
+    del slab
+
+
+def _mp_worker(rank, world, port, case_name, out_dir):
+    """one PROCESS per rank (all on GPU 0): torch.distributed over gloo carries the slab layer's messages (SlabTransportC.host_staged)"""
+    import torch
+    import torch.distributed as dist
+    import treensearch_amd as T
+    from treensearch_amd.multi import SlabSearchC, SlabTransportC, balanced_cuts_c, redistribute_c
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    case = CS.by_name(case_name)
+    p_h = case.points[0]
+    n = len(p_h)
+    lo_i, hi_i = (n * rank) // world, (n * (rank + 1)) // world
+    eng = T.TreeNSearch()
+    tr = SlabTransportC.host_staged(rank, world)
+    share = torch.from_numpy(np.ascontiguousarray(p_h[lo_i:hi_i])).cuda()
+    cuts = balanced_cuts_c(eng, tr, rank, world, [share], float(case.radius) * 1.002)
+    pts, gids = redistribute_c(eng, tr, rank, world, cuts, share, torch.arange(lo_i, hi_i, dtype=torch.int64, device="cuda"))
+    slab = SlabSearchC(float(cuts[rank]), float(cuts[rank + 1]), float(case.radius), eng, tr, rank, world)
+    slab.set_watchdog(60.0)
+    log = []
+    for _ in range(3):
+        slab.step(pts, gids)
+        inf = slab.info()
+        log.append((int(inf.speculative_last), int(inf.redone_last), int(inf.rounds_last)))
+    offs, idx = eng.neighbor_csr(slab.set_id(0), slab.set_id(0), sort_each=False)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), gids=gids.cpu().numpy(), offs=offs, idx=idx.astype(np.int64), cuts=cuts, log=np.array(log))
+    del slab
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_c_abi_across_processes_over_gloo(world, oracle, tmp_path):
+    """The C entry points of the slab layer (cuts, redistribution, three steps) with one PROCESS per rank: the messages cross real process
+    boundaries through an application-filled tnsx_slab_transport (torch.distributed gloo, staged through host memory), the ranks share the
+    one GPU of the box.  What RCCL does on eight GPUs, minus RCCL: protocol, message sizes, all-reduces, speculation and the union."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0))
+        port = sck.getsockname()[1]
+    name = "uniform_fixed_1000000"
+    mp.start_processes(_mp_worker, args=(world, port, name, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    case = CS.by_name(name)
+    per_rank, cuts0 = [], None
+    for k in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"rank{k}.npz"))
+        per_rank.append((d["gids"], d["offs"], d["idx"]))
+        cuts0 = d["cuts"] if cuts0 is None else cuts0
+        assert np.array_equal(cuts0, d["cuts"]), "every rank must arrive at the same cuts"
+        log = [tuple(x) for x in d["log"]]
+        assert log[0] == (0, 0, 2) and log[1] == (1, 0, 1) and log[2] == (1, 0, 1), f"rank {k}: exact step first, then single speculative rounds; got {log}"
+    assert sum(len(g) for g, _, _ in per_rank) == len(case.points[0])
+    g_offs, g_idx = union_csr(len(case.points[0]), per_rank)
+    fx = load_golden(case.name)["pairs"]["0->0"]["strict"]
+    d_union = oracle.digest(g_offs, g_idx.astype(np.int32))
+    assert int(g_offs[-1]) == fx["total"]
+    assert (f"{d_union[0]:016x}", f"{d_union[1]:016x}") == (fx["digest_sum"], fx["digest_xor"]), "union of the processes' lists differs from the reference's digest"
 
 
 def test_rccl_transport_on_one_rank():

@@ -56,7 +56,7 @@ class Stats(C.Structure):
                 ("n_pool_pairs", C.c_int), ("pool_retries", C.c_int), ("cold_passes", C.c_int), ("speculated", C.c_int),
                 ("speculation_redos", C.c_int), ("n_cached_sets", C.c_int), ("n_filtered_cells", C.c_uint32), ("n_devices_used", C.c_int),
                 ("world_bottom", C.c_float * 3), ("world_top", C.c_float * 3), ("world_cells_pow2", C.c_int), ("zsort_cell_size_inv", C.c_float),
-                ("grid_trimmed", C.c_int), ("n_group_pairs", C.c_uint32), ("n_group_passed_cells", C.c_uint32)]
+                ("grid_trimmed", C.c_int), ("n_group_pairs", C.c_uint32), ("n_group_passed_cells", C.c_uint32), ("one_read_builds", C.c_int), ("heavy_catchups", C.c_int)]
 
     def as_dict(self):
         d = {}
@@ -71,7 +71,7 @@ ABI_SYMBOLS = [
     "tnsx_default_options", "tnsx_create", "tnsx_destroy", "tnsx_last_error", "tnsx_version",
     "tnsx_add_point_set", "tnsx_resize_point_set",
     "tnsx_set_search_radius", "tnsx_set_cell_size", "tnsx_set_symmetric_search", "tnsx_set_active_search",
-    "tnsx_set_active_search_all", "tnsx_set_all_searches", "tnsx_set_arithmetic",
+    "tnsx_set_active_search_all", "tnsx_set_all_searches", "tnsx_set_arithmetic", "tnsx_set_collect_stage_times",
     "tnsx_get_n_sets", "tnsx_get_n_points_in_set", "tnsx_get_total_n_points", "tnsx_is_search_active",
     "tnsx_does_set_exist", "tnsx_get_neighborlist_n_bytes",
     "tnsx_run", "tnsx_run_scalar", "tnsx_get_pair_view", "tnsx_mirror_pair_to_host", "tnsx_copy_pair",
@@ -81,13 +81,18 @@ ABI_SYMBOLS = [
     "tnsx_slab_rccl_unique_id", "tnsx_slab_transport_rccl", "tnsx_slab_rccl_error", "tnsx_slab_local_group_create", "tnsx_slab_local_group_release",
     "tnsx_slab_transport_local", "tnsx_slab_transport_release", "tnsx_slab_balanced_cuts", "tnsx_slab_create", "tnsx_slab_destroy",
     "tnsx_slab_last_error", "tnsx_slab_set_active_search", "tnsx_slab_step", "tnsx_slab_engine_set", "tnsx_slab_get_info",
-    "tnsx_slab_debug_set_capacity",
+    "tnsx_slab_debug_set_capacity", "tnsx_slab_set_watchdog", "tnsx_slab_redistribute_begin", "tnsx_slab_redistribute_finish",
 ]
 
 
 class SlabTransport(C.Structure):
     """tnsx_slab_transport (include/tnsx.h): filled by tnsx_slab_transport_rccl / tnsx_slab_transport_local"""
-    _fields_ = [("user", C.c_void_p), ("exchange", C.c_void_p), ("allreduce", C.c_void_p), ("release", C.c_void_p)]
+    _fields_ = [("user", C.c_void_p), ("exchange", C.c_void_p), ("allreduce", C.c_void_p), ("release", C.c_void_p), ("abort", C.c_void_p)]
+
+
+class SlabOp(C.Structure):
+    """tnsx_slab_op: one message pair with one neighbour (a transport's exchange gets an array of them)"""
+    _fields_ = [("peer", C.c_int), ("send", C.c_void_p), ("send_bytes", C.c_size_t), ("recv", C.c_void_p), ("recv_bytes", C.c_size_t)]
 
 
 class SlabInfo(C.Structure):
@@ -135,6 +140,7 @@ def load_library():
     L.tnsx_set_active_search_all.argtypes = [vp, ci, ci, ci]
     L.tnsx_set_all_searches.argtypes = [vp, ci]
     L.tnsx_set_arithmetic.argtypes = [vp, ci]
+    L.tnsx_set_collect_stage_times.argtypes = [vp, ci]
     L.tnsx_get_n_sets.argtypes = [vp]
     L.tnsx_get_n_points_in_set.argtypes = [vp, ci]
     L.tnsx_get_total_n_points.argtypes = [vp]
@@ -174,6 +180,9 @@ def load_library():
     L.tnsx_slab_engine_set.argtypes = [vp, ci]
     L.tnsx_slab_get_info.argtypes = [vp, C.POINTER(SlabInfo)]
     L.tnsx_slab_debug_set_capacity.argtypes = [vp, ci, C.c_uint]
+    L.tnsx_slab_set_watchdog.argtypes = [vp, C.c_double]
+    L.tnsx_slab_redistribute_begin.argtypes = [vp, tp, ci, ci, C.POINTER(C.c_float), vp, vp, vp, ci, C.POINTER(vp), C.POINTER(ci)]
+    L.tnsx_slab_redistribute_finish.argtypes = [vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -314,6 +323,10 @@ class TreeNSearch:
 
     def set_arithmetic(self, arith: int) -> None:
         self._check(self._L.tnsx_set_arithmetic(self._h, int(arith)))
+
+    def set_collect_stage_times(self, on: bool) -> None:
+        """hipEvents around every stage from the next run on (each one is a bubble between two kernels: off in timed loops)"""
+        self._check(self._L.tnsx_set_collect_stage_times(self._h, int(bool(on))))
 
     def _wait_for_producers(self) -> None:
         """Device inputs are read on the engine's stream.  When that is the engine's own stream, work that torch has queued on

@@ -43,16 +43,22 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
-    objs = []
-    for src in SOURCES:
+    objs, procs = [], []
+    dep_t = max(os.path.getmtime(h if os.path.isabs(h) else os.path.join(CSRC, h)) for h in HEADERS + [os.path.abspath(__file__)])
+    for src in SOURCES:   # one hipcc per translation unit, all at once (the query kernels alone take two minutes)
         obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
         extra = os.environ.get("TNSX_EXTRA_FLAGS", "").split()     # experiments, e.g. -DTNSX_FAST_WAVES_PER_EU=5
+        if not force and not extra and os.path.exists(obj) and os.path.getmtime(obj) > max(dep_t, os.path.getmtime(os.path.join(CSRC, src))):
+            continue
         per_file = ["-mllvm", "-amdgpu-mfma-vgpr-form"] if src == "tnsx_query_group.hip" else []   # MFMA results straight into VGPRs (no v_accvgpr_read)
         cmd = [hipcc()] + FLAGS + per_file + extra + ["-I" + os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        objs.append(obj)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)

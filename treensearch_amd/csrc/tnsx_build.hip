@@ -508,8 +508,8 @@ static constexpr int BS_KEEP = 12;     // points per thread that stay in registe
 static constexpr int BS_UNROLL = 4;    // loads in flight per thread for the points beyond that
 template <bool VARIABLE, bool SPLIT>
 __global__ void __launch_bounds__(BS_THREADS) k_bucket_sort(const float4* __restrict__ in, float4* __restrict__ out, float* __restrict__ r2_out,
-                                                            const float* __restrict__ radii, GridParams g, int lo_bits, const uint32_t* __restrict__ totals,
-                                                            uint2* __restrict__ table, uint2* __restrict__ occ_tmp, uint2* __restrict__ bucket_info,
+                                                            const float* __restrict__ radii, GridParams g, int lo_bits, const uint32_t* __restrict__ totals, int tstride,
+                                                            const uint2* __restrict__ win, uint2* __restrict__ table, uint2* __restrict__ occ_tmp, uint2* __restrict__ bucket_info,
                                                             uint32_t* __restrict__ n_occ, const int* __restrict__ ids, uint32_t* __restrict__ orig_out,
                                                             uint32_t query_limit, BuildGuard gd)
 {
@@ -522,21 +522,26 @@ __global__ void __launch_bounds__(BS_THREADS) k_bucket_sort(const float4* __rest
 	const uint32_t n_cells = (uint32_t)(g.nx * g.ny * g.nz);
 	// ---- where the bucket lies in the output of pass A: the counts of the buckets before it
 	uint32_t part = 0;
-	for (int k = (int)threadIdx.x; k < b; k += BS_THREADS) part += totals[k];
+	// (totals: the dense totals of the histogram pass, or -- tstride > 1 -- the cursors the one-read bucket pass left behind)
+	for (int k = (int)threadIdx.x; k < b; k += BS_THREADS) part += totals[(size_t)k * tstride];
 	#pragma unroll
 	for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, WAVE);
 	if (lane == 0) red[w] = part;
-	const uint32_t count = totals[b];
+	// (one-read pass: the cursor holds what the tiles ASKED the window for.  More than it holds means that the window overflowed, the guard flag
+	//  is up and this attempt will be thrown away -- but it must not read past the window, which for the last buckets is the end of the array)
+	const uint32_t count = win ? min(totals[(size_t)b * tstride], win[b].y) : totals[(size_t)b * tstride];
 	for (int k = (int)threadIdx.x; k < RADIX; k += BS_THREADS) h[k] = 0u;
 	__syncthreads();
 	uint32_t start = 0;
 	#pragma unroll
 	for (int k = 0; k < BS_THREADS / WAVE; k++) start += red[k];
 	if (count == 0u) { if (threadIdx.x == 0) bucket_info[b] = make_uint2(0u, 0u); return; }
+	// where the bucket's points are: packed behind the buckets before it (histogram pass), or in the bucket's own window (one-read pass)
+	if (win) in += win[b].x; else in += start;
 	// ---- the bucket's points -> registers (all loads in flight at once), sweep 1: points per cell
 	float4 keep[BS_KEEP];
 	#pragma unroll
-	for (int u = 0; u < BS_KEEP; u++) { const uint32_t i = (uint32_t)u * BS_THREADS + threadIdx.x; keep[u] = in[start + (i < count ? i : count - 1u)]; }
+	for (int u = 0; u < BS_KEEP; u++) { const uint32_t i = (uint32_t)u * BS_THREADS + threadIdx.x; keep[u] = in[i < count ? i : count - 1u]; }
 	#pragma unroll
 	for (int u = 0; u < BS_KEEP; u++) {
 		const uint32_t i = (uint32_t)u * BS_THREADS + threadIdx.x;
@@ -545,7 +550,7 @@ __global__ void __launch_bounds__(BS_THREADS) k_bucket_sort(const float4* __rest
 	for (uint32_t i0 = BS_KEEP * BS_THREADS; i0 < count; i0 += BS_THREADS * BS_UNROLL) {   // (a bucket larger than the registers hold: read twice)
 		float4 q[BS_UNROLL];
 		#pragma unroll
-		for (int u = 0; u < BS_UNROLL; u++) { const uint32_t i = i0 + (uint32_t)u * BS_THREADS + threadIdx.x; q[u] = in[start + (i < count ? i : count - 1u)]; }
+		for (int u = 0; u < BS_UNROLL; u++) { const uint32_t i = i0 + (uint32_t)u * BS_THREADS + threadIdx.x; q[u] = in[i < count ? i : count - 1u]; }
 		#pragma unroll
 		for (int u = 0; u < BS_UNROLL; u++) {
 			const uint32_t i = i0 + (uint32_t)u * BS_THREADS + threadIdx.x;
@@ -614,7 +619,7 @@ __global__ void __launch_bounds__(BS_THREADS) k_bucket_sort(const float4* __rest
 		float4 qq[BS_UNROLL];
 		float rr[BS_UNROLL];
 		#pragma unroll
-		for (int u = 0; u < BS_UNROLL; u++) { const uint32_t i = i0 + (uint32_t)u * BS_THREADS + threadIdx.x; qq[u] = in[start + (i < count ? i : count - 1u)]; }
+		for (int u = 0; u < BS_UNROLL; u++) { const uint32_t i = i0 + (uint32_t)u * BS_THREADS + threadIdx.x; qq[u] = in[i < count ? i : count - 1u]; }
 		#pragma unroll
 		for (int u = 0; u < BS_UNROLL; u++) rr[u] = VARIABLE ? radii[__float_as_uint(qq[u].w)] : 0.0f;
 		#pragma unroll
@@ -623,23 +628,113 @@ __global__ void __launch_bounds__(BS_THREADS) k_bucket_sort(const float4* __rest
 	// (speculated grid: a radius above the one the cell edge was chosen for -> the host repeats the run with fresh bounds)
 	if (VARIABLE && gd.flag && __builtin_amdgcn_ballot_w64(bad_r) != 0ull && lane == 0) atomicOr(gd.flag, 1u);
 }
-// the buckets' pieces of the occupied-cell list -> key order (what the query's XCD-contiguous work split wants)
-__global__ void __launch_bounds__(BS_THREADS) k_occ_reorder(const uint2* __restrict__ occ_tmp, uint2* __restrict__ occ, const uint2* __restrict__ bucket_info)
+// the buckets' pieces of the occupied-cell list -> key order (what the query's XCD-contiguous work split wants).
+// Also, for the NEXT run's one-read bucket pass: win_next[b] = {first slot, capacity} of bucket b's window of the intermediate array, the capacity
+// this run's count + 1/8 + 64 (points move by a fraction of a cell per step: the counts of a bucket of several rows change slowly)
+__host__ __device__ __forceinline__ uint32_t bucket_window_cap(uint32_t count) { return (count + (count >> 3) + 64u + 7u) & ~7u; }
+__global__ void __launch_bounds__(BS_THREADS) k_occ_reorder(const uint2* __restrict__ occ_tmp, uint2* __restrict__ occ, const uint2* __restrict__ bucket_info,
+                                                            const uint32_t* __restrict__ totals, int tstride, uint2* __restrict__ win_next)
 {
-	__shared__ uint32_t red[BS_THREADS / WAVE];
+	__shared__ uint32_t red[2 * (BS_THREADS / WAVE)];
 	const int b = (int)blockIdx.x;
 	const uint2 me = bucket_info[b];
-	if (me.y == 0u) return;
-	uint32_t part = 0;
-	for (int k = (int)threadIdx.x; k < b; k += BS_THREADS) part += bucket_info[k].y;
+	uint32_t part = 0, wpart = 0;
+	for (int k = (int)threadIdx.x; k < b; k += BS_THREADS) { part += bucket_info[k].y; if (win_next) wpart += bucket_window_cap(totals[(size_t)k * tstride]); }
 	#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, WAVE);
-	if (lane_id() == 0) red[threadIdx.x / WAVE] = part;
+	for (int o = 32; o > 0; o >>= 1) { part += __shfl_xor(part, o, WAVE); wpart += __shfl_xor(wpart, o, WAVE); }
+	if (lane_id() == 0) { red[threadIdx.x / WAVE] = part; red[BS_THREADS / WAVE + threadIdx.x / WAVE] = wpart; }
 	__syncthreads();
-	uint32_t prefix = 0;
+	uint32_t prefix = 0, wprefix = 0;
 	#pragma unroll
-	for (int k = 0; k < BS_THREADS / WAVE; k++) prefix += red[k];
+	for (int k = 0; k < BS_THREADS / WAVE; k++) { prefix += red[k]; wprefix += red[BS_THREADS / WAVE + k]; }
+	if (win_next && threadIdx.x == 0) win_next[b] = make_uint2(wprefix, bucket_window_cap(totals[(size_t)b * tstride]));
 	for (uint32_t i = threadIdx.x; i < me.y; i += BS_THREADS) occ[prefix + i] = occ_tmp[me.x + i];
+}
+
+// =====================================================================================================
+// Pass A in ONE read (round 4).  The histogram pass + its two scan kernels exist only to tell the scatter where every bucket starts and how
+// much of it the tiles before this one fill.  A steady-state step knows both well enough from the previous run: every bucket gets a WINDOW of
+// the intermediate array (last run's count + 1/8 + 64 slots, k_occ_reorder), and a tile reserves its piece of a window with one returning atomic
+// per bucket it touches on a cursor that starts at zero (k_run_begin).  The order of the tiles inside a window is whatever the atomics give --
+// nothing downstream needs it (k_bucket_sort re-sorts the bucket by cell; the exact layout keeps the stable LSD passes).  A window that
+// overflows raises the run's guard flag: the attempt is thrown away and repeated with the histogram pass, like any other failed assumption
+// of a speculative run.  Tiles are large (1024 threads x 16 points) so that the ~1000 atomics of a tile of points in random order are one per
+// 16 points (measured: tools/ubench/atomic_scatter.hip, 0.6 M returning atomics on cursors 128 bytes apart take 25 us on their own) and a
+// tile's piece of a window is 256 contiguous bytes.  The rank of a point inside its (tile, bucket) piece is an LDS atomic.
+// Carries the run-time checks of the speculation like k_cs_hist does (box guard, checksum).
+// =====================================================================================================
+static constexpr int B1_THREADS = 1024, B1_ITEMS = 16, B1_TILE = B1_THREADS * B1_ITEMS;
+__global__ void __launch_bounds__(B1_THREADS) k_bucket_scatter(const float* __restrict__ xyz, int n, GridParams g, int lo_bits, int n_buckets, const uint2* __restrict__ win,
+                                                               uint32_t* __restrict__ cursors, float4* __restrict__ out, const float* __restrict__ radii, BuildGuard gd)
+{
+	extern __shared__ uint32_t b1_h[];   // per bucket: points of this tile, then where the tile's piece starts
+	for (int b = threadIdx.x; b < n_buckets; b += B1_THREADS) b1_h[b] = 0u;
+	__syncthreads();
+	const size_t base = (size_t)blockIdx.x * B1_TILE;
+	float px[B1_ITEMS], py[B1_ITEMS], pz[B1_ITEMS];
+	uint32_t dr[B1_ITEMS];   // bucket | rank inside the tile's piece << 16 (a tile holds 2^14 points; at most 2^11 buckets)
+	const uint32_t rem = base < (size_t)n ? (uint32_t)((size_t)n - base < (size_t)B1_TILE ? (size_t)n - base : (size_t)B1_TILE) : 0u;
+	#pragma unroll
+	for (int i = 0; i < B1_ITEMS; i++) {   // all loads up front, branch-free (clamped)
+		const uint32_t li = (uint32_t)i * B1_THREADS + threadIdx.x;
+		const F3 q = (reinterpret_cast<const F3*>(xyz) + base)[li < rem ? li : rem - 1u];
+		px[i] = q.x; py[i] = q.y; pz[i] = q.z;
+	}
+	bool bad = false;
+	float mn[3] = { gd.hi[0], gd.hi[1], gd.hi[2] }, mx[3] = { gd.lo[0], gd.lo[1], gd.lo[2] };
+	unsigned long long chk = 0;
+	uint32_t n_outside = 0;
+	#pragma unroll
+	for (int i = 0; i < B1_ITEMS; i++) {
+		const uint32_t li = (uint32_t)i * B1_THREADS + threadIdx.x;
+		if (li < rem) {
+			const float x = px[i], y = py[i], z = pz[i];
+			if (gd.flag) {   // (see k_cs_hist: a NaN x is no point and counts for nothing)
+				const bool pt = x == x;
+				const float qy = pt ? y : x, qz = pt ? z : x;
+				mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
+				mn[1] = fminf(mn[1], qy); mx[1] = fmaxf(mx[1], qy);
+				mn[2] = fminf(mn[2], qz); mx[2] = fmaxf(mx[2], qz);
+				bad |= pt & ((y != y) | (z != z));
+				if (gd.outside) n_outside += pt & ((x < gd.soft_lo[0]) | (x > gd.soft_hi[0]) | (y < gd.soft_lo[1]) | (y > gd.soft_hi[1]) | (z < gd.soft_lo[2]) | (z > gd.soft_hi[2]));
+			}
+			if (gd.checksum) chk += point_hash((uint32_t)(base + li), x, y, z, radii ? radii[base + li] : 0.0f);
+			// A NaN x is NO POINT (the padding rows of a speculative ghost message): it enters no cell and nothing ever reads it, so it is simply
+			// left out here -- their number changes from step to step with the fill of the messages, and a window sized for last step's would
+			// overflow for nothing.  (The sorted array then has unused slots behind its last cell.)
+			dr[i] = 0xffffffffu;
+			if (x == x) {
+				const uint32_t d = cell_key(x, y, z, g) >> lo_bits;
+				dr[i] = d | (atomicAdd(&b1_h[d], 1u) << 16);
+			}
+		}
+	}
+	if (gd.flag) bad |= mn[0] < gd.lo[0] || mn[1] < gd.lo[1] || mn[2] < gd.lo[2] || mx[0] > gd.hi[0] || mx[1] > gd.hi[1] || mx[2] > gd.hi[2];
+	if (gd.flag && gd.outside && __builtin_amdgcn_ballot_w64(n_outside != 0u) != 0ull) {
+		const unsigned long long w = wave_sum_u64((unsigned long long)n_outside);
+		if (lane_id() == 0) atomicAdd(gd.outside, w);
+	}
+	if (gd.checksum) { chk = wave_sum_u64(chk); if (lane_id() == 0 && chk) atomicAdd(gd.checksum + (blockIdx.x % CHK_SLOTS) * CHK_STRIDE, chk); }
+	__syncthreads();
+	// ---- this tile's piece of every window it touches
+	for (int b = threadIdx.x; b < n_buckets; b += B1_THREADS) {
+		const uint32_t c = b1_h[b];
+		if (c == 0u) continue;
+		const uint2 w = win[b];
+		const uint32_t first = atomicAdd(&cursors[(size_t)b * BUCKET_CURSOR_STRIDE], c);
+		if (first + c > w.y) { bad = true; b1_h[b] = 0xffffffffu; }   // the window is full: nothing of this piece is written, the run is repeated
+		else b1_h[b] = w.x + first;
+	}
+	if (gd.flag && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane_id() == 0) atomicOr(gd.flag, 1u);
+	__syncthreads();
+	#pragma unroll
+	for (int i = 0; i < B1_ITEMS; i++) {
+		const uint32_t li = (uint32_t)i * B1_THREADS + threadIdx.x;
+		if (li < rem && dr[i] != 0xffffffffu) {
+			const uint32_t p0 = b1_h[dr[i] & 0xffffu];
+			if (p0 != 0xffffffffu) out[p0 + (dr[i] >> 16)] = make_float4(px[i], py[i], pz[i], __uint_as_float((uint32_t)(base + li)));
+		}
+	}
 }
 
 // bits of the two digits of the bucket build, or {0, 0} when the key is too wide for it (the LSD passes + k_cell_table then)
@@ -659,9 +754,17 @@ size_t cell_build_temp_bytes(int n)
 	// the sort's tables, then occ_tmp (n entries) and bucket_info (2^CS_MAX_BITS entries) of the bucket build
 	return ((cell_sort_temp_bytes(n) + 255) / 256) * 256 + (size_t)(n > 0 ? n : 1) * sizeof(uint2) + ((size_t)1 << CS_MAX_BITS) * sizeof(uint2) + 256;
 }
+bool cell_build_uses_buckets(int n, int key_bits, bool stable_order, int bucket_min_points, int* n_buckets)
+{
+	int hi_bits = 0, lo_bits = 0;
+	if (stable_order || !bucket_plan(key_bits, n, bucket_min_points, hi_bits, lo_bits)) return false;
+	if (n_buckets) *n_buckets = 1 << hi_bits;
+	return true;
+}
+size_t bucket_window_slots(int n, int n_buckets) { return (size_t)n + (size_t)n / 8 + (size_t)n_buckets * 72 + 64; }   // >= the sum of bucket_window_cap over any counts that sum to n
 int launch_cell_build(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, const int* ids,
                       uint32_t* orig_sorted, const BuildGuard& gd, uint32_t query_limit, bool stable_order, int bucket_min_points, uint2* table, uint2* occ,
-                      uint32_t* n_occ, int* passes_out, hipStream_t s)
+                      uint32_t* n_occ, int* passes_out, const BucketWindows& bw, hipStream_t s)
 {
 	int hi_bits = 0, lo_bits = 0;
 	if (stable_order || !bucket_plan(key_bits, n, bucket_min_points, hi_bits, lo_bits)) {
@@ -678,18 +781,29 @@ int launch_cell_build(const float* xyz, const float* radii, int n, GridParams g,
 	uint32_t* strip_sums = totals + ((size_t)1 << CS_MAX_BITS);
 	uint2* occ_tmp = (uint2*)((char*)temp + ((cell_sort_temp_bytes(n) + 255) / 256) * 256);
 	uint2* bucket_info = occ_tmp + (size_t)n;
-	// ---- pass A: bucket = high digit.  (radii and ids are picked up by original index in pass B)
-	BuildGuard gda = gd;
-	TNSX_CS_DISPATCH(hi_bits, (cs_hist<B, false>(true, xyz, b.xyzi[0], n, g, lo_bits, hist, ntiles, radii, gda, s)));
-	TNSX_CS_DISPATCH(hi_bits, cs_scan<B>(hist, ntiles, strip_sums, totals, s));
-	TNSX_CS_DISPATCH(hi_bits, (cs_scatter<B, false>(true, false, xyz, nullptr, b.xyzi[0], b.r2[0], b.xyzi[1], b.r2[1], n, g, lo_bits, hist, totals, ntiles, nullptr,
-	                                               nullptr, gda, s)));
-	// ---- pass B: one workgroup per bucket
 	const int n_buckets = 1 << hi_bits;
+	// ---- pass A: bucket = high digit.  (radii and ids are picked up by original index in pass B)
+	const uint32_t* counts = totals;
+	int cstride = 1;
+	const uint2* win = nullptr;
+	if (bw.use && bw.win && bw.cursors) {
+		// one read: windows from the previous run, one returning atomic per tile and bucket (k_bucket_scatter)
+		hipLaunchKernelGGL(k_bucket_scatter, dim3((n + B1_TILE - 1) / B1_TILE), dim3(B1_THREADS), (size_t)n_buckets * sizeof(uint32_t), s, xyz, n, g, lo_bits, n_buckets, bw.win,
+		                   bw.cursors, b.xyzi[1], radii, gd);
+		counts = bw.cursors; cstride = BUCKET_CURSOR_STRIDE; win = bw.win;
+	}
+	else {
+		BuildGuard gda = gd;
+		TNSX_CS_DISPATCH(hi_bits, (cs_hist<B, false>(true, xyz, b.xyzi[0], n, g, lo_bits, hist, ntiles, radii, gda, s)));
+		TNSX_CS_DISPATCH(hi_bits, cs_scan<B>(hist, ntiles, strip_sums, totals, s));
+		TNSX_CS_DISPATCH(hi_bits, (cs_scatter<B, false>(true, false, xyz, nullptr, b.xyzi[0], b.r2[0], b.xyzi[1], b.r2[1], n, g, lo_bits, hist, totals, ntiles, nullptr,
+		                                               nullptr, gda, s)));
+	}
+	// ---- pass B: one workgroup per bucket
 	const bool variable = radii != nullptr, split = query_limit < (uint32_t)n;
 	const size_t lds = ((size_t)1 << lo_bits) * sizeof(uint32_t) * (split ? 2 : 1);
 #define TNSX_BS_GO(V, SP) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_sort<V, SP>), dim3(n_buckets), dim3(BS_THREADS), lds, s, b.xyzi[1], b.xyzi[0], b.r2[0], radii, g, lo_bits, \
-	                                         totals, table, occ_tmp, bucket_info, n_occ, ids, orig_sorted, query_limit, gd)
+	                                         counts, cstride, win, table, occ_tmp, bucket_info, n_occ, ids, orig_sorted, query_limit, gd)
 	if (lds > 48u * 1024u) {   // (a 13-bit low digit with two cursors per cell: above the default limit of dynamic LDS)
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_sort<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_sort<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -697,7 +811,8 @@ int launch_cell_build(const float* xyz, const float* radii, int n, GridParams g,
 	if (variable) { if (split) TNSX_BS_GO(true, true); else TNSX_BS_GO(true, false); }
 	else          { if (split) TNSX_BS_GO(false, true); else TNSX_BS_GO(false, false); }
 #undef TNSX_BS_GO
-	hipLaunchKernelGGL(k_occ_reorder, dim3(n_buckets), dim3(BS_THREADS), 0, s, occ_tmp, occ, bucket_info);
+	// (the windows of the next run: from this run's counts, whichever pass A produced them; written behind pass B, which reads this run's)
+	hipLaunchKernelGGL(k_occ_reorder, dim3(n_buckets), dim3(BS_THREADS), 0, s, occ_tmp, occ, bucket_info, counts, cstride, bw.win);
 	return 0;
 }
 

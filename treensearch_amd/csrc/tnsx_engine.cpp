@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -100,6 +101,11 @@ struct PointSet {
 	const void* chk_xyz = nullptr; const void* chk_radii = nullptr;
 	int chk_n = -1;
 	uint32_t built_gen = 0;        // grid generation the sorted arrays / table were built for (0: none)
+	// one-read bucket pass (tnsx_build.hip k_bucket_scatter): windows of the intermediate array written by the last build, cursors of this run
+	DevBuf bk_win, bk_cur;
+	uint32_t bk_gen = 0;           // grid generation the windows were written for (0: none)
+	int bk_n = 0, bk_buckets = 0;  // ... and the size of the set / the number of buckets then
+	bool bk_now = false, bk_used = false;   // this attempt: the bucket build runs / with the one-read pass
 	// zsort
 	std::vector<int> zsort_host;    // filled on demand (zsort_host_order)
 	int zsort_n = 0;
@@ -125,6 +131,9 @@ struct PairResult {
 	uint32_t n_cells_i = 0;      // occupied cells of set i in the previous run
 	bool groups_off = false;     // the group formulation sent too much of this pair to its leftover kernel: cell kernels from now on
 	bool groups_now = false;     // this attempt runs the group formulation
+	bool heavy_known = false;    // heavy_cells is what the previous run of this pair saw
+	uint32_t heavy_cells = 0;    // cells its first tier passed on to the heavy tiers
+	bool heavy_skipped = false;  // this attempt did not launch the heavy tiers (the previous run had nothing for them; checked after the run)
 	DevBuf counts, offs_sorted, offs_orig, records, heavy, heavy2, filtered;
 	PinnedBuf h_offs, h_records;
 	bool mirrored = false;
@@ -177,6 +186,7 @@ struct tnsx_context {
 	tnsx_stats stats{};
 	std::vector<hipEvent_t> events;
 	std::mutex mirror_mutex;
+	double sync_timeout_s = 0.0;   // slab layer watchdog: > 0 bounds the waits of a run on the stream (tnsx_internal_set_sync_timeout)
 };
 
 namespace {
@@ -408,6 +418,21 @@ struct StageTimer {
 
 }  // namespace
 
+// hipStreamSynchronize, or -- with a deadline (the slab layer's watchdog: an exchange that never completes must not hang the process) -- a poll
+static tnsx_status sync_stream(tnsx_context* c)
+{
+	if (!(c->sync_timeout_s > 0.0)) { HIPCHK(c, hipStreamSynchronize(c->stream)); return TNSX_OK; }
+	const auto t0 = std::chrono::steady_clock::now();
+	for (;;) {
+		const hipError_t q = hipStreamQuery(c->stream);
+		if (q == hipSuccess) return TNSX_OK;
+		if (q != hipErrorNotReady) TNSX_FAIL(c, TNSX_ERR_HIP, "HIP error %s while waiting for the stream", hipGetErrorString(q));
+		if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->sync_timeout_s)
+			TNSX_FAIL(c, TNSX_ERR_TIMEOUT, "the stream did not drain within %.1f s (watchdog)", c->sync_timeout_s);
+		std::this_thread::yield();
+	}
+}
+
 // ================================================================================================== C ABI
 extern "C" {
 
@@ -573,6 +598,12 @@ tnsx_status tnsx_set_arithmetic(tnsx_context* c, int arith)
 	if (arith != TNSX_ARITH_STRICT && arith != TNSX_ARITH_CONTRACTED) TNSX_FAIL(c, TNSX_ERR_INVALID, "set_arithmetic: unknown mode %d", arith);
 	if (c->multi) tnsx_multi::set_arithmetic(c->multi, arith);
 	c->opt.arith = arith;
+	return TNSX_OK;
+}
+tnsx_status tnsx_set_collect_stage_times(tnsx_context* c, int on)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	c->opt.collect_stage_times = on != 0;   // (multi-device contexts collect no stage times)
 	return TNSX_OK;
 }
 tnsx_status tnsx_set_active_search(tnsx_context* c, int i, int j, int active)
@@ -796,88 +827,20 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		if (c->n_occ.p != old) for (PointSet& s : c->sets) s.built_gen = 0;   // the occupied-cell counts of cached sets lived in the old buffer
 	}
 	std::vector<char> skipped((size_t)n_sets, 0);
-	int t_first = -1;   // the event in front of k_run_begin: start of the first built set's stages
 	auto keeps_its_build = [&](const PointSet& s) {
 		const bool same_input = s.chk_valid && s.chk_xyz == s.user_xyz && s.chk_radii == s.user_radii && s.chk_n == s.n && s.chk_double == s.is_double;
 		const bool cacheable = !s.user_ids && s.n > 0;
 		return speculate && cacheable && s.predicted_static && same_input && s.built_gen == c->grid_gen && s.table_state == 1;
 	};
-	{
-		// one launch zeroes the words of this attempt and the occupied-cell counts of the sets that are built (fill commands between kernels cost
-		// a bubble each)
-		t_first = tm.mark();   // (in front of the launch: every event record between two kernels costs a bubble of 6-9 us)
-		unsigned long long built = 0;
-		for (int si = 0; si < std::min(n_sets, 64); si++) if (!keeps_its_build(c->sets[si])) built |= 1ull << si;
-		tnsx::launch_run_begin(d_words, WB * (size_t)(n_sets + 1), c->n_occ.as<uint32_t>(), built, st);
-	}
-	for (int si = 0; si < n_sets; si++) {
-		PointSet& s = c->sets[si];
-		const bool cacheable = !s.user_ids && s.n > 0;
-		if (keeps_its_build(s)) {
-			// taken to be unchanged: only its checksum is computed (and compared after the run)
-			tnsx::launch_set_checksum(s.d_xyz, variable ? s.d_radii : nullptr, s.n, d_words + WB * (size_t)(1 + si), st);
-			skipped[(size_t)si] = 1;
-			S.n_cached_sets++;
-			continue;
-		}
-		// the table is needed even for empty sets (they can be searched into)
-		const int t0 = t_first >= 0 ? t_first : tm.mark();
-		t_first = -1;
-		if (si >= 64) HIPCHK(c, hipMemsetAsync(c->n_occ.as<uint32_t>() + si, 0, sizeof(uint32_t), st));   // (the others: launch_run_begin above)
-		{
-			const void* old_table = s.table.p;
-			HIPCHK(c, s.table.reserve(n_cells * sizeof(uint2)));
-			if (s.table.p != old_table || s.table_state == 2) HIPCHK(c, hipMemsetAsync(s.table.p, 0, s.table.cap, st));   // new or unknown: all of it
-			else if (s.table_state == 1 && s.table_dirty > 0) tnsx::launch_table_clear(s.occ.as<uint2>(), s.table_dirty, s.table.as<uint2>(), st);
-			s.table_state = 0; s.table_dirty = 0;
-		}
-		HIPCHK(c, s.occ.reserve((size_t)std::max(s.n, 1) * sizeof(uint2)));   // (after the clear: it reads the previous list)
-		s.built_gen = 0;
-		if (s.n == 0) continue;
-		s.table_state = 2;   // until this run's occupied-cell count has reached the host
-		for (int k = 0; k < 2; k++) {
-			HIPCHK(c, s.xyzi[k].reserve((size_t)s.n * sizeof(float4)));
-			if (variable) HIPCHK(c, s.r2[k].reserve((size_t)s.n * sizeof(float)));
-		}
-		HIPCHK(c, c->sort_temp.reserve(tnsx::cell_build_temp_bytes(s.n)));
-		tnsx::CellSortBuffers cb;
-		for (int k = 0; k < 2; k++) { cb.xyzi[k] = s.xyzi[k].as<float4>(); cb.r2[k] = s.r2[k].as<float>(); }
-		tnsx::BuildGuard gd;
-		if (speculate) {
-			for (int d = 0; d < 3; d++) { gd.lo[d] = c->grid_lo[d]; gd.hi[d] = c->grid_hi[d]; }
-			gd.r_max = c->grid_r_max;
-			gd.flag = reinterpret_cast<uint32_t*>(d_words);
-			if (c->grid_trimmed) {
-				// the grid covers the bulk of the points only: whoever is outside it is binned into its border cells (exact), so the box that
-				// must hold is the WORLD box (whose update needs the true bounds); the points outside the grid's own box are counted, and
-				// the grid is laid out afresh when they become many
-				for (int d = 0; d < 3; d++) { gd.soft_lo[d] = c->grid_lo[d]; gd.soft_hi[d] = c->grid_hi[d]; gd.lo[d] = c->world[d]; gd.hi[d] = c->world[3 + d]; }
-				gd.outside = d_words + tnsx::CHK_STRIDE;
-			}
-		}
-		if (cacheable) gd.checksum = d_words + WB * (size_t)(1 + si);
-		const int t1 = tm.mark();
-		if (s.user_ids) HIPCHK(c, s.orig_sorted.reserve((size_t)s.n * sizeof(uint32_t)));
-		// sort + cell table + occupied-cell list (two-pass bucket build where the key fits; the exact layout keeps the stable sort)
-		int passes = 0;
-		const uint32_t q_limit = (s.n_query >= 0 && s.n_query < s.n) ? (uint32_t)s.n_query : 0xffffffffu;
-		s.sorted_buf = tnsx::launch_cell_build(s.d_xyz, variable ? s.d_radii : nullptr, s.n, g, key_bits, cb, c->sort_temp.p, s.user_ids,
-		                                       s.user_ids ? s.orig_sorted.as<uint32_t>() : nullptr, gd, q_limit, c->opt.exact_layout != 0,
-		                                       c->opt.bucket_build_min_points, s.table.as<uint2>(), s.occ.as<uint2>(), c->n_occ.as<uint32_t>() + si, &passes, st);
-		S.radix_passes = passes;
-		const int t2 = tm.mark();
-		const int t3 = t2;   // (the table is part of the build now: ms_cells stays 0 unless the LSD path ran)
-		span(ST_KEYS, t0, t1); span(ST_SORT, t1, t2); span(ST_CELLS, t2, t3);
-	}
 
-	// ---- per active pair: the query.
+	// ---- per active pair: what its pass needs on the host side (sizes from the previous run; nothing here waits for the device).
 	//      pool mode (default): ONE pass, records bump-allocated from the regions of the pair's pool (first run of a pair: a dry pass first);
 	//      exact mode (opt.exact_layout): count -> scan -> fill, gap-free CSR in sorted order.
-	struct Job { int i, j; bool pool; };
+	struct Job { int i, j; bool pool; bool begun; };
 	std::vector<Job> jobs;
-	for (int i = 0; i < n_sets; i++) for (int j = 0; j < n_sets; j++) if (c->active[i][j]) jobs.push_back({ i, j, false });
+	for (int i = 0; i < n_sets; i++) for (int j = 0; j < n_sets; j++) if (c->active[i][j]) jobs.push_back({ i, j, false, false });
 	constexpr size_t HC = (size_t)PairResult::NR * tnsx::POOL_CTRL_WORDS;   // per job: cursor / neighbours / unused ints of every pool region (exact layout: word 0 = total)
-	HIPCHK(c, c->h_small.reserve(sizeof(uint64_t) * (HC * jobs.size() + 2 + WB * ((size_t)n_sets + 1)) + sizeof(uint32_t) * (size_t)(n_sets + 1 + 2 * (jobs.size() + 1)) + 64));
+	HIPCHK(c, c->h_small.reserve(sizeof(uint64_t) * (HC * jobs.size() + 2 + WB * ((size_t)n_sets + 1)) + sizeof(uint32_t) * (size_t)(n_sets + 1 + 3 * (jobs.size() + 1)) + 64));
 	uint64_t* h_ctrl = c->h_small.as<uint64_t>();
 	uint64_t* h_words = h_ctrl + HC * jobs.size() + 2;                  // guard flag, partial checksums
 	uint32_t* h_nocc = reinterpret_cast<uint32_t*>(h_words + WB * ((size_t)n_sets + 1));
@@ -885,6 +848,8 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	for (size_t k = 0; k < jobs.size(); k++) h_filt[k] = 0;
 	uint32_t* h_left = h_filt + jobs.size() + 1;                        // per job: cells the group kernel passed on to the cell tiers
 	for (size_t k = 0; k < jobs.size(); k++) h_left[k] = 0;
+	uint32_t* h_heavy = h_left + jobs.size() + 1;                       // per job: cells the first tier passed on to the heavy tiers
+	for (size_t k = 0; k < jobs.size(); k++) h_heavy[k] = 0;
 	// the words of the pool passes go to the host with the ONE kernel at the end of the attempt (launch_run_end); the repeat of a pass that
 	// overflowed, and attempts with more pool passes than that kernel takes, copy them pass by pass
 	tnsx::RunEndArgs run_end{};
@@ -892,109 +857,6 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	HIPCHK(c, c->pool_ctrl.reserve(tnsx::CTRL_BYTES * (jobs.size() + 1)));   // per job: cursor, hit_total, 2 x (8 tickets, n_heavy), spread out
 	auto ctrl_slot = [&](size_t k, int slot) { return c->pool_ctrl.as<uint32_t>() + (k * tnsx::CTRL_SLOTS + (size_t)slot) * tnsx::CTRL_STRIDE_U32; };
 	const int query_waves = c->n_cus * 8 * 4;
-
-	auto make_args = [&](const Job& jb, PairResult& pr, size_t k) {
-		const PointSet& A = c->sets[jb.i];
-		const PointSet& B = c->sets[jb.j];
-		tnsx::QueryArgs a{};
-		a.occ_i = A.occ.as<uint2>(); a.n_occ_i = c->n_occ.as<uint32_t>() + jb.i;
-		a.table_i = A.table.as<uint2>();
-		a.xyzi_i = A.xyzi[A.sorted_buf].as<float4>(); a.r2_i = A.r2[A.sorted_buf].as<float>();
-		a.orig_i = A.user_ids ? A.orig_sorted.as<uint32_t>() : nullptr;
-		a.table_j = B.table.as<uint2>(); a.xyzi_j = B.xyzi[B.sorted_buf].as<float4>(); a.r2_j = B.r2[B.sorted_buf].as<float>();
-		a.r2_fixed = c->radius_sq;
-		a.query_limit = A.n_query < 0 ? 0xffffffffu : (uint32_t)A.n_query;
-		a.n_points_i = (uint32_t)A.n;
-		a.g = g;
-		a.counts = pr.counts.as<uint32_t>();
-		a.offs_sorted = pr.offs_sorted.as<uint64_t>();
-		a.records = pr.records.as<int>();
-		a.offs_by_orig = pr.offs_orig.as<uint64_t>();
-		a.pool_cursor = reinterpret_cast<unsigned long long*>(ctrl_slot(k, tnsx::CTRL_CURSOR));
-		a.pool_regions = reinterpret_cast<const unsigned long long*>(ctrl_slot(k, tnsx::CTRL_REGIONS));
-		a.tickets = ctrl_slot(k, tnsx::CTRL_TICKETS);
-		a.n_heavy = ctrl_slot(k, tnsx::CTRL_NHEAVY);
-		a.tickets2 = ctrl_slot(k, tnsx::CTRL_TICKETS2);
-		a.n_heavy2 = ctrl_slot(k, tnsx::CTRL_NHEAVY2);
-		a.heavy = pr.heavy.as<uint2>();
-		a.heavy2 = pr.heavy2.as<uint2>();
-		// (the worklist of the group formulation shares buffer and counter with the candidate-presence filter: that one is for pairs of two
-		//  different sets, the group formulation for a set searched in itself)
-		a.heavy0 = pr.filtered.as<uint2>();
-		a.n_heavy0 = ctrl_slot(k, tnsx::CTRL_NFILTERED);
-		a.pool_slab = pr.pool_slab;
-		a.pool_slab_heavy = std::max<uint32_t>(pr.pool_slab, 8192u);
-		a.shared_empty = jb.pool && jb.i != jb.j ? 1u : 0u;
-		if (a.shared_empty && pr.n_query > 0) {
-			// the query walks the cells that have candidates at all (launch_mark_cells + launch_filter_marked, enqueued by launch_pool)
-			a.occ_i = pr.filtered.as<uint2>();
-			a.n_occ_i = ctrl_slot(k, tnsx::CTRL_NFILTERED);
-		}
-		return a;
-	};
-	tnsx::QueryConfig qc{};
-	qc.arith = c->opt.arith;
-	qc.variable = variable;
-	qc.symmetric = variable && c->symmetric;   // TreeNSearch.cpp:2431
-	qc.blocks_per_cu = c->opt.query_blocks_per_cu;
-	qc.fast_blocks_per_cu = c->opt.fast_blocks_per_cu;
-
-	auto launch_pool = [&](size_t k) -> tnsx_status {
-		const Job& jb = jobs[k];
-		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
-		const int t0 = tm.mark();   // (in front of k_pool_begin, next to the event that ends the build: one bubble instead of two)
-		{
-			// the region table of this pass (all capacities 0: nothing is written, everything is counted).
-			// A pair of two different sets: most query cells may have no candidate at all (a fluid searched in its boundary).  Int 0 of
-			// the pool is THE empty record and every offset starts out pointing at it: cells without candidates then cost no
-			// allocation, no record and no scattered 8-byte offset store.
-			unsigned long long regions[2 * PairResult::NR];
-			const bool count_only = c->debug_nostore || pr.dry;
-			for (int r = 0; r < PairResult::NR; r++) { regions[2 * r] = pr.region_base[r]; regions[2 * r + 1] = count_only ? 0ull : pr.region_cap[r]; }
-			tnsx::launch_pool_begin(regions, ctrl_slot(k, 0), pr.offs_orig.as<uint64_t>(),
-			                        pr.shared_empty ? (size_t)pr.n_query : 0, pr.records.as<int>(), st);
-		}
-		if (pr.shared_empty) {
-			const PointSet& A = c->sets[jb.i];
-			const size_t max_cells = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pr.n_i, n_cells));
-			HIPCHK(c, pr.filtered.reserve(max_cells * sizeof(uint2)));
-			{
-				const PointSet& B = c->sets[jb.j];
-				const void* old_map = c->cell_map.p;
-				HIPCHK(c, c->cell_map.reserve(n_cells));
-				if (c->cell_map.p != old_map) HIPCHK(c, hipMemsetAsync(c->cell_map.p, 0, c->cell_map.cap, st));   // (all zero between uses)
-				const size_t max_cells_j = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(B.n, 1), n_cells));
-				unsigned char* map = c->cell_map.as<unsigned char>();
-				tnsx::launch_mark_cells(B.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.j, g, map, 1, max_cells_j, st);
-				tnsx::launch_filter_marked(A.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.i, map, pr.filtered.as<uint2>(), ctrl_slot(k, tnsx::CTRL_NFILTERED), max_cells, st);
-				tnsx::launch_mark_cells(B.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.j, g, map, 0, max_cells_j, st);
-			}
-		}
-		if (pr.n_i > 0) {
-			qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_POOL;
-			// opt-in (tnsx_options.query_formulation = 1), fixed radius, a set searched in itself: the group formulation (tnsx_query_group.hip)
-			// in front of the cell kernels, unless it was switched off for this pair
-			pr.groups_now = !variable && jb.i == jb.j && c->opt.query_formulation == 1 && !pr.groups_off && c->grid_h * c->grid_h > 1e-30f;
-			qc.groups = pr.groups_now;
-			if (pr.groups_now) HIPCHK(c, pr.filtered.reserve((size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pr.n_i, n_cells)) * sizeof(uint2)));
-			tnsx::launch_query(make_args(jb, pr, k), qc, c->n_cus, st);
-			qc.groups = false;
-		}
-		const int t1 = tm.mark();
-		span(ST_FILL, t0, t1);
-		uint32_t* const h_count = pr.shared_empty ? h_filt + k : (pr.groups_now && pr.n_i > 0 ? h_left + k : nullptr);   // (the two worklists share a counter, see make_args)
-		if (defer_readback && run_end.n_jobs < tnsx::RUN_END_MAX_JOBS) {
-			tnsx::RunEndJob& rj = run_end.job[run_end.n_jobs++];
-			rj.ctrl_cursor = ctrl_slot(k, tnsx::CTRL_CURSOR); rj.h_ctrl = reinterpret_cast<unsigned long long*>(h_ctrl + HC * k);
-			rj.d_count = ctrl_slot(k, tnsx::CTRL_NFILTERED); rj.h_count = h_count;
-			return TNSX_OK;
-		}
-		HIPCHK(c, hipMemcpy2DAsync(h_ctrl + HC * k, tnsx::POOL_CTRL_WORDS * sizeof(uint64_t), ctrl_slot(k, tnsx::CTRL_CURSOR), tnsx::CTRL_STRIDE_U32 * sizeof(uint32_t),
-		                           tnsx::POOL_CTRL_WORDS * sizeof(uint64_t), PairResult::NR, hipMemcpyDeviceToHost, st));
-		if (h_count) HIPCHK(c, hipMemcpyAsync(h_count, ctrl_slot(k, tnsx::CTRL_NFILTERED), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-		return TNSX_OK;
-	};
-
 	// slab size, regions and record storage of a pool pass.  payload[r]: ints of records region r is expected to receive (nullptr: dry
 	// pass); asked[r]: what the waves asked region r for in the previous pass with the same slab size -- records plus the unused ends
 	// of their slabs, which is what the region has to hold (nullptr after a dry pass, whose slabs have another size: the regions then
@@ -1057,6 +919,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		pr.n_query = c->sets[jb.i].n_query < 0 ? n_i : std::min(n_i, c->sets[jb.i].n_query);
 		HIPCHK(c, pr.offs_orig.reserve((size_t)std::max(n_i, 1) * sizeof(uint64_t)));
 		jb.pool = !c->opt.exact_layout && n_i > 0;
+		pr.heavy_skipped = false;
 		if (jb.pool) {
 			// capacity: last run's exact need + 12 % + room for every wave's partly used slab.  A pair that runs for the first time
 			// makes a DRY pass first (same kernels, capacity 0: everything is counted, nothing is written), which the overflow
@@ -1068,13 +931,238 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			const size_t max_cells = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_i, n_cells));
 			HIPCHK(c, pr.heavy.reserve(max_cells * sizeof(uint2)));
 			HIPCHK(c, pr.heavy2.reserve(max_cells * sizeof(uint2)));
-			const tnsx_status r = launch_pool(k);
-			if (r != TNSX_OK) return r;
 		}
 		else {
 			HIPCHK(c, pr.counts.reserve((size_t)std::max(n_i, 1) * sizeof(uint32_t)));
 			HIPCHK(c, pr.offs_sorted.reserve(((size_t)n_i + 1) * sizeof(uint64_t)));
 			HIPCHK(c, c->scan_temp.reserve(tnsx::scan_temp_bytes((size_t)n_i)));
+		}
+	}
+
+	// ---- ONE launch in front of everything (round 4: four kernels of a steady-state step, ~5 us of dispatch each): the words of this attempt and
+	//      the occupied-cell counts of the sets that are built start at zero, the table entries the previous run set are cleared, every pool
+	//      pass gets the hot words of its control block and its region table
+	const int t_build0 = tm.mark();
+	{
+		tnsx::RunBeginArgs rb{};
+		rb.words = d_words; rb.n_words = WB * (size_t)(n_sets + 1); rb.n_occ = c->n_occ.as<uint32_t>();
+		for (int si = 0; si < n_sets; si++) {
+			PointSet& s = c->sets[si];
+			if (keeps_its_build(s)) continue;
+			if (si < 64) rb.sets |= 1ull << si;
+			else HIPCHK(c, hipMemsetAsync(c->n_occ.as<uint32_t>() + si, 0, sizeof(uint32_t), st));
+			// the table is needed even for empty sets (they can be searched into)
+			const void* old_table = s.table.p;
+			HIPCHK(c, s.table.reserve(n_cells * sizeof(uint2)));
+			if (s.table.p != old_table || s.table_state == 2) HIPCHK(c, hipMemsetAsync(s.table.p, 0, s.table.cap, st));   // new or unknown: all of it
+			else if (s.table_state == 1 && s.table_dirty > 0) {
+				if (rb.n_clear < tnsx::RUN_BEGIN_MAX_SETS) rb.clear[rb.n_clear++] = { s.occ.as<uint2>(), s.table.as<uint2>(), s.table_dirty };
+				else tnsx::launch_table_clear(s.occ.as<uint2>(), s.table_dirty, s.table.as<uint2>(), st);
+			}
+			s.table_state = 0; s.table_dirty = 0;
+			// the bucket build's first pass in one read: the previous build of this set on this grid left a window per bucket (see k_bucket_scatter);
+			// an overflowing window raises the guard flag like a point outside the box does
+			int nb = 0;
+			s.bk_now = s.n > 0 && tnsx::cell_build_uses_buckets(s.n, key_bits, c->opt.exact_layout != 0, c->opt.bucket_build_min_points, &nb);
+			s.bk_used = false;
+			if (s.bk_now) {
+				const void* old_win = s.bk_win.p;
+				HIPCHK(c, s.bk_win.reserve((size_t)nb * sizeof(uint2)));
+				HIPCHK(c, s.bk_cur.reserve((size_t)nb * tnsx::BUCKET_CURSOR_STRIDE * sizeof(uint32_t)));
+				if (s.bk_win.p != old_win || s.bk_buckets != nb) s.bk_gen = 0;
+				s.bk_used = speculate && c->opt.temporal_reuse != 0 && s.bk_gen == c->grid_gen && s.bk_gen != 0 && rb.n_zero < tnsx::RUN_BEGIN_MAX_SETS &&
+				            (int64_t)s.n <= (int64_t)s.bk_n + s.bk_n / 16 && (int64_t)s.n >= (int64_t)s.bk_n - s.bk_n / 16;
+				if (s.bk_used) { rb.zero[rb.n_zero] = s.bk_cur.as<uint32_t>(); rb.n_zero_words[rb.n_zero] = (uint32_t)nb * tnsx::BUCKET_CURSOR_STRIDE; rb.n_zero++; }
+				s.bk_buckets = nb;
+			}
+			else s.bk_gen = 0;
+		}
+		for (size_t k = 0; k < jobs.size() && rb.n_pool < tnsx::RUN_BEGIN_MAX_POOLS; k++) {
+			Job& jb = jobs[k];
+			if (!jb.pool) continue;
+			const PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
+			tnsx::RunBeginPool& bp = rb.pool[rb.n_pool++];
+			const bool count_only = c->debug_nostore || pr.dry;
+			for (int r = 0; r < PairResult::NR; r++) { bp.regions[2 * r] = pr.region_base[r]; bp.regions[2 * r + 1] = count_only ? 0ull : pr.region_cap[r]; }
+			bp.ctrl = ctrl_slot(k, 0); bp.offs = pr.offs_orig.as<uint64_t>(); bp.n_shared_empty = pr.shared_empty ? (size_t)pr.n_query : 0; bp.records = pr.records.as<int>();
+			jb.begun = true;
+		}
+		tnsx::launch_run_begin(rb, st);
+	}
+	for (int si = 0; si < n_sets; si++) {
+		PointSet& s = c->sets[si];
+		const bool cacheable = !s.user_ids && s.n > 0;
+		if (keeps_its_build(s)) {
+			// taken to be unchanged: only its checksum is computed (and compared after the run)
+			tnsx::launch_set_checksum(s.d_xyz, variable ? s.d_radii : nullptr, s.n, d_words + WB * (size_t)(1 + si), st);
+			skipped[(size_t)si] = 1;
+			S.n_cached_sets++;
+			continue;
+		}
+		HIPCHK(c, s.occ.reserve((size_t)std::max(s.n, 1) * sizeof(uint2)));   // (after the clear, which reads the previous list, has been enqueued)
+		s.built_gen = 0;
+		if (s.n == 0) continue;
+		s.table_state = 2;   // until this run's occupied-cell count has reached the host
+		for (int k = 0; k < 2; k++) {
+			// ([1] is the intermediate array of the bucket build: its buckets lie in windows with some slack)
+			HIPCHK(c, s.xyzi[k].reserve((k == 1 && s.bk_now ? tnsx::bucket_window_slots(s.n, s.bk_buckets) : (size_t)s.n) * sizeof(float4)));
+			if (variable) HIPCHK(c, s.r2[k].reserve((size_t)s.n * sizeof(float)));
+		}
+		HIPCHK(c, c->sort_temp.reserve(tnsx::cell_build_temp_bytes(s.n)));
+		tnsx::CellSortBuffers cb;
+		for (int k = 0; k < 2; k++) { cb.xyzi[k] = s.xyzi[k].as<float4>(); cb.r2[k] = s.r2[k].as<float>(); }
+		tnsx::BuildGuard gd;
+		if (speculate) {
+			for (int d = 0; d < 3; d++) { gd.lo[d] = c->grid_lo[d]; gd.hi[d] = c->grid_hi[d]; }
+			gd.r_max = c->grid_r_max;
+			gd.flag = reinterpret_cast<uint32_t*>(d_words);
+			if (c->grid_trimmed) {
+				// the grid covers the bulk of the points only: whoever is outside it is binned into its border cells (exact), so the box that
+				// must hold is the WORLD box (whose update needs the true bounds); the points outside the grid's own box are counted, and
+				// the grid is laid out afresh when they become many
+				for (int d = 0; d < 3; d++) { gd.soft_lo[d] = c->grid_lo[d]; gd.soft_hi[d] = c->grid_hi[d]; gd.lo[d] = c->world[d]; gd.hi[d] = c->world[3 + d]; }
+				gd.outside = d_words + tnsx::CHK_STRIDE;
+			}
+		}
+		if (cacheable) gd.checksum = d_words + WB * (size_t)(1 + si);
+		if (s.user_ids) HIPCHK(c, s.orig_sorted.reserve((size_t)s.n * sizeof(uint32_t)));
+		// sort + cell table + occupied-cell list (two-pass bucket build where the key fits; the exact layout keeps the stable sort)
+		int passes = 0;
+		const uint32_t q_limit = (s.n_query >= 0 && s.n_query < s.n) ? (uint32_t)s.n_query : 0xffffffffu;
+		s.sorted_buf = tnsx::launch_cell_build(s.d_xyz, variable ? s.d_radii : nullptr, s.n, g, key_bits, cb, c->sort_temp.p, s.user_ids,
+		                                       s.user_ids ? s.orig_sorted.as<uint32_t>() : nullptr, gd, q_limit, c->opt.exact_layout != 0,
+		                                       c->opt.bucket_build_min_points, s.table.as<uint2>(), s.occ.as<uint2>(), c->n_occ.as<uint32_t>() + si, &passes,
+		                                       tnsx::BucketWindows{ s.bk_used && gd.flag != nullptr, s.bk_now ? s.bk_win.as<uint2>() : nullptr, s.bk_cur.as<uint32_t>() }, st);
+		S.radix_passes = passes;
+		if (s.bk_used) S.one_read_builds++;
+	}
+	// (stage times: the build is everything from the first launch of the attempt to here -- table clear and control blocks included; no event
+	//  between its kernels, every event record between two kernels is a bubble of 6-9 us)
+	int t_build1 = -1;
+
+	// ---- per active pair: the query
+	auto make_args = [&](const Job& jb, PairResult& pr, size_t k) {
+		const PointSet& A = c->sets[jb.i];
+		const PointSet& B = c->sets[jb.j];
+		tnsx::QueryArgs a{};
+		a.occ_i = A.occ.as<uint2>(); a.n_occ_i = c->n_occ.as<uint32_t>() + jb.i;
+		a.table_i = A.table.as<uint2>();
+		a.xyzi_i = A.xyzi[A.sorted_buf].as<float4>(); a.r2_i = A.r2[A.sorted_buf].as<float>();
+		a.orig_i = A.user_ids ? A.orig_sorted.as<uint32_t>() : nullptr;
+		a.table_j = B.table.as<uint2>(); a.xyzi_j = B.xyzi[B.sorted_buf].as<float4>(); a.r2_j = B.r2[B.sorted_buf].as<float>();
+		a.r2_fixed = c->radius_sq;
+		a.query_limit = A.n_query < 0 ? 0xffffffffu : (uint32_t)A.n_query;
+		a.n_points_i = (uint32_t)A.n;
+		a.g = g;
+		a.counts = pr.counts.as<uint32_t>();
+		a.offs_sorted = pr.offs_sorted.as<uint64_t>();
+		a.records = pr.records.as<int>();
+		a.offs_by_orig = pr.offs_orig.as<uint64_t>();
+		a.pool_cursor = reinterpret_cast<unsigned long long*>(ctrl_slot(k, tnsx::CTRL_CURSOR));
+		a.pool_regions = reinterpret_cast<const unsigned long long*>(ctrl_slot(k, tnsx::CTRL_REGIONS));
+		a.tickets = ctrl_slot(k, tnsx::CTRL_TICKETS);
+		a.n_heavy = ctrl_slot(k, tnsx::CTRL_NHEAVY);
+		a.tickets2 = ctrl_slot(k, tnsx::CTRL_TICKETS2);
+		a.n_heavy2 = ctrl_slot(k, tnsx::CTRL_NHEAVY2);
+		a.heavy = pr.heavy.as<uint2>();
+		a.heavy2 = pr.heavy2.as<uint2>();
+		// (the worklist of the group formulation shares buffer and counter with the candidate-presence filter: that one is for pairs of two
+		//  different sets, the group formulation for a set searched in itself)
+		a.heavy0 = pr.filtered.as<uint2>();
+		a.n_heavy0 = ctrl_slot(k, tnsx::CTRL_NFILTERED);
+		a.abort_flag = speculate ? reinterpret_cast<const uint32_t*>(d_words) : nullptr;
+		a.pool_slab = pr.pool_slab;
+		a.pool_slab_heavy = std::max<uint32_t>(pr.pool_slab, 8192u);
+		a.shared_empty = jb.pool && jb.i != jb.j ? 1u : 0u;
+		if (a.shared_empty && pr.n_query > 0) {
+			// the query walks the cells that have candidates at all (launch_mark_cells + launch_filter_marked, enqueued by launch_pool)
+			a.occ_i = pr.filtered.as<uint2>();
+			a.n_occ_i = ctrl_slot(k, tnsx::CTRL_NFILTERED);
+		}
+		return a;
+	};
+	tnsx::QueryConfig qc{};
+	qc.arith = c->opt.arith;
+	qc.variable = variable;
+	qc.symmetric = variable && c->symmetric;   // TreeNSearch.cpp:2431
+	qc.blocks_per_cu = c->opt.query_blocks_per_cu;
+	qc.fast_blocks_per_cu = c->opt.fast_blocks_per_cu;
+
+	// tiers: bit 0 = begin (if the pass was not begun by launch_run_begin) + candidate-presence filter + first tier, bit 1 = the heavy tiers
+	auto launch_pool = [&](size_t k, int tiers, bool fresh) -> tnsx_status {
+		const Job& jb = jobs[k];
+		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
+		if ((tiers & 1) && (fresh || !jb.begun)) {
+			// the region table of this pass (all capacities 0: nothing is written, everything is counted).
+			// A pair of two different sets: most query cells may have no candidate at all (a fluid searched in its boundary).  Int 0 of
+			// the pool is THE empty record and every offset starts out pointing at it: cells without candidates then cost no
+			// allocation, no record and no scattered 8-byte offset store.
+			unsigned long long regions[2 * PairResult::NR];
+			const bool count_only = c->debug_nostore || pr.dry;
+			for (int r = 0; r < PairResult::NR; r++) { regions[2 * r] = pr.region_base[r]; regions[2 * r + 1] = count_only ? 0ull : pr.region_cap[r]; }
+			tnsx::launch_pool_begin(regions, ctrl_slot(k, 0), pr.offs_orig.as<uint64_t>(),
+			                        pr.shared_empty ? (size_t)pr.n_query : 0, pr.records.as<int>(), st);
+		}
+		const int t0 = tm.mark();   // (behind the last kernel of the build / of the previous pass: the bracket holds the pass's query kernels only)
+		if (pr.shared_empty && (tiers & 1)) {
+			const PointSet& A = c->sets[jb.i];
+			const size_t max_cells = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pr.n_i, n_cells));
+			HIPCHK(c, pr.filtered.reserve(max_cells * sizeof(uint2)));
+			{
+				const PointSet& B = c->sets[jb.j];
+				const void* old_map = c->cell_map.p;
+				HIPCHK(c, c->cell_map.reserve(n_cells));
+				if (c->cell_map.p != old_map) HIPCHK(c, hipMemsetAsync(c->cell_map.p, 0, c->cell_map.cap, st));   // (all zero between uses)
+				const size_t max_cells_j = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(B.n, 1), n_cells));
+				unsigned char* map = c->cell_map.as<unsigned char>();
+				tnsx::launch_mark_cells(B.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.j, g, map, 1, max_cells_j, st);
+				tnsx::launch_filter_marked(A.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.i, map, pr.filtered.as<uint2>(), ctrl_slot(k, tnsx::CTRL_NFILTERED), max_cells, st);
+				tnsx::launch_mark_cells(B.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.j, g, map, 0, max_cells_j, st);
+			}
+		}
+		if (pr.n_i > 0) {
+			qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_POOL;
+			// opt-in (tnsx_options.query_formulation = 1), fixed radius, a set searched in itself: the group formulation (tnsx_query_group.hip)
+			// in front of the cell kernels, unless it was switched off for this pair
+			pr.groups_now = !variable && jb.i == jb.j && c->opt.query_formulation == 1 && !pr.groups_off && c->grid_h * c->grid_h > 1e-30f;
+			qc.groups = pr.groups_now;
+			if (pr.groups_now) { HIPCHK(c, pr.filtered.reserve((size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pr.n_i, n_cells)) * sizeof(uint2))); tiers = 3; }
+			qc.tiers = tiers;
+			tnsx::launch_query(make_args(jb, pr, k), qc, c->n_cus, st);
+			qc.groups = false; qc.tiers = 3;
+		}
+		pr.heavy_skipped = !(tiers & 2);
+		const int t1 = tm.mark();
+		span(ST_FILL, t0, t1);
+		uint32_t* const h_count = pr.shared_empty ? h_filt + k : (pr.groups_now && pr.n_i > 0 ? h_left + k : nullptr);   // (the two worklists share a counter, see make_args)
+		if (defer_readback && run_end.n_jobs < tnsx::RUN_END_MAX_JOBS) {
+			tnsx::RunEndJob& rj = run_end.job[run_end.n_jobs++];
+			rj.ctrl_cursor = ctrl_slot(k, tnsx::CTRL_CURSOR); rj.h_ctrl = reinterpret_cast<unsigned long long*>(h_ctrl + HC * k);
+			rj.d_count = ctrl_slot(k, tnsx::CTRL_NFILTERED); rj.h_count = h_count;
+			rj.d_heavy = ctrl_slot(k, tnsx::CTRL_NHEAVY); rj.h_heavy = h_heavy + k;
+			return TNSX_OK;
+		}
+		HIPCHK(c, hipMemcpy2DAsync(h_ctrl + HC * k, tnsx::POOL_CTRL_WORDS * sizeof(uint64_t), ctrl_slot(k, tnsx::CTRL_CURSOR), tnsx::CTRL_STRIDE_U32 * sizeof(uint32_t),
+		                           tnsx::POOL_CTRL_WORDS * sizeof(uint64_t), PairResult::NR, hipMemcpyDeviceToHost, st));
+		if (h_count) HIPCHK(c, hipMemcpyAsync(h_count, ctrl_slot(k, tnsx::CTRL_NFILTERED), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+		HIPCHK(c, hipMemcpyAsync(h_heavy + k, ctrl_slot(k, tnsx::CTRL_NHEAVY), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+		return TNSX_OK;
+	};
+
+	t_build1 = tm.mark();
+	span(ST_SORT, t_build0, t_build1);
+	for (size_t k = 0; k < jobs.size(); k++) {
+		Job& jb = jobs[k];
+		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
+		const int n_i = pr.n_i;
+		if (jb.pool) {
+			// the heavy tiers (cells with more than 512 candidates or more than 64 query points) are not launched when the previous run of the
+			// pair had nothing for them: what the first tier passes on is counted, and they run after the synchronisation if it did
+			const bool light = speculate && !pr.dry && pr.heavy_known && pr.heavy_cells == 0;
+			const tnsx_status r = launch_pool(k, light ? 1 : 3, false);
+			if (r != TNSX_OK) return r;
+		}
+		else {
 			const int t0 = tm.mark();
 			if (n_i > 0) {
 				qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_COUNT;
@@ -1091,7 +1179,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	run_end.words = d_words; run_end.h_words = reinterpret_cast<unsigned long long*>(h_words); run_end.n_words = WB * (size_t)(n_sets + 1);
 	tnsx::launch_run_end(run_end, st);
 	defer_readback = false;
-	HIPCHK(c, hipStreamSynchronize(st));   // record totals / pool cursors / what was speculated on are needed on the host
+	{ const tnsx_status r = sync_stream(c); if (r != TNSX_OK) return r; }   // record totals / pool cursors / what was speculated on are needed on the host
 
 	// ---- were the assumptions of this attempt right?
 	for (int si = 0; si < n_sets; si++) {
@@ -1116,6 +1204,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		s.chk_valid = cacheable; s.chk_value = chk_now;
 		s.chk_xyz = s.user_xyz; s.chk_radii = s.user_radii; s.chk_n = s.n; s.chk_double = s.is_double;
 		if (!skipped[(size_t)si] && s.n > 0) s.built_gen = c->grid_gen;
+		if (!skipped[(size_t)si] && s.bk_now) { s.bk_gen = c->grid_gen; s.bk_n = s.n; }   // (this build wrote the windows of the next one)
 	}
 	if (wrong) { *redo = true; S.speculation_redos++; return TNSX_OK; }
 
@@ -1127,6 +1216,14 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			// what every XCD produced: ints it asked for - ints it left unused.  The pass failed if a wave found both its own region and the
 			// overflow region full (or if it was a dry pass): size the pool by what was counted and redo this pair's pass.
 			const uint64_t* hc = h_ctrl + HC * k;
+			if (pr.heavy_skipped && h_heavy[k] != 0u) {
+				// the first tier did pass cells on after all: the two heavy tiers now, on the same control block
+				const tnsx_status r = launch_pool(k, 2, false);
+				if (r != TNSX_OK) return r;
+				HIPCHK(c, hipStreamSynchronize(st));
+				S.heavy_catchups++;
+			}
+			pr.heavy_cells = h_heavy[k]; pr.heavy_known = true;
 			uint64_t payload[PairResult::NR], asked_now[PairResult::NR];
 			auto read_counters = [&]() {
 				n_neighbors = 0;
@@ -1152,9 +1249,10 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 					S.pool_retries++;
 				}
 				{ const tnsx_status r = size_pool(pr, payload, was_dry ? nullptr : asked_now, !was_dry); if (r != TNSX_OK) return r; }
-				const tnsx_status r = launch_pool(k);
+				const tnsx_status r = launch_pool(k, 3, true);
 				if (r != TNSX_OK) return r;
 				HIPCHK(c, hipStreamSynchronize(st));
+				pr.heavy_cells = h_heavy[k];
 				read_counters();
 			}
 			pr.n_records = pr.shared_empty ? 1 : 0;
@@ -1227,7 +1325,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	}
 	const int e_end = tm.mark();
 	span(ST_MIRROR, e_m0, e_end);
-	HIPCHK(c, hipStreamSynchronize(st));   // run() is synchronous like the reference
+	{ const tnsx_status r = sync_stream(c); if (r != TNSX_OK) return r; }   // run() is synchronous like the reference
 
 	// ---- statistics: algorithmic bytes with the measured Q, E, C
 	{
@@ -1562,6 +1660,7 @@ tnsx_status tnsx_set_query_count(tnsx_context* c, int set_i, int n_query)
 // (tnsx_slab.cpp) the stream / device a single-device context works on
 void* tnsx_internal_stream(tnsx_context* c) { return c && !c->multi ? (void*)c->stream : nullptr; }
 int tnsx_internal_device(tnsx_context* c) { return c ? c->device : 0; }
+void tnsx_internal_set_sync_timeout(tnsx_context* c, double seconds) { if (c) c->sync_timeout_s = seconds; }
 
 tnsx_status tnsx_get_stats(const tnsx_context* c, tnsx_stats* out)
 {

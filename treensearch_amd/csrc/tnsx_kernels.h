@@ -57,9 +57,17 @@ struct BuildGuard {
 // else launch_cell_sort + launch_cell_table.  query_limit: points with original index >= query_limit are candidates only and must
 // come behind the others inside a cell; stable_order: keep the input order inside a cell (exact layout).  temp: cell_build_temp_bytes(n).
 size_t cell_build_temp_bytes(int n);
+// The one-read form of the bucket build's first pass (round 4, tnsx_build.hip k_bucket_scatter): every bucket has a window {first slot, capacity} of the
+// intermediate array xyzi[1] -- written by the previous build of the same set on the same grid (win, n_buckets entries; every build writes the next
+// run's) -- and a cursor (cursors[b * BUCKET_CURSOR_STRIDE], zero at the start of the run: launch_run_begin).  use = false: the histogram pass.
+// xyzi[1] must hold bucket_window_slots(n, n_buckets) points whenever win is given.
+static constexpr int BUCKET_CURSOR_STRIDE = 32;   // 128 bytes: returning atomics on one cache line serialise
+struct BucketWindows { bool use = false; uint2* win = nullptr; uint32_t* cursors = nullptr; };
+bool cell_build_uses_buckets(int n, int key_bits, bool stable_order, int bucket_min_points, int* n_buckets);
+size_t bucket_window_slots(int n, int n_buckets);
 int launch_cell_build(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, const int* ids,
                       uint32_t* orig_sorted, const BuildGuard& gd, uint32_t query_limit, bool stable_order, int bucket_min_points, uint2* table, uint2* occ,
-                      uint32_t* n_occ, int* passes_out, hipStream_t s);
+                      uint32_t* n_occ, int* passes_out, const BucketWindows& bw, hipStream_t s);
 int launch_cell_sort(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, const int* ids,
                      uint32_t* orig_sorted, const BuildGuard& gd, hipStream_t s);
 // the same checksum on its own (sets whose build is skipped)
@@ -104,6 +112,8 @@ struct QueryArgs {
 	uint2* heavy;                      // worklist {first sorted position, key} of the cells the fast kernel skipped
 	uint32_t* n_heavy;                 // its length (zeroed before the launch)
 	uint32_t* tickets2; uint2* heavy2; uint32_t* n_heavy2;   // the same for the second tier (fat kernel -> general kernel)
+	const uint32_t* abort_flag;   // the run's guard word (or nullptr): non-zero = the build already knows that this attempt will be thrown away (a point outside the
+	                              // reused grid, an overflowed window of the one-read bucket pass -- the sorted arrays then have HOLES): the query kernels do nothing
 	uint2* heavy0; uint32_t* n_heavy0;   // group formulation (tnsx_query_group.hip): worklist of the cells it passes on to the three cell tiers (zeroed before)
 };
 // Control block of one pool pass.  Every hot counter sits CTRL_STRIDE_U32 words (4352 B) from the next: the L2 serialises
@@ -130,6 +140,8 @@ struct QueryConfig {
 	bool groups = false;   // QUERY_POOL with a fixed radius: the group formulation (tnsx_query_group.hip) instead of the three cell tiers
 	int group_waves_per_cu = 0;   // its launch width (waves per CU); 0 = default
 	int blocks_per_cu = 0, fast_blocks_per_cu = 0;   // launch widths (workgroups per CU) of the general / the fast kernels; 0 = default
+	int tiers = 3;   // QUERY_POOL: bit 0 = the first tier, bit 1 = the two heavy tiers over the first tier's reject list (launched later, or not at all, when
+	                 // the previous run of the pair rejected nothing: two empty launches are ~10 us of a step)
 };
 void launch_query(const QueryArgs& a, const QueryConfig& c, int n_compute_units, hipStream_t s);
 // group formulation of a pool pass with a fixed radius (tnsx_query_group.hip): k_query_groups over the occupied cells, then the three cell tiers
@@ -157,18 +169,38 @@ void launch_slab_unpack(const float* rows, uint32_t n_rows, const unsigned int* 
 void launch_slab_ids(const long long* gids, int n, int* ids, unsigned int* flag, hipStream_t s);          // ids[i] = (int)gids[i]; *flag on overflow
 void launch_slab_flag_gt(const float* v, int n, float limit, unsigned int* flag, hipStream_t s);         // *flag = 1 if any v[i] > limit
 void launch_slab_x_range(const float* xyz, int n, float* minmax, hipStream_t s);                          // minmax[0] = min(.., x), minmax[1] = max(.., x) (NaN skipped)
+// redistribution (tnsx_slab_redistribute_begin): slab d owns cuts[d] <= x < cuts[d + 1] (world <= 64).  count_only: counters[d] += the points of slab d;
+// else rows [x, y, z, (r,) gid_lo, gid_hi] of W floats, the points of slab d behind row first[d] in the order counters[d] (zeroed before) hands out
+void launch_slab_dest_rows(bool count_only, const float* xyz, const float* radii, const long long* gids, int n, const float* cuts, int world, unsigned int* counters,
+                           const unsigned int* first, float* rows, int W, hipStream_t s);
+void launch_slab_rows_to_points(const float* rows, size_t n_rows, int W, float* xyz, float* radii, long long* gids, hipStream_t s);
 
 // ---- start of a pool pass: the hot words of the pass's control block `ctrl` (CTRL_SLOTS slots) are zeroed and
 //      regions[2 * (POOL_REGIONS + 1)] = {first int, capacity} of every region -> the device table the query reads (slot CTRL_REGIONS);
-//      n_shared_empty > 0 (a pair of two different sets): offs[0..n) = 0 and records[0] = 0, the shared empty record at int 0 of the pool
+//      n_shared_empty > 0 (a pair of two different sets): offs[0..n) = 0 and records[0] = 0, the shared empty record at int 0 of the pool.
+//      (On its own only for the repeat of a pass and for runs with more pool passes than launch_run_begin takes.)
 void launch_pool_begin(const unsigned long long* regions, uint32_t* ctrl, uint64_t* offs, size_t n_shared_empty, int* records, hipStream_t s);
-// start of a run: words[0..n_words) = 0 (guard flag, partial checksums) and n_occ[si] = 0 for every set si whose bit is set in `sets` (si < 64)
-void launch_run_begin(unsigned long long* words, size_t n_words, uint32_t* n_occ, unsigned long long sets, hipStream_t s);
+// ---- start of a run, ONE launch (round 4; every kernel of a step costs ~5 us of dispatch whatever it does):
+//      words[0..n_words) = 0 (guard flag, partial checksums), n_occ[si] = 0 for every set si whose bit is set in `sets` (si < 64),
+//      zero[k][0..n_zero[k]) = 0 (the cursors of the one-read bucket pass),
+//      clear[k]: the table entries of the first n cells of a set's previous occupied-cell list are zeroed (what launch_table_clear does),
+//      pool[k]:  what launch_pool_begin does, for every pool pass of the run
+static constexpr int RUN_BEGIN_MAX_SETS = 8, RUN_BEGIN_MAX_POOLS = 8;
+struct RunBeginClear { const uint2* occ; uint2* table; uint32_t n; };
+struct RunBeginPool { unsigned long long regions[2 * (POOL_REGIONS + 1)]; uint32_t* ctrl; uint64_t* offs; size_t n_shared_empty; int* records; };
+struct RunBeginArgs {
+	unsigned long long* words; size_t n_words; uint32_t* n_occ; unsigned long long sets;
+	int n_clear; RunBeginClear clear[RUN_BEGIN_MAX_SETS];
+	int n_zero; uint32_t* zero[RUN_BEGIN_MAX_SETS]; uint32_t n_zero_words[RUN_BEGIN_MAX_SETS];
+	int n_pool; RunBeginPool pool[RUN_BEGIN_MAX_POOLS];
+};
+void launch_run_begin(const RunBeginArgs& a, hipStream_t s);
 
 // ---- end of a run: what the host reads after its one synchronisation, written into pinned host memory by one kernel (h_* are host pointers
 //      of hipHostMalloc'ed memory; d_count / h_count may be nullptr)
 static constexpr int RUN_END_MAX_JOBS = 8;
-struct RunEndJob { const uint32_t* ctrl_cursor; unsigned long long* h_ctrl; const uint32_t* d_count; uint32_t* h_count; };
+struct RunEndJob { const uint32_t* ctrl_cursor; unsigned long long* h_ctrl; const uint32_t* d_count; uint32_t* h_count;
+                   const uint32_t* d_heavy; uint32_t* h_heavy; /* length of the first tier's reject list (nullptr: not wanted) */ };
 struct RunEndArgs { RunEndJob job[RUN_END_MAX_JOBS]; int n_jobs; const uint32_t* n_occ; uint32_t* h_nocc; int n_sets; const unsigned long long* words; unsigned long long* h_words; size_t n_words; };
 void launch_run_end(const RunEndArgs& a, hipStream_t s);
 

@@ -397,6 +397,83 @@ void launch_slab_x_range(const float* xyz, int n, float* minmax, hipStream_t s)
 }
 
 // =====================================================================================================
+// slab layer, redistribution (the one all-to-all of a decomposition: every point goes to the slab that owns its x).
+//   k_slab_dest_rows<COUNT = true>   counts[d] += points with cuts[d] <= x < cuts[d + 1] (LDS-aggregated; NaN x: no point, goes nowhere)
+//   k_slab_dest_rows<COUNT = false>  the same points as rows [x, y, z, (r,) gid_lo, gid_hi] at rows[(first[d] + k) * W], k from the cursor of d
+//   k_slab_rows_to_points            rows -> xyz / radii / 64-bit ids
+// The slab of a point is found by counting the interior cuts at or below x (world <= 64: a handful of compares on wave-uniform values).
+// =====================================================================================================
+static constexpr int RD_MAX_WORLD = 64;
+struct SlabCuts { float c[RD_MAX_WORLD + 1]; int world; };
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_slab_dest_rows(const float* __restrict__ xyz, const float* __restrict__ radii, const long long* __restrict__ gids, int n, SlabCuts cuts,
+                                                        unsigned int* __restrict__ counters, const unsigned int* __restrict__ first, float* __restrict__ rows, int W)
+{
+	__shared__ unsigned int h[RD_MAX_WORLD], base[RD_MAX_WORLD];
+	if (threadIdx.x < RD_MAX_WORLD) h[threadIdx.x] = 0u;
+	__syncthreads();
+	constexpr int ITEMS = 8;
+	int dest[ITEMS];
+	unsigned int rank[ITEMS];
+	const size_t b0 = (size_t)blockIdx.x * (256 * ITEMS);
+	#pragma unroll
+	for (int i = 0; i < ITEMS; i++) {
+		const size_t p = b0 + (size_t)i * 256 + threadIdx.x;
+		dest[i] = -1; rank[i] = 0;
+		if (p < (size_t)n) {
+			const float x = xyz[3 * p];
+			if (x == x) {
+				int d = 0;
+				for (int k = 1; k < cuts.world; k++) d += x >= cuts.c[k] ? 1 : 0;   // cuts ascending: the number of interior cuts at or below x
+				dest[i] = d;
+				rank[i] = atomicAdd(&h[d], 1u);
+			}
+		}
+	}
+	__syncthreads();
+	if ((int)threadIdx.x < cuts.world) { const unsigned int c = h[threadIdx.x]; base[threadIdx.x] = c ? atomicAdd(counters + threadIdx.x, c) : 0u; }
+	if (COUNT) return;
+	__syncthreads();
+	#pragma unroll
+	for (int i = 0; i < ITEMS; i++) {
+		if (dest[i] < 0) continue;
+		const size_t p = b0 + (size_t)i * 256 + threadIdx.x;
+		float* r = rows + ((size_t)first[dest[i]] + base[dest[i]] + rank[i]) * (size_t)W;
+		r[0] = xyz[3 * p]; r[1] = xyz[3 * p + 1]; r[2] = xyz[3 * p + 2];
+		if (radii) r[3] = radii[p];
+		const unsigned long long g = (unsigned long long)gids[p];
+		r[W - 2] = __uint_as_float((uint32_t)g); r[W - 1] = __uint_as_float((uint32_t)(g >> 32));
+	}
+}
+void launch_slab_dest_rows(bool count_only, const float* xyz, const float* radii, const long long* gids, int n, const float* cuts, int world, unsigned int* counters,
+                           const unsigned int* first, float* rows, int W, hipStream_t s)
+{
+	if (n <= 0) return;
+	SlabCuts c;
+	c.world = world;
+	for (int k = 0; k <= world && k <= RD_MAX_WORLD; k++) c.c[k] = cuts[k];
+	const unsigned blocks = (unsigned)(((size_t)n + 2047) / 2048);
+	if (count_only) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slab_dest_rows<true>), dim3(blocks), dim3(256), 0, s, xyz, radii, gids, n, c, counters, first, rows, W);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slab_dest_rows<false>), dim3(blocks), dim3(256), 0, s, xyz, radii, gids, n, c, counters, first, rows, W);
+}
+__global__ void __launch_bounds__(256) k_slab_rows_to_points(const float* __restrict__ rows, size_t n_rows, int W, float* __restrict__ xyz, float* __restrict__ radii,
+                                                             long long* __restrict__ gids)
+{
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_rows; i += (size_t)gridDim.x * 256) {
+		const float* r = rows + i * (size_t)W;
+		xyz[3 * i] = r[0]; xyz[3 * i + 1] = r[1]; xyz[3 * i + 2] = r[2];
+		if (radii) radii[i] = r[3];
+		gids[i] = (long long)(((unsigned long long)__float_as_uint(r[W - 1]) << 32) | __float_as_uint(r[W - 2]));
+	}
+}
+void launch_slab_rows_to_points(const float* rows, size_t n_rows, int W, float* xyz, float* radii, long long* gids, hipStream_t s)
+{
+	if (!n_rows) return;
+	const unsigned blocks = (unsigned)std::min<size_t>((n_rows + 255) / 256, 8192);
+	hipLaunchKernelGGL(k_slab_rows_to_points, dim3(blocks), dim3(256), 0, s, rows, n_rows, W, xyz, radii, gids);
+}
+
+// =====================================================================================================
 // x-plane histogram (multi-GPU slabs: balanced cuts).  hist[b] += points with clamp(trunc((x - x0) * inv_dx), 0, n_bins - 1) == b.
 // Every block keeps a private copy of the bins in LDS (n_bins <= XH_LDS_BINS) and adds its non-zero bins to the global
 // histogram at the end; wider histograms go straight to global atomics.
@@ -461,20 +538,21 @@ void launch_translate_records(int* records, const uint64_t* offs_by_orig, int n_
 // (int 0 of the pool, count 0) -- one launch instead of a copy and three memsets
 // =====================================================================================================
 struct PoolRegionTable { unsigned long long v[2 * (POOL_REGIONS + 1)]; };
+__device__ __forceinline__ void pool_begin_block(const unsigned long long* __restrict__ regions, uint32_t* __restrict__ ctrl)
+{
+	// the control block of the pass: the hot words of every slot (cursor + neighbour / waste counters: 18 64-bit words; ticket counters and
+	// worklist lengths: the first word) start at zero -- 141 x 144 bytes instead of a memset of the whole 600 KB block
+	if (threadIdx.x < CTRL_SLOTS) {
+		uint32_t* slot = ctrl + (size_t)threadIdx.x * CTRL_STRIDE_U32;
+		for (int w = 0; w < 2 * POOL_CTRL_WORDS; w++) slot[w] = 0u;
+	}
+	__syncthreads();
+	unsigned long long* table = reinterpret_cast<unsigned long long*>(ctrl + (size_t)CTRL_REGIONS * CTRL_STRIDE_U32);
+	if (threadIdx.x < 2 * (POOL_REGIONS + 1)) table[threadIdx.x] = regions[threadIdx.x];
+}
 __global__ void __launch_bounds__(256) k_pool_begin(PoolRegionTable t, uint32_t* __restrict__ ctrl, uint64_t* __restrict__ offs, size_t n, int* __restrict__ records)
 {
-	if (blockIdx.x == 0) {
-		// the control block of the pass: the hot words of every slot (cursor + neighbour / waste counters: 18 64-bit words; ticket counters and
-		// worklist lengths: the first word) start at zero -- 141 x 144 bytes instead of a memset of the whole 600 KB block, and no fill
-		// command (with the bubble it brings) between the build and the query
-		if (threadIdx.x < CTRL_SLOTS) {
-			uint32_t* slot = ctrl + (size_t)threadIdx.x * CTRL_STRIDE_U32;
-			for (int w = 0; w < 2 * POOL_CTRL_WORDS; w++) slot[w] = 0u;
-		}
-		__syncthreads();
-		unsigned long long* table = reinterpret_cast<unsigned long long*>(ctrl + (size_t)CTRL_REGIONS * CTRL_STRIDE_U32);
-		if (threadIdx.x < 2 * (POOL_REGIONS + 1)) table[threadIdx.x] = t.v[threadIdx.x];
-	}
+	if (blockIdx.x == 0) pool_begin_block(t.v, ctrl);
 	if (n == 0) return;
 	if (blockIdx.x == 0 && threadIdx.x == 0) records[0] = 0;
 	ulonglong2* o2 = reinterpret_cast<ulonglong2*>(offs);
@@ -505,6 +583,7 @@ __global__ void __launch_bounds__(256) k_run_end(RunEndArgs a)
 			jb.h_ctrl[t] = reinterpret_cast<const unsigned long long*>(jb.ctrl_cursor + (size_t)r * CTRL_STRIDE_U32)[w];
 		}
 		if (tid == 0 && jb.h_count) *jb.h_count = *jb.d_count;
+		if (tid == 1 && jb.h_heavy) *jb.h_heavy = *jb.d_heavy;
 	}
 	for (uint32_t t = tid; t < (uint32_t)a.n_sets; t += 256u) a.h_nocc[t] = a.n_occ[t];
 	for (size_t t = tid; t < a.n_words; t += 256u) a.h_words[t] = a.words[t];
@@ -514,17 +593,40 @@ void launch_run_end(const RunEndArgs& a, hipStream_t s)
 	hipLaunchKernelGGL(k_run_end, dim3(1), dim3(256), 0, s, a);
 }
 
-// start of a run: the words the build kernels add to (guard flag, partial checksums: `words`, 64-bit) and the occupied-cell counts of the sets
-// that are built in this run (bit si of `sets`; at most 64 sets) start at zero -- one launch instead of one fill command per buffer
-__global__ void __launch_bounds__(256) k_run_begin(unsigned long long* __restrict__ words, size_t n_words, uint32_t* __restrict__ n_occ, unsigned long long sets)
+// start of a run, ONE launch: the words the build kernels add to (guard flag, partial checksums: `words`, 64-bit), the occupied-cell counts
+// of the sets that are built in this run (bit si of `sets`; at most 64 sets) and the cursors of the one-read bucket pass start at zero; the
+// table entries the previous run set are cleared (k_table_clear's job); every pool pass of the run gets its control block (k_pool_begin's job).
+// Round 4: these were three to four launches of a steady-state step, ~5 us of dispatch each, for a few microseconds of work.
+__global__ void __launch_bounds__(256) k_run_begin(const RunBeginArgs a)
 {
-	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (size_t)gridDim.x * 256) words[i] = 0ull;
-	if (blockIdx.x == 0 && threadIdx.x < 64 && ((sets >> threadIdx.x) & 1ull)) n_occ[threadIdx.x] = 0u;
+	const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, gsz = (size_t)gridDim.x * 256;
+	for (size_t i = gtid; i < a.n_words; i += gsz) a.words[i] = 0ull;
+	if (blockIdx.x == 0 && threadIdx.x < 64 && ((a.sets >> threadIdx.x) & 1ull)) a.n_occ[threadIdx.x] = 0u;
+	for (int k = 0; k < a.n_zero; k++) for (size_t i = gtid; i < (size_t)a.n_zero_words[k]; i += gsz) a.zero[k][i] = 0u;
+	for (int k = 0; k < a.n_clear; k++) {
+		const RunBeginClear& c = a.clear[k];
+		for (size_t i = gtid; i < (size_t)c.n; i += gsz) c.table[c.occ[i].y] = make_uint2(0u, 0u);
+	}
+	for (int k = 0; k < a.n_pool; k++) {
+		const RunBeginPool& p = a.pool[k];
+		if (blockIdx.x == (unsigned)k % gridDim.x) pool_begin_block(p.regions, p.ctrl);   // (uniform per block: the barrier inside is safe)
+		if (p.n_shared_empty == 0) continue;
+		if (gtid == 0) p.records[0] = 0;
+		ulonglong2* o2 = reinterpret_cast<ulonglong2*>(p.offs);
+		const size_t n2 = p.n_shared_empty / 2;
+		for (size_t i = gtid; i < n2; i += gsz) o2[i] = make_ulonglong2(0ull, 0ull);
+		if (gtid == 0 && (p.n_shared_empty & 1)) p.offs[p.n_shared_empty - 1] = 0ull;
+	}
 }
-void launch_run_begin(unsigned long long* words, size_t n_words, uint32_t* n_occ, unsigned long long sets, hipStream_t s)
+void launch_run_begin(const RunBeginArgs& a, hipStream_t s)
 {
-	const unsigned blocks = (unsigned)std::min<size_t>(64, (n_words + 255) / 256 + 1);
-	hipLaunchKernelGGL(k_run_begin, dim3(blocks), dim3(256), 0, s, words, n_words, n_occ, sets);
+	static_assert(CTRL_SLOTS <= 256, "one thread per slot");
+	size_t work = a.n_words;
+	for (int k = 0; k < a.n_zero; k++) work = std::max<size_t>(work, a.n_zero_words[k]);
+	for (int k = 0; k < a.n_clear; k++) work = std::max<size_t>(work, a.clear[k].n);
+	for (int k = 0; k < a.n_pool; k++) work = std::max<size_t>(work, a.pool[k].n_shared_empty / 16);   // (16 bytes per store, 8 stores per thread)
+	const size_t blocks = std::min<size_t>(2048, std::max<size_t>((work + 255) / 256, (size_t)std::max(a.n_pool, 1)));
+	hipLaunchKernelGGL(k_run_begin, dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
 
 // =====================================================================================================

@@ -456,6 +456,7 @@ __device__ __forceinline__ void process_batch_nc(const QueryArgs& a, const RunRe
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int MODE>
 __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 {
+	if (a.abort_flag && *a.abort_flag != 0u) return;   // (this attempt is already known to be wrong; its sorted arrays may have holes)
 	const int lane = lane_id();
 	const uint32_t w = readfirstlane_u32(threadIdx.x / WAVE);
 	const uint32_t n_occ = *a.n_occ_i;
@@ -1150,6 +1151,7 @@ __attribute__((amdgpu_waves_per_eu(FAT ? TNSX_FAT_WAVES_PER_EU : TNSX_FAST_WAVES
 #endif
 __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a)
 {
+	if (a.abort_flag && *a.abort_flag != 0u) return;   // (this attempt is already known to be wrong; its sorted arrays may have holes)
 	// FAT = false: cells from the occupied-cell list, 1..8 chunks; the rest -> a.heavy.
 	// FAT = true : cells from a.heavy, 9..16 chunks; the rest -> a.heavy2 (general kernel).
 	const uint2* __restrict__ cell_list = FAT ? a.heavy : a.occ_i;
@@ -1373,11 +1375,12 @@ static void launch_query_t(const QueryArgs& a, int blocks, hipStream_t s)
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<ARITH, VARIABLE, SYM, SELF, MODE>), dim3(blocks), dim3(Q_THREADS), 0, s, a);
 }
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF>
-static void launch_pool_t(const QueryArgs& a, int blocks_fast, int blocks_heavy, hipStream_t s)
+static void launch_pool_t(const QueryArgs& a, int blocks_fast, int blocks_heavy, int tiers, hipStream_t s)
 {
 	// three tiers: fast kernel (<= 512 candidates per cell) over all occupied cells -> fat kernel (<= 1024) over its rejects ->
 	// general kernel over what is left (more candidates, > 64 query points per cell, ...)
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_pool_fast<ARITH, VARIABLE, SYM, SELF, false>), dim3(blocks_fast), dim3(Q_THREADS), 0, s, a);
+	if (tiers & 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_pool_fast<ARITH, VARIABLE, SYM, SELF, false>), dim3(blocks_fast), dim3(Q_THREADS), 0, s, a);
+	if (!(tiers & 2)) return;
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_pool_fast<ARITH, VARIABLE, SYM, SELF, true>), dim3(blocks_fast), dim3(Q_THREADS), 0, s, a);
 	QueryArgs h = a;
 	h.occ_i = a.heavy2;
@@ -1394,7 +1397,7 @@ static void launch_query_3(const QueryArgs& a, const QueryConfig& c, int n_cus, 
 	else if (c.mode == QUERY_FILL) launch_query_t<ARITH, VARIABLE, SYM, SELF, MODE_FILL>(a, blocks, s);
 	else {
 		const int fast_per_cu = (c.fast_blocks_per_cu >= 1 && c.fast_blocks_per_cu <= 16) ? c.fast_blocks_per_cu : 8;   // (tnsx_options.fast_blocks_per_cu)
-		launch_pool_t<ARITH, VARIABLE, SYM, SELF>(a, ((n_cus * fast_per_cu + 7) / 8) * 8, ((n_cus * 2 + 7) / 8) * 8, s);
+		launch_pool_t<ARITH, VARIABLE, SYM, SELF>(a, ((n_cus * fast_per_cu + 7) / 8) * 8, ((n_cus * 2 + 7) / 8) * 8, c.tiers, s);
 	}
 }
 template <int ARITH, bool VARIABLE, bool SYM>

@@ -81,6 +81,7 @@ __device__ __forceinline__ float dist_sq1(float qx, float qy, float qz, float cx
 template <int ARITH, bool SELF>
 __global__ void __launch_bounds__(WAVE) k_query_groups(const QueryArgs a)
 {
+	if (a.abort_flag && *a.abort_flag != 0u) return;   // (see k_query_pool_fast)
 	__shared__ __attribute__((aligned(16))) unsigned char lds[G_LDS_BYTES];
 	const int lane = (int)threadIdx.x;
 	const uint32_t j = (uint32_t)lane & 15u, qa = (uint32_t)lane >> 4;

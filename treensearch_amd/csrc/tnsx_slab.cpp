@@ -22,6 +22,8 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
+#include <thread>
 #include <cmath>
 #include <condition_variable>
 #include <cstdarg>
@@ -36,6 +38,7 @@ extern "C" {
 // (tnsx_engine.cpp) the stream / device a context works on
 void* tnsx_internal_stream(tnsx_context* c);
 int tnsx_internal_device(tnsx_context* c);
+void tnsx_internal_set_sync_timeout(tnsx_context* c, double seconds);
 }
 
 namespace {
@@ -46,6 +49,7 @@ struct RcclApi {
 	ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
 	ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
 	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;   // optional
 	ncclResult_t (*GroupStart)() = nullptr;
 	ncclResult_t (*GroupEnd)() = nullptr;
 	ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -66,6 +70,7 @@ struct RcclApi {
 		TNSX_SYM(GroupStart, "ncclGroupStart") TNSX_SYM(GroupEnd, "ncclGroupEnd") TNSX_SYM(Send, "ncclSend") TNSX_SYM(Recv, "ncclRecv")
 		TNSX_SYM(AllReduce, "ncclAllReduce") TNSX_SYM(GetErrorString, "ncclGetErrorString")
 #undef TNSX_SYM
+		CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(lib, "ncclCommAbort"));
 		return true;
 	}
 };
@@ -105,6 +110,12 @@ void rccl_release(void* user)
 	RcclTransport* t = static_cast<RcclTransport*>(user);
 	if (t && t->comm) (void)g_rccl.CommDestroy(t->comm);
 	delete t;
+}
+void rccl_abort(void* user)
+{
+	// the watchdog's last resort: the pending send / recv kernels of this rank return, the communicator is gone
+	RcclTransport* t = static_cast<RcclTransport*>(user);
+	if (t && t->comm && g_rccl.CommAbort) { (void)g_rccl.CommAbort(t->comm); t->comm = nullptr; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- in-process transport
@@ -266,6 +277,7 @@ struct tnsx_slab {
 	size_t small_words = 0;
 	tnsx_slab_info info{};
 	std::string last_error;
+	double watchdog_s = 120.0;    // bound of every wait on the stream (tnsx_slab_set_watchdog)
 };
 
 namespace {
@@ -279,7 +291,37 @@ tnsx_status sfail(tnsx_slab* s, tnsx_status st, const char* fmt, ...)
 #define SHIP(s, call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return sfail(s, TNSX_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
 #define SENG(s, call) do { const tnsx_status r_ = (call); if (r_ != TNSX_OK) return sfail(s, r_, "%s: %s", #call, tnsx_last_error((s)->engine)); } while (0)
 
+// hipStreamSynchronize with a deadline.  -> 0 ok, 1 HIP error, 2 timed out
+int wait_stream(hipStream_t st, double seconds)
+{
+	if (!(seconds > 0.0)) return hipStreamSynchronize(st) == hipSuccess ? 0 : 1;
+	const auto t0 = std::chrono::steady_clock::now();
+	for (;;) {
+		const hipError_t q = hipStreamQuery(st);
+		if (q == hipSuccess) return 0;
+		if (q != hipErrorNotReady) return 1;
+		if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return 2;
+		std::this_thread::yield();
+	}
+}
 inline int peer_of(const tnsx_slab* s, int side) { return side == 0 ? s->rank - 1 : s->rank + 1; }
+// the watchdog fired: say which links this rank was waiting on, make the transport let go, fail the step
+tnsx_status timed_out(tnsx_slab* s, const char* what)
+{
+	std::string links;
+	for (int side = 0; side < 2; side++) {
+		const int p = peer_of(s, side);
+		if (p < 0 || p >= s->world) continue;
+		char b[160];
+		const SetState* st = s->sets.empty() ? nullptr : &s->sets[0];
+		std::snprintf(b, sizeof b, "%s link %d <-> %d (set 0: %u rows agreed out, %u in)", links.empty() ? "" : ";", s->rank, p, st ? st->cap_s[side] : 0u, st ? st->cap_r[side] : 0u);
+		links += b;
+	}
+	if (s->tr.abort) s->tr.abort(s->tr.user);
+	return sfail(s, TNSX_ERR_TIMEOUT, "rank %d of %d: the stream did not drain within %.1f s while %s -- a neighbour that never posted its side of the exchange, or a message-size "
+	             "mismatch.%s.  The transport was %s", s->rank, s->world, s->watchdog_s, what, links.c_str(), s->tr.abort ? "aborted" : "left as it is (no abort hook)");
+}
+#define SWAIT(s, what) do { const int w_ = wait_stream((s)->stream, (s)->watchdog_s); if (w_ == 2) return timed_out(s, what); if (w_ == 1) return sfail(s, TNSX_ERR_HIP, "HIP error while %s", what); } while (0)
 inline bool has_side(const tnsx_slab* s, int side) { const int p = peer_of(s, side); return p >= 0 && p < s->world; }
 
 // scratch layout (32-bit words): [set * 8 + 0..1] pack counts, [+2..3] received header counts, [+4] radius flag, [+5] id flag
@@ -362,7 +404,11 @@ tnsx_status run_engine(tnsx_slab* s)
 		}
 		s->active_applied = true;
 	}
-	SENG(s, tnsx_run(s->engine));
+	tnsx_internal_set_sync_timeout(s->engine, s->watchdog_s);
+	const tnsx_status r = tnsx_run(s->engine);
+	tnsx_internal_set_sync_timeout(s->engine, 0.0);
+	if (r == TNSX_ERR_TIMEOUT) return timed_out(s, "waiting for the halo exchange and the search behind it");
+	if (r != TNSX_OK) return sfail(s, r, "tnsx_run: %s", tnsx_last_error(s->engine));
 	return TNSX_OK;
 }
 
@@ -378,7 +424,8 @@ int do_exchange(tnsx_slab* s, const std::vector<tnsx_slab_op>& ops)
 
 extern "C" {
 
-const char* tnsx_slab_last_error(const tnsx_slab* s) { return s ? s->last_error.c_str() : "null slab"; }
+static thread_local std::string g_slab_create_error;   // what tnsx_slab_create / tnsx_slab_balanced_cuts had to say (no slab to carry it)
+const char* tnsx_slab_last_error(const tnsx_slab* s) { return s ? s->last_error.c_str() : g_slab_create_error.c_str(); }
 
 // ------------------------------------------------------------------------------------------------ transports
 tnsx_status tnsx_slab_rccl_unique_id(void* out128)
@@ -406,7 +453,7 @@ tnsx_status tnsx_slab_transport_rccl(const void* unique_id128, int rank, int wor
 	t->device = device;
 	const ncclResult_t r = g_rccl.CommInitRank(&t->comm, world, id, rank);
 	if (r != ncclSuccess) { g_rccl.error = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); delete t; return TNSX_ERR_HIP; }
-	out->user = t; out->exchange = rccl_exchange; out->allreduce = rccl_allreduce; out->release = rccl_release;
+	out->user = t; out->exchange = rccl_exchange; out->allreduce = rccl_allreduce; out->release = rccl_release; out->abort = rccl_abort;
 	return TNSX_OK;
 }
 
@@ -434,13 +481,13 @@ tnsx_status tnsx_slab_transport_local(void* group, int rank, tnsx_slab_transport
 	if (!g || !out || rank < 0 || rank >= g->world) return TNSX_ERR_INVALID;
 	{ std::lock_guard<std::mutex> lk(g->mu); g->refs++; }
 	LocalTransport* t = new LocalTransport{ g, rank };
-	out->user = t; out->exchange = local_exchange; out->allreduce = local_allreduce; out->release = local_release;
+	out->user = t; out->exchange = local_exchange; out->allreduce = local_allreduce; out->release = local_release; out->abort = nullptr;
 	return TNSX_OK;
 }
 void tnsx_slab_transport_release(tnsx_slab_transport* t)
 {
 	if (t && t->release) t->release(t->user);
-	if (t) { t->user = nullptr; t->exchange = nullptr; t->allreduce = nullptr; t->release = nullptr; }
+	if (t) { t->user = nullptr; t->exchange = nullptr; t->allreduce = nullptr; t->release = nullptr; t->abort = nullptr; }
 }
 
 // ------------------------------------------------------------------------------------------------ decomposition
@@ -448,6 +495,8 @@ tnsx_status tnsx_slab_balanced_cuts(tnsx_context* engine, const tnsx_slab_transp
                                     const int* n_points, float plane_width, int n_slabs, float* cuts_out)
 {
 	if (!engine || !cuts_out || n_sets < 0 || world < 1 || !(plane_width > 0.0f)) return TNSX_ERR_INVALID;
+	// (cuts computed from the local points alone would differ from rank to rank: points dropped or owned twice)
+	if (world > 1 && (!tr || !tr->allreduce)) { g_slab_create_error = "tnsx_slab_balanced_cuts: world > 1 needs a transport with an all-reduce"; return TNSX_ERR_INVALID; }
 	if (n_slabs <= 0) n_slabs = world;
 	const int device = tnsx_internal_device(engine);
 	hipStream_t stream = static_cast<hipStream_t>(tnsx_internal_stream(engine));
@@ -466,8 +515,12 @@ tnsx_status tnsx_slab_balanced_cuts(tnsx_context* engine, const tnsx_slab_transp
 	if (hipMemcpyAsync(range, d.p, 8, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return TNSX_ERR_HIP;
 	float x0 = range[0], x1 = range[1];
 	if (!(std::isfinite(x0) && std::isfinite(x1)) || x1 < x0) { x0 = 0.0f; x1 = 0.0f; }   // no points anywhere
-	const int n_planes = (int)((x1 - x0) / plane_width) + 1;
-	if (n_planes > MAX_PLANES || n_planes < n_slabs) return TNSX_ERR_GRID_TOO_LARGE;     // (too many planes, or fewer planes than slabs)
+	const double planes_d = std::floor(((double)x1 - (double)x0) / (double)plane_width) + 1.0;   // (range-checked before the cast)
+	if (!(planes_d <= (double)MAX_PLANES) || planes_d < (double)n_slabs) {
+		g_slab_create_error = "tnsx_slab_balanced_cuts: the x range holds too many planes of plane_width (> 32768), or fewer planes than slabs";
+		return TNSX_ERR_GRID_TOO_LARGE;
+	}
+	const int n_planes = (int)planes_d;
 	// ---- histogram of the x planes, all ranks
 	unsigned int* hist = d.as<unsigned int>() + 8;
 	if (hipMemsetAsync(hist, 0, (size_t)n_planes * 4, stream) != hipSuccess) return TNSX_ERR_HIP;
@@ -514,6 +567,17 @@ tnsx_status tnsx_slab_create(tnsx_context* engine, const tnsx_slab_transport* tr
 	if (!(s->max_radius > 0.0f)) { delete s; return TNSX_ERR_INVALID; }   // per-point radii: an upper bound of every radius sizes the halo
 	s->halo = s->max_radius * (1.0f + (halo_margin > 0.0f ? halo_margin : 1.0e-3f));
 	s->speculative = speculative != 0;
+	// ghosts only ever come from rank - 1 and rank + 1: a slab with two neighbours that is thinner than the halo would leave points of rank - 1
+	// within the radius of points of rank + 1 unseen by either -- silently incomplete lists.  (tnsx_slab_balanced_cuts never cuts thinner than its
+	// plane_width; caller-supplied cuts are checked here.)
+	if (rank > 0 && rank < world - 1 && !(slab_hi - slab_lo >= s->halo)) {
+		char b[256];
+		std::snprintf(b, sizeof b, "tnsx_slab_create: slab %d of %d is %g wide, thinner than the halo %g (ghosts are exchanged with the two adjacent slabs only)", rank, world,
+		              (double)(slab_hi - slab_lo), (double)s->halo);
+		g_slab_create_error = b;
+		delete s;
+		return TNSX_ERR_INVALID;
+	}
 	s->stream = static_cast<hipStream_t>(tnsx_internal_stream(engine));
 	s->device = tnsx_internal_device(engine);
 	if (!s->stream) { delete s; return TNSX_ERR_STATE; }   // (a multi-device context shards host data itself: tnsx_options.n_devices)
@@ -527,6 +591,13 @@ void tnsx_slab_destroy(tnsx_slab* s)
 	if (!s) return;
 	(void)hipSetDevice(s->device);
 	(void)hipStreamSynchronize(s->stream);
+	// the engine holds the slab's [owned | ghosts] buffers as TNSX_DEVICE inputs of its sets: they become empty sets before the buffers go
+	// (an engine that outlives its slab must not read freed memory at its next run / prepare_zsort)
+	for (SetState& st : s->sets) {
+		if (st.set_id < 0) continue;
+		(void)tnsx_set_point_ids(s->engine, st.set_id, nullptr);
+		(void)tnsx_resize_point_set(s->engine, st.set_id, nullptr, nullptr, 0, TNSX_F32 | TNSX_DEVICE | (s->variable ? TNSX_VARIABLE : 0u));
+	}
 	if (s->h_small) (void)hipHostFree(s->h_small);
 	delete s;
 }
@@ -560,6 +631,9 @@ tnsx_status tnsx_slab_step(tnsx_slab* s, int n_sets, const float* const* xyz, co
 		if (n_points[k] < 0 || (n_points[k] > 0 && (!xyz[k] || !gids[k]))) return sfail(s, TNSX_ERR_INVALID, "tnsx_slab_step: null pointer or negative size (set %d)", k);
 		if (s->variable && n_points[k] > 0 && (!radii || !radii[k])) return sfail(s, TNSX_ERR_INVALID, "per-point radii must be given for every set, or for none (fixed radius)");
 	}
+	// (the engine's sets, their active pairs and the agreed capacities all hang on the set list of the first step)
+	if (!s->sets.empty() && (size_t)n_sets != s->sets.size())
+		return sfail(s, TNSX_ERR_INVALID, "tnsx_slab_step: %d sets, but the slab was first stepped with %zu (a set may be empty, n_points = 0, but must be passed)", n_sets, s->sets.size());
 	if ((size_t)n_sets > s->sets.size()) s->sets.resize((size_t)n_sets);
 	{ const tnsx_status r = ensure_small(s, (size_t)n_sets); if (r != TNSX_OK) return r; }
 	const size_t W = s->variable ? 6 : 5;
@@ -594,7 +668,7 @@ tnsx_status tnsx_slab_step(tnsx_slab* s, int n_sets, const float* const* xyz, co
 		}
 		SHIP(s, hipMemcpyAsync(s->h_small, s->d_small.p, (size_t)n_sets * 8 * 4, hipMemcpyDeviceToHost, s->stream));
 		{ const tnsx_status r = run_engine(s); if (r != TNSX_OK) return r; }       // (synchronises the stream)
-		SHIP(s, hipStreamSynchronize(s->stream));
+		SWAIT(s, "reading the counts of the speculative exchange");
 		// ---- validate: every link on its own.  Both ends of a link see the same two numbers (what travelled, what was agreed).
 		bool repair_link[2] = { false, false };
 		for (int k = 0; k < n_sets; k++) {
@@ -635,7 +709,7 @@ tnsx_status tnsx_slab_step(tnsx_slab* s, int n_sets, const float* const* xyz, co
 			}
 			SHIP(s, hipMemcpyAsync(s->h_small, s->d_small.p, (size_t)n_sets * 8 * 4, hipMemcpyDeviceToHost, s->stream));
 			{ const tnsx_status r = run_engine(s); if (r != TNSX_OK) return r; }
-			SHIP(s, hipStreamSynchronize(s->stream));
+			SWAIT(s, "finishing the repaired step");
 		}
 	}
 	else {
@@ -661,7 +735,7 @@ tnsx_status tnsx_slab_step(tnsx_slab* s, int n_sets, const float* const* xyz, co
 		for (int k = 0; k < n_sets; k++) for (int side = 0; side < 2; side++) if (side_on[side])
 			SHIP(s, hipMemcpyAsync(small_dev(s, (size_t)k) + 2 + side, s->sets[(size_t)k].recv[side].p, 4, hipMemcpyDeviceToDevice, s->stream));
 		SHIP(s, hipMemcpyAsync(s->h_small, s->d_small.p, (size_t)n_sets * 8 * 4, hipMemcpyDeviceToHost, s->stream));
-		SHIP(s, hipStreamSynchronize(s->stream));
+		SWAIT(s, "exchanging the row counts with the neighbours");
 		ops.clear();
 		for (int k = 0; k < n_sets; k++) {
 			SetState& st = s->sets[(size_t)k];
@@ -682,7 +756,7 @@ tnsx_status tnsx_slab_step(tnsx_slab* s, int n_sets, const float* const* xyz, co
 		}
 		SHIP(s, hipMemcpyAsync(s->h_small, s->d_small.p, (size_t)n_sets * 8 * 4, hipMemcpyDeviceToHost, s->stream));
 		{ const tnsx_status r = run_engine(s); if (r != TNSX_OK) return r; }
-		SHIP(s, hipStreamSynchronize(s->stream));
+		SWAIT(s, "finishing the exact step");
 	}
 	// ---- capacities for the next step: grow only, the same rule on the same numbers at both ends of a link
 	for (int k = 0; k < n_sets; k++) {
@@ -698,6 +772,106 @@ tnsx_status tnsx_slab_step(tnsx_slab* s, int n_sets, const float* const* xyz, co
 	}
 	s->info.n_owned = s->sets[0].n_owned; s->info.n_ghost = s->sets[0].n_ghost;
 	return TNSX_OK;
+}
+
+tnsx_status tnsx_slab_set_watchdog(tnsx_slab* s, double seconds)
+{
+	if (!s) return TNSX_ERR_INVALID;
+	s->watchdog_s = seconds;
+	return TNSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ redistribution
+}  // extern "C"
+struct tnsx_slab_redist {
+	DBuf rows;            // the rows this rank owns after the exchange, W floats each
+	size_t n_rows = 0;
+	int W = 5;
+	hipStream_t stream = nullptr;
+	int device = 0;
+};
+extern "C" {
+
+tnsx_status tnsx_slab_redistribute_begin(tnsx_context* engine, const tnsx_slab_transport* tr, int rank, int world, const float* cuts, const float* xyz,
+                                         const long long* gids, const float* radii, int n_points, tnsx_slab_redist** out, int* n_owned)
+{
+	auto fail = [&](tnsx_status st, const char* msg) { g_slab_create_error = std::string("tnsx_slab_redistribute_begin: ") + msg; return st; };
+	if (!engine || !cuts || !out || !n_owned || world < 1 || world > 64 || rank < 0 || rank >= world || n_points < 0) return fail(TNSX_ERR_INVALID, "bad argument (1 <= world <= 64)");
+	if (n_points > 0 && (!xyz || !gids)) return fail(TNSX_ERR_INVALID, "null point or id array");
+	if (world > 1 && (!tr || !tr->exchange)) return fail(TNSX_ERR_INVALID, "world > 1 needs a transport");
+	for (int k = 1; k < world; k++) if (!(cuts[k] >= cuts[k - 1])) return fail(TNSX_ERR_INVALID, "cuts must ascend");
+	const int device = tnsx_internal_device(engine);
+	hipStream_t stream = static_cast<hipStream_t>(tnsx_internal_stream(engine));
+	if (!stream) return fail(TNSX_ERR_STATE, "multi-device contexts shard host data themselves");
+	if (hipSetDevice(device) != hipSuccess) return fail(TNSX_ERR_HIP, "hipSetDevice failed");
+	const int W = radii ? 6 : 5;
+	const double watchdog = 120.0;
+	// ---- how many of my points go where
+	DBuf d_small;   // [0, world) send counts = scatter cursors, [world, 2 world) first row of every destination, [2 world, 3 world) receive counts
+	if (!d_small.reserve((size_t)3 * world * 4)) return fail(TNSX_ERR_HIP, "out of device memory");
+	unsigned int* d_cnt = d_small.as<unsigned int>(), *d_first = d_cnt + world, *d_rcnt = d_first + world;
+	if (hipMemsetAsync(d_small.p, 0, (size_t)3 * world * 4, stream) != hipSuccess) return fail(TNSX_ERR_HIP, "memset failed");
+	tnsx::launch_slab_dest_rows(true, xyz, radii, gids, n_points, cuts, world, d_cnt, nullptr, nullptr, W, stream);
+	std::vector<unsigned int> h_cnt((size_t)world, 0u), h_rcnt((size_t)world, 0u), h_first((size_t)world, 0u);
+	// ---- round 1: the counts, to and from every other rank
+	std::vector<tnsx_slab_op> ops;
+	for (int p = 0; p < world; p++) if (p != rank) ops.push_back({ p, d_cnt + p, 4, d_rcnt + p, 4 });
+	if (!ops.empty() && tr->exchange(tr->user, rank, world, ops.data(), (int)ops.size(), stream)) return fail(TNSX_ERR_HIP, "exchange of the counts failed (transport)");
+	if (hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)world * 4, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+	    hipMemcpyAsync(h_rcnt.data(), d_rcnt, (size_t)world * 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return fail(TNSX_ERR_HIP, "copy of the counts failed");
+	{
+		const int w = wait_stream(stream, watchdog);
+		if (w == 2) { if (tr && tr->abort) tr->abort(tr->user); return fail(TNSX_ERR_TIMEOUT, "the exchange of the counts did not complete within 120 s (a rank that never called, or a transport that does not reach every pair of ranks)"); }
+		if (w == 1) return fail(TNSX_ERR_HIP, "HIP error while exchanging the counts");
+	}
+	h_rcnt[(size_t)rank] = h_cnt[(size_t)rank];   // my own share stays
+	size_t n_send = 0, n_recv = 0;
+	for (int p = 0; p < world; p++) { h_first[(size_t)p] = (unsigned int)n_send; n_send += h_cnt[(size_t)p]; n_recv += h_rcnt[(size_t)p]; }
+	if (n_recv > 0x7fffffffull) return fail(TNSX_ERR_LIST_TOO_LONG, "a slab would own more than 2^31 - 1 points");
+	// ---- my points as rows, grouped by destination
+	DBuf send;
+	tnsx_slab_redist* r = new tnsx_slab_redist();
+	r->W = W; r->stream = stream; r->device = device; r->n_rows = n_recv;
+	if (!send.reserve(std::max<size_t>(n_send, 1) * W * 4) || !r->rows.reserve(std::max<size_t>(n_recv, 1) * W * 4)) { delete r; return fail(TNSX_ERR_HIP, "out of device memory (rows)"); }
+	if (hipMemcpyAsync(d_first, h_first.data(), (size_t)world * 4, hipMemcpyHostToDevice, stream) != hipSuccess ||
+	    hipMemsetAsync(d_cnt, 0, (size_t)world * 4, stream) != hipSuccess) { delete r; return fail(TNSX_ERR_HIP, "copy failed"); }
+	tnsx::launch_slab_dest_rows(false, xyz, radii, gids, n_points, cuts, world, d_cnt, d_first, send.as<float>(), W, stream);
+	// ---- round 2: the rows.  Receive layout: the shares of rank 0, 1, ... one behind the other.
+	ops.clear();
+	size_t roff = 0;
+	for (int p = 0; p < world; p++) {
+		const size_t sb = (size_t)h_cnt[(size_t)p] * W * 4, rb = (size_t)h_rcnt[(size_t)p] * W * 4;
+		const float* src = send.as<float>() + (size_t)h_first[(size_t)p] * W;
+		float* dst = r->rows.as<float>() + roff * W;
+		if (p == rank) { if (sb && hipMemcpyAsync(dst, src, sb, hipMemcpyDeviceToDevice, stream) != hipSuccess) { delete r; return fail(TNSX_ERR_HIP, "copy failed"); } }
+		else if (sb || rb) ops.push_back({ p, sb ? (const void*)src : nullptr, sb, rb ? (void*)dst : nullptr, rb });
+		roff += h_rcnt[(size_t)p];
+	}
+	if (!ops.empty() && tr->exchange(tr->user, rank, world, ops.data(), (int)ops.size(), stream)) { delete r; return fail(TNSX_ERR_HIP, "exchange of the rows failed (transport)"); }
+	{
+		const int w = wait_stream(stream, watchdog);   // (the send buffer is released below)
+		if (w == 2) { if (tr && tr->abort) tr->abort(tr->user); delete r; return fail(TNSX_ERR_TIMEOUT, "the exchange of the rows did not complete within 120 s"); }
+		if (w == 1) { delete r; return fail(TNSX_ERR_HIP, "HIP error while exchanging the rows"); }
+	}
+	*out = r;
+	*n_owned = (int)n_recv;
+	return TNSX_OK;
+}
+
+tnsx_status tnsx_slab_redistribute_finish(tnsx_slab_redist* r, float* xyz_out, long long* gids_out, float* radii_out)
+{
+	if (!r) return TNSX_ERR_INVALID;
+	tnsx_status st = TNSX_OK;
+	if (xyz_out || gids_out) {
+		if (!xyz_out || !gids_out || (r->W == 6 && !radii_out)) { g_slab_create_error = "tnsx_slab_redistribute_finish: xyz, ids (and radii, if radii were given) are needed together"; st = TNSX_ERR_INVALID; }
+		else if (hipSetDevice(r->device) != hipSuccess) st = TNSX_ERR_HIP;
+		else {
+			tnsx::launch_slab_rows_to_points(r->rows.as<float>(), r->n_rows, r->W, xyz_out, r->W == 6 ? radii_out : nullptr, gids_out, r->stream);
+			if (hipStreamSynchronize(r->stream) != hipSuccess) st = TNSX_ERR_HIP;   // (the rows are freed with the handle)
+		}
+	}
+	delete r;
+	return st;
 }
 
 tnsx_status tnsx_slab_debug_set_capacity(tnsx_slab* s, int side, unsigned rows)

@@ -638,6 +638,79 @@ class SlabTransportC:
         self.kind = "local"
         return self
 
+    @classmethod
+    def host_staged(cls, rank: int, world: int, group=None):
+        """A transport over torch.distributed with the messages staged through host memory (any backend that moves CPU tensors: gloo):
+        an application-filled tnsx_slab_transport, as include/tnsx.h invites MPI codes to write.  Slow (two PCIe crossings per message) but
+        it needs neither RCCL nor peer access -- the ranks may even share one GPU -- and it is what tests/test_gpu_slabs.py runs the C
+        entry points over real process boundaries with."""
+        import ctypes as C
+        from . import api as A
+        self = cls()
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        H2D, D2H = 1, 2
+
+        def exchange(user, rk, wd, ops, n_ops, stream):
+            try:
+                if hip.hipStreamSynchronize(stream) != 0:        # the send buffers are produced on the stream
+                    return 1
+                work, recvs = [], []
+                for k in range(n_ops):
+                    op = ops[k]
+                    if op.send_bytes:
+                        t = torch.empty(op.send_bytes, dtype=torch.uint8)
+                        if hip.hipMemcpy(t.data_ptr(), op.send, op.send_bytes, D2H) != 0:
+                            return 1
+                        work.append(dist.isend(t, op.peer, group=group))
+                    if op.recv_bytes:
+                        t = torch.empty(op.recv_bytes, dtype=torch.uint8)
+                        work.append(dist.irecv(t, op.peer, group=group))
+                        recvs.append((op.recv, t))
+                for w in work:
+                    w.wait()
+                for dst, t in recvs:                              # (synchronous copies: complete when the call returns, as the contract asks)
+                    if hip.hipMemcpy(dst, t.data_ptr(), t.numel(), H2D) != 0:
+                        return 1
+                return 0
+            except Exception:                                     # pragma: no cover - reported through the status
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def allreduce(user, rk, wd, buf, count, op, stream):
+            try:
+                if hip.hipStreamSynchronize(stream) != 0:
+                    return 1
+                raw = torch.empty(count, dtype=torch.int32)
+                if hip.hipMemcpy(raw.data_ptr(), buf, count * 4, D2H) != 0:
+                    return 1
+                if op == 0:                                       # TNSX_SLAB_SUM_U32 (the sums stay far below 2^63)
+                    v = (raw.to(torch.int64) & 0xffffffff)
+                    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+                    raw = torch.from_numpy((v.numpy() & 0xffffffff).astype(np.uint32).view(np.int32).copy())
+                else:
+                    v = raw.view(torch.float32).clone()
+                    dist.all_reduce(v, op=dist.ReduceOp.MIN if op == 1 else dist.ReduceOp.MAX, group=group)
+                    raw = v.view(torch.int32)
+                return 0 if hip.hipMemcpy(buf, raw.data_ptr(), count * 4, H2D) == 0 else 1
+            except Exception:                                     # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        EX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(A.SlabOp), C.c_int, C.c_void_p)
+        AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
+        self._cb = (EX(exchange), AR(allreduce))                  # (kept alive with the object)
+        self.t.user = None
+        self.t.exchange = C.cast(self._cb[0], C.c_void_p)
+        self.t.allreduce = C.cast(self._cb[1], C.c_void_p)
+        self.t.release = None
+        self.t.abort = None
+        self.kind = "host"
+        return self
+
     @staticmethod
     def local_group(world: int):
         import ctypes as C
@@ -654,9 +727,16 @@ class SlabTransportC:
 
     def release(self) -> None:
         import ctypes as C
-        if self.kind is not None:
+        if self.kind is not None and self.kind != "host":
             self._L.tnsx_slab_transport_release(C.byref(self.t))
-            self.kind = None
+        self.kind = None
+
+    def __del__(self):
+        # (the RCCL communicator / the local group's reference must not leak when release() is never called by hand)
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 def balanced_cuts_c(engine, transport: Optional[SlabTransportC], rank: int, world: int, point_sets: Sequence[torch.Tensor], plane_width: float,
@@ -673,8 +753,36 @@ def balanced_cuts_c(engine, transport: Optional[SlabTransportC], rank: int, worl
     st = L.tnsx_slab_balanced_cuts(engine._h, C.byref(transport.t) if transport is not None else None, int(rank), int(world), n, ptrs, cnts,
                                    C.c_float(float(plane_width)), ns, out)
     if st != 0:
-        raise ValueError(f"tnsx_slab_balanced_cuts failed with status {st} (5: more than 32768 x planes, or fewer planes than slabs)")
+        raise ValueError(f"tnsx_slab_balanced_cuts failed with status {st}: " + (L.tnsx_slab_last_error(None) or b"").decode())
     return np.array(list(out), np.float32)
+
+
+def redistribute_c(engine, transport: Optional["SlabTransportC"], rank: int, world: int, cuts, pts: torch.Tensor, gids: torch.Tensor,
+                   radii: Optional[torch.Tensor] = None):
+    """tnsx_slab_redistribute_begin / _finish: the all-to-all that moves every point to the slab owning its x (collective over the
+    transport).  -> (points, ids[, radii]) of the points this rank owns, as new tensors on the engine's device."""
+    import ctypes as C
+    L = engine._L
+    assert pts.is_cuda and pts.dtype == torch.float32 and pts.is_contiguous() and gids.dtype == torch.int64 and gids.is_contiguous()
+    assert radii is None or (radii.is_cuda and radii.dtype == torch.float32 and radii.is_contiguous())
+    cc = (C.c_float * (world + 1))(*[float(x) for x in cuts])
+    h, n_owned = C.c_void_p(), C.c_int(0)
+    engine._wait_for_producers_of([pts, gids] + ([radii] if radii is not None else []))
+    n = int(pts.shape[0])
+    st = L.tnsx_slab_redistribute_begin(engine._h, C.byref(transport.t) if transport is not None else None, int(rank), int(world), cc,
+                                        pts.data_ptr() if n else None, gids.data_ptr() if n else None, radii.data_ptr() if (radii is not None and n) else None, n,
+                                        C.byref(h), C.byref(n_owned))
+    if st != 0:
+        raise RuntimeError(f"tnsx_slab_redistribute_begin failed with status {st}: " + (L.tnsx_slab_last_error(None) or b"").decode())
+    m = int(n_owned.value)
+    o_pts = torch.empty((max(m, 1), 3), dtype=torch.float32, device=pts.device)[:m]
+    o_gid = torch.empty(max(m, 1), dtype=torch.int64, device=pts.device)[:m]
+    o_rad = torch.empty(max(m, 1), dtype=torch.float32, device=pts.device)[:m] if radii is not None else None
+    torch.cuda.current_stream(pts.device).synchronize()   # (the outputs were allocated on torch's stream; the library writes them on the engine's)
+    st = L.tnsx_slab_redistribute_finish(h, o_pts.data_ptr(), o_gid.data_ptr(), o_rad.data_ptr() if o_rad is not None else None)
+    if st != 0:
+        raise RuntimeError(f"tnsx_slab_redistribute_finish failed with status {st}: " + (L.tnsx_slab_last_error(None) or b"").decode())
+    return (o_pts, o_gid) if radii is None else (o_pts, o_gid, o_rad)
 
 
 class SlabSearchC:
@@ -696,7 +804,7 @@ class SlabSearchC:
                                       C.c_float(float(slab_hi)), C.c_float(-1.0 if self.variable else float(radius)),
                                       C.c_float(float(max_radius) if self.variable else float(radius)), C.c_float(float(halo_margin)), int(bool(speculative)), C.byref(h))
         if st != 0:
-            raise RuntimeError(f"tnsx_slab_create failed with status {st}")
+            raise RuntimeError(f"tnsx_slab_create failed with status {st}: " + (self._L.tnsx_slab_last_error(None) or b"").decode())
         self._h = h
         self._keep = None
         self.n_sets = 0
@@ -711,6 +819,11 @@ class SlabSearchC:
 
     def set_symmetric_search(self, active: bool) -> None:
         self.engine.set_symmetric_search(active)
+
+    def set_watchdog(self, seconds: float) -> None:
+        """every wait of step() on the stream is bounded by `seconds` (default 120; <= 0: for ever): TNSX_ERR_TIMEOUT names the link"""
+        import ctypes as C
+        self._check(self._L.tnsx_slab_set_watchdog(self._h, C.c_double(float(seconds))))
 
     def set_active_search(self, i: int, j: int, active: bool = True) -> None:
         self._check(self._L.tnsx_slab_set_active_search(self._h, int(i), int(j), int(bool(active))))
