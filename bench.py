@@ -266,13 +266,13 @@ def secondary_workload(name, points, arith):
 
 
 def measured_copy_peak(torch):
-    """device-to-device copy of 2 GiB (read + write), best of 5: the ceiling a streaming kernel reaches on THIS box"""
+    """device-to-device copy of 2 GiB (read + write), best of 24: the ceiling a streaming kernel reaches on THIS box"""
     n = 1 << 29
     a = torch.empty(n, dtype=torch.float32, device="cuda")
     b = torch.empty_like(a)
     a.fill_(1.0)
     best = 0.0
-    for _ in range(6):
+    for _ in range(24):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         b.copy_(a)
@@ -519,20 +519,7 @@ def main():
     cold_ms = (time.perf_counter() - t0) * 1e3
     cold_stats = ns.get_stats()
     acc = {k: 0.0 for k in STAGES}
-    # ---- stage pass: steps with hipEvents around every stage (on the engine's stream; the query's bracket holds its kernels only), BEFORE the timed
-    #      loop: the stage times of the roofline come from here, the timed loop itself records no events
-    stage_steps = 0 if args.no_stage_pass else min(max(args.steps, 1), 10)
-    if stage_steps:
-        ns.set_collect_stage_times(True)
-        step(1)                                           # (the first run with events creates them)
-        for k in range(2, 2 + stage_steps):
-            step(k)
-            rs = ns.get_stats_raw()
-            for key in STAGES:
-                acc[key] += getattr(rs, key)
-        ns.set_collect_stage_times(False)
-        torch.cuda.synchronize()
-    for k in range(args.warmup):                          # W untimed warm-up steps, then exactly K timed ones
+    for k in range(1, args.warmup):                       # (the cold run was the first of the W untimed warm-up steps)
         step(k)
     counts = {"pool_retries": 0, "speculation_redos": 0, "speculated": 0, "n_cached_sets": 0, "heavy_catchups": 0, "one_read_builds": 0}
     if "zsort_ms_per_step" in extra:
@@ -548,6 +535,19 @@ def main():
     for rs in raw_stats:
         for key in counts:
             counts[key] += getattr(rs, key)
+    # ---- stage pass: the same steps again with hipEvents around every stage (on the engine's stream; the query's bracket holds its kernels only),
+    #      AFTER the timed loop: the stage times of the roofline come from here, the timed loop itself records no events
+    stage_steps = 0 if args.no_stage_pass else min(max(args.steps, 1), 10)
+    if stage_steps:
+        ns.set_collect_stage_times(True)
+        step(args.warmup + args.steps)                    # (the first run with events creates them)
+        for k in range(args.warmup + args.steps + 1, args.warmup + args.steps + 1 + stage_steps):
+            step(k)
+            rs = ns.get_stats_raw()
+            for key in STAGES:
+                acc[key] += getattr(rs, key)
+        ns.set_collect_stage_times(False)
+        torch.cuda.synchronize()
     if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -588,8 +588,8 @@ def main():
                                    "achieved_gbs": round(run_bytes / (dev_ms * 1e-3) / 1e9, 1) if dev_ms > 0 else 0.0,
                                    "frac": round(run_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dev_ms > 0 else 0.0}},
         "stage_ms": {k[3:]: round(v / max(stage_steps, 1), 4) for k, v in acc.items()},
-        "stage_pass": {"steps": stage_steps, "note": "stage_ms and roofline.avg_launch_ms: hipEvent brackets on the engine's stream, collected in extra steps between "
-                                                     "the cold run and the warm-up steps (the timed loop records no events); roofline.kernel_trace: rocprofv3's view "
+        "stage_pass": {"steps": stage_steps, "note": "stage_ms and roofline.avg_launch_ms: hipEvent brackets on the engine's stream, collected in extra steps AFTER "
+                                                     "the timed loop (the timed loop records no events); roofline.kernel_trace: rocprofv3's view "
                                                      "of the same kernels"},
         "steady_state": {"runs_that_reused_the_grid": counts["speculated"], "runs_repeated_after_a_failed_assumption": counts["speculation_redos"],
                          "pool_retries": counts["pool_retries"], "cached_set_builds_skipped": counts["n_cached_sets"],

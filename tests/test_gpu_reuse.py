@@ -193,8 +193,9 @@ def test_one_read_bucket_pass_and_its_overflow(oracle):
     rng = np.random.default_rng(11)
     # a cloud that is dense at the bottom and thin at the top (z is the slowest axis of the cell key: a bucket is a few x-rows of one z-layer),
     # with fixed corner points that pin the bounding box
+    # (the cloud stays clear of the faces of the box: a jitter must not pile points up on a face by clipping)
     z = rng.random(n, dtype=np.float32) ** np.float32(3.0)
-    pts = np.stack([rng.random(n, dtype=np.float32), rng.random(n, dtype=np.float32), z], axis=1).astype(np.float32)
+    pts = (np.float32(0.05) + np.float32(0.9) * np.stack([rng.random(n, dtype=np.float32), rng.random(n, dtype=np.float32), z], axis=1)).astype(np.float32)
     pts[0] = (0.0, 0.0, 0.0)
     pts[1] = (1.0, 1.0, 1.0)
     r = np.float32(0.02)
@@ -212,16 +213,14 @@ def test_one_read_bucket_pass_and_its_overflow(oracle):
     assert st["one_read_builds"] == 0 and st["radix_passes"] == 2, "the first run has no windows yet: histogram pass"
     for k in range(2):
         pts[2:] += (rng.random((n - 2, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(0.1) * r
-        np.clip(pts, 0.0, 1.0, out=pts)
         d.copy_(torch.from_numpy(pts))
         st = run_and_check(f"jitter {k}")
-        assert st["one_read_builds"] == 1 and st["speculated"] == 1 and st["speculation_redos"] == 0, st
+        assert st["one_read_builds"] == 1 and st["speculated"] == 1 and st["speculation_redos"] == 0, str({k: st[k] for k in ("one_read_builds", "speculated", "speculation_redos", "key_bits", "radix_passes", "grid_dims", "n_points")})
     pts[:, 2] = np.float32(1.0) - pts[:, 2]            # mirror in z: same box, same n, every bucket's count changes
     d.copy_(torch.from_numpy(pts))
     st = run_and_check("mirrored")
     assert st["speculation_redos"] == 1 and st["speculated"] == 0 and st["one_read_builds"] == 0, f"the overflow must be noticed and the run repeated: {st}"
     pts[2:] += (rng.random((n - 2, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(0.1) * r
-    np.clip(pts, 0.0, 1.0, out=pts)
     d.copy_(torch.from_numpy(pts))
     st = run_and_check("after the repair")
     assert st["one_read_builds"] == 1 and st["speculation_redos"] == 0
@@ -266,7 +265,9 @@ def test_one_read_bucket_pass_leaves_nan_points_out(oracle):
 def test_heavy_tiers_are_launched_after_the_sync_when_needed(oracle):
     """Round 4: the two heavy tiers of a pool pass (cells with more than 512 candidates or more than 64 query points) are not launched when the
     previous run of the pair had no such cell; what the first tier passes on is counted, and when that is not zero they run after the run's
-    synchronisation (tnsx_stats.heavy_catchups).  A uniform cloud (nothing heavy), then a clump appears inside the same box."""
+    synchronisation (tnsx_stats.heavy_catchups).  A uniform cloud (nothing heavy), then a clump appears inside the same box.  (With the
+    LSD build: in the bucket build the clump overflows its bucket's window first and the whole run is repeated, all tiers included --
+    the second half of the test.)"""
     import torch
     import treensearch_amd as T
     from treensearch_amd import datagen as D
@@ -275,11 +276,13 @@ def test_heavy_tiers_are_launched_after_the_sync_when_needed(oracle):
     pts[0] = (0.0, 0.0, 0.0); pts[1] = (1.0, 1.0, 1.0)
     r = D.radius_for_neighbors(n, 30.0)
     d = torch.from_numpy(pts).cuda()
-    ns = T.TreeNSearch()
+    ns = T.TreeNSearch(bucket_build_min_points=-1)
     ns.set_search_radius(r)
     ns.add_point_set(d)
     ns.set_active_search(0, 0, True)
     for k in range(2):
+        pts[7, 0] += np.float32(1e-4)                 # (an unchanged set would be taken for static: its build skipped, and repeated when it moves)
+        d.copy_(torch.from_numpy(pts))
         ns.run()
         assert ns.get_stats()["heavy_catchups"] == 0
     P.assert_same_csr(ns.neighbor_csr(0, 0), oracle.pair_search(pts, pts, radius=r, same_set=True), "uniform")
@@ -289,8 +292,27 @@ def test_heavy_tiers_are_launched_after_the_sync_when_needed(oracle):
     d.copy_(torch.from_numpy(pts))
     ns.run()
     st = ns.get_stats()
-    assert st["heavy_catchups"] == 1 and st["speculation_redos"] == 0, st
+    assert st["heavy_catchups"] == 1 and st["speculation_redos"] == 0, str({k: st[k] for k in ("heavy_catchups", "speculation_redos", "speculated", "pool_retries", "radix_passes", "one_read_builds")})
     P.assert_same_csr(ns.neighbor_csr(0, 0), oracle.pair_search(pts, pts, radius=r, same_set=True), "with a clump")
     ns.run()
     assert ns.get_stats()["heavy_catchups"] == 0, "the run after it launches the heavy tiers with the first"
     P.assert_same_csr(ns.neighbor_csr(0, 0), oracle.pair_search(pts, pts, radius=r, same_set=True), "with a clump, again")
+    # the same scene with the default (bucket) build: the clump overflows a window of the one-read pass, the run is repeated with every tier
+    pts2 = D.uniform_cloud(n, 9)
+    pts2[0] = (0.0, 0.0, 0.0); pts2[1] = (1.0, 1.0, 1.0)
+    d2 = torch.from_numpy(pts2).cuda()
+    nb = T.TreeNSearch()
+    nb.set_search_radius(r)
+    nb.add_point_set(d2)
+    nb.set_active_search(0, 0, True)
+    for k in range(2):
+        pts2[7, 0] += np.float32(1e-4)
+        d2.copy_(torch.from_numpy(pts2))
+        nb.run()
+    assert nb.get_stats()["one_read_builds"] == 1
+    pts2[1000:4000] = clump
+    d2.copy_(torch.from_numpy(pts2))
+    nb.run()
+    st = nb.get_stats()
+    assert st["speculation_redos"] == 1 and st["heavy_catchups"] == 0, st
+    P.assert_same_csr(nb.neighbor_csr(0, 0), oracle.pair_search(pts2, pts2, radius=r, same_set=True), "bucket build, with a clump")

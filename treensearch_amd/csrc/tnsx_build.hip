@@ -502,6 +502,15 @@ void launch_cell_table(const float4* xyzi_sorted, int n, GridParams g, uint2* ta
 // points that get lists (original index < query_limit) come before the candidates-only points of their cell (the ghosts of a
 // slab) -- the former fill a cell from the front, the latter from the back.
 // =====================================================================================================
+#ifndef TNSX_NT_BUCKET_LOADS
+#define TNSX_NT_BUCKET_LOADS 1
+#endif
+#if TNSX_NT_BUCKET_LOADS
+__device__ __forceinline__ float4 ld_bucket_nt(const float4* p) { const float* f = reinterpret_cast<const float*>(p); typedef float v4 __attribute__((ext_vector_type(4))); const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4*>(f)); return make_float4(v.x, v.y, v.z, v.w); }
+#define TNSX_LD_BUCKET(p) ld_bucket_nt(p)
+#else
+#define TNSX_LD_BUCKET(p) (*(p))
+#endif
 static constexpr int BS_THREADS = 1024;
 static constexpr int BS_KEEP = 12;     // points per thread that stay in registers between the two sweeps (12 K points per bucket: all of them, usually);
                                        // their loads are issued back to back -- with one load in flight per thread the sweeps are latency-bound
@@ -541,7 +550,7 @@ __global__ void __launch_bounds__(BS_THREADS) k_bucket_sort(const float4* __rest
 	// ---- the bucket's points -> registers (all loads in flight at once), sweep 1: points per cell
 	float4 keep[BS_KEEP];
 	#pragma unroll
-	for (int u = 0; u < BS_KEEP; u++) { const uint32_t i = (uint32_t)u * BS_THREADS + threadIdx.x; keep[u] = in[i < count ? i : count - 1u]; }
+	for (int u = 0; u < BS_KEEP; u++) { const uint32_t i = (uint32_t)u * BS_THREADS + threadIdx.x; keep[u] = TNSX_LD_BUCKET(in + (i < count ? i : count - 1u)); }
 	#pragma unroll
 	for (int u = 0; u < BS_KEEP; u++) {
 		const uint32_t i = (uint32_t)u * BS_THREADS + threadIdx.x;
@@ -550,7 +559,7 @@ __global__ void __launch_bounds__(BS_THREADS) k_bucket_sort(const float4* __rest
 	for (uint32_t i0 = BS_KEEP * BS_THREADS; i0 < count; i0 += BS_THREADS * BS_UNROLL) {   // (a bucket larger than the registers hold: read twice)
 		float4 q[BS_UNROLL];
 		#pragma unroll
-		for (int u = 0; u < BS_UNROLL; u++) { const uint32_t i = i0 + (uint32_t)u * BS_THREADS + threadIdx.x; q[u] = in[i < count ? i : count - 1u]; }
+		for (int u = 0; u < BS_UNROLL; u++) { const uint32_t i = i0 + (uint32_t)u * BS_THREADS + threadIdx.x; q[u] = TNSX_LD_BUCKET(in + (i < count ? i : count - 1u)); }
 		#pragma unroll
 		for (int u = 0; u < BS_UNROLL; u++) {
 			const uint32_t i = i0 + (uint32_t)u * BS_THREADS + threadIdx.x;
@@ -619,7 +628,7 @@ __global__ void __launch_bounds__(BS_THREADS) k_bucket_sort(const float4* __rest
 		float4 qq[BS_UNROLL];
 		float rr[BS_UNROLL];
 		#pragma unroll
-		for (int u = 0; u < BS_UNROLL; u++) { const uint32_t i = i0 + (uint32_t)u * BS_THREADS + threadIdx.x; qq[u] = in[i < count ? i : count - 1u]; }
+		for (int u = 0; u < BS_UNROLL; u++) { const uint32_t i = i0 + (uint32_t)u * BS_THREADS + threadIdx.x; qq[u] = TNSX_LD_BUCKET(in + (i < count ? i : count - 1u)); }
 		#pragma unroll
 		for (int u = 0; u < BS_UNROLL; u++) rr[u] = VARIABLE ? radii[__float_as_uint(qq[u].w)] : 0.0f;
 		#pragma unroll
@@ -663,7 +672,16 @@ __global__ void __launch_bounds__(BS_THREADS) k_occ_reorder(const uint2* __restr
 // tile's piece of a window is 256 contiguous bytes.  The rank of a point inside its (tile, bucket) piece is an LDS atomic.
 // Carries the run-time checks of the speculation like k_cs_hist does (box guard, checksum).
 // =====================================================================================================
-static constexpr int B1_THREADS = 1024, B1_ITEMS = 16, B1_TILE = B1_THREADS * B1_ITEMS;
+#ifndef TNSX_B1_THREADS
+#define TNSX_B1_THREADS 512
+#endif
+#ifndef TNSX_B1_ITEMS
+#define TNSX_B1_ITEMS 16
+#endif
+#ifndef TNSX_NT_BUILD_LOADS
+#define TNSX_NT_BUILD_LOADS 1
+#endif
+static constexpr int B1_THREADS = TNSX_B1_THREADS, B1_ITEMS = TNSX_B1_ITEMS, B1_TILE = B1_THREADS * B1_ITEMS;
 __global__ void __launch_bounds__(B1_THREADS) k_bucket_scatter(const float* __restrict__ xyz, int n, GridParams g, int lo_bits, int n_buckets, const uint2* __restrict__ win,
                                                                uint32_t* __restrict__ cursors, float4* __restrict__ out, const float* __restrict__ radii, BuildGuard gd)
 {
@@ -677,8 +695,13 @@ __global__ void __launch_bounds__(B1_THREADS) k_bucket_scatter(const float* __re
 	#pragma unroll
 	for (int i = 0; i < B1_ITEMS; i++) {   // all loads up front, branch-free (clamped)
 		const uint32_t li = (uint32_t)i * B1_THREADS + threadIdx.x;
+#if TNSX_NT_BUILD_LOADS
+		const float* qp = xyz + 3 * (base + (li < rem ? li : rem - 1u));
+		px[i] = __builtin_nontemporal_load(qp); py[i] = __builtin_nontemporal_load(qp + 1); pz[i] = __builtin_nontemporal_load(qp + 2);
+#else
 		const F3 q = (reinterpret_cast<const F3*>(xyz) + base)[li < rem ? li : rem - 1u];
 		px[i] = q.x; py[i] = q.y; pz[i] = q.z;
+#endif
 	}
 	bool bad = false;
 	float mn[3] = { gd.hi[0], gd.hi[1], gd.hi[2] }, mx[3] = { gd.lo[0], gd.lo[1], gd.lo[2] };

@@ -592,6 +592,12 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 //     offset once per cell.
 // The query loop of one simple cell: NC register-resident candidate chunks (packed pairs) against the nq query points held one
 // per lane in qv / qr2.  Tests, record allocation, emission.
+#ifndef TNSX_NT_OFFS
+#define TNSX_NT_OFFS 0
+#endif
+#ifndef TNSX_BLOCK_STORE_HINT
+#define TNSX_BLOCK_STORE_HINT " nt"
+#endif
 template <int NC> struct StageSize { static constexpr uint32_t ints = NC > 8 ? 2048u : 1536u; };   // ints of a wave's staging area: > 2 x the longest record of the tier
 #ifndef TNSX_CELL_STAGE
 #define TNSX_CELL_STAGE 1
@@ -690,14 +696,20 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 				const uint32_t i = f + (uint32_t)lane;
 				const uint32_t v0 = stage[i], v1 = stage[i + 64u], v2 = stage[i + 128u], v3 = stage[i + 192u];
 				// (every store is bounded by its own index: the instruction offset takes no part in the hardware's range check)
-				asm volatile("buffer_store_dword %[v0], %[i0], %[rsrc], 0 idxen\n\t"
-				             "buffer_store_dword %[v1], %[i1], %[rsrc], 0 idxen\n\t"
-				             "buffer_store_dword %[v2], %[i2], %[rsrc], 0 idxen\n\t"
-				             "buffer_store_dword %[v3], %[i3], %[rsrc], 0 idxen"
+				asm volatile("buffer_store_dword %[v0], %[i0], %[rsrc], 0 idxen" TNSX_BLOCK_STORE_HINT "\n\t"
+				             "buffer_store_dword %[v1], %[i1], %[rsrc], 0 idxen" TNSX_BLOCK_STORE_HINT "\n\t"
+				             "buffer_store_dword %[v2], %[i2], %[rsrc], 0 idxen" TNSX_BLOCK_STORE_HINT "\n\t"
+				             "buffer_store_dword %[v3], %[i3], %[rsrc], 0 idxen" TNSX_BLOCK_STORE_HINT
 				             : : [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [i0] "v"(i), [i1] "v"(i + 64u), [i2] "v"(i + 128u), [i3] "v"(i + 192u),
 				                 [rsrc] "s"(rsrc) : "memory");
 			}
-			if ((uint32_t)lane >= t0 && (uint32_t)lane < t1) a.offs_by_orig[qidx] = dst + v_pos;
+			if ((uint32_t)lane >= t0 && (uint32_t)lane < t1) {
+#if TNSX_NT_OFFS
+				__builtin_nontemporal_store((unsigned long)(dst + v_pos), reinterpret_cast<unsigned long*>(a.offs_by_orig) + qidx);
+#else
+				a.offs_by_orig[qidx] = dst + v_pos;
+#endif
+			}
 		}
 		hits += block - (t1 - t0);
 		if (from_slab) { base += block; left -= block; }
