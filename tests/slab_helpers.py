@@ -66,7 +66,8 @@ class LocalTransport:
     """Moves the messages of SlabExchange between the emulated ranks of one process: a FIFO per (source, destination).  The
     receiver's buffer must have exactly the shape of the message -- that IS the agreement the wire protocol promises."""
 
-    def __init__(self, world: int, timeout: float = 400.0):   # (generous: on a box whose host is busy with other jobs a step of the 1 M-point dam break has been seen to take > 120 s)
+    def __init__(self, world: int, timeout: float = 60.0):   # a step takes milliseconds; the 0.8 - 280 s steps of round 3 were a bug (junk radii behind NaN x), not a slow host.
+                                                             # A stalled step now fails within a minute with the per-rank step times and engine statistics (run_slabs_in_threads)
         import queue
         import threading
         self.q = {(s, d): queue.Queue() for s in range(world) for d in range(world) if abs(s - d) == 1}

@@ -311,10 +311,11 @@ def test_halo_pack_asymmetric_capacities():
 # in-process transport (tnsx_slab_transport_local: a thread per slab, one GPU); on several GPUs the same code runs over
 # tnsx_slab_transport_rccl (ncclSend / ncclRecv).
 # ======================================================================================================================
-def _run_slabs_c(case, world, n_steps=2, speculative=True, shrink_link_before_step=None, shrink_link=None, sets=None, active=None, redistribute=False):
+def _run_slabs_c(case, world, n_steps=2, speculative=True, shrink_link_before_step=None, shrink_link=None, sets=None, active=None, redistribute=False, cap_fn=None):
     """sets: [(points, radii or None)] of the WHOLE cloud (default: set 0 of the case); -> ({(i, j): union csr}, log, slabs' sizes).
     redistribute: every emulated rank starts with an equal INDEX share of every set and the points reach their owners through
-    tnsx_slab_redistribute_begin / _finish (the all-to-all of the decomposition) instead of being picked on the host."""
+    tnsx_slab_redistribute_begin / _finish (the all-to-all of the decomposition) instead of being picked on the host.
+    cap_fn(step, ghosts of every rank after the previous step) -> rows or None: the agreed capacity of every link is set to that before the step."""
     import threading
     import torch
     import treensearch_amd as T
@@ -333,6 +334,7 @@ def _run_slabs_c(case, world, n_steps=2, speculative=True, shrink_link_before_st
     barrier = threading.Barrier(world)
     owned = [None] * world
     log = [[] for _ in range(world)]
+    ghosts = [0] * world
 
     def work(k):
         try:
@@ -365,6 +367,14 @@ def _run_slabs_c(case, world, n_steps=2, speculative=True, shrink_link_before_st
             for (i, j) in active:
                 slab.set_active_search(i, j, True)
             for s in range(n_steps):
+                if cap_fn is not None and s > 0:
+                    ghosts[k] = int(slab.info().n_ghost)
+                    barrier.wait()
+                    rows = cap_fn(s, list(ghosts))
+                    barrier.wait()
+                    if rows is not None:
+                        for side in (0, 1):
+                            slab.debug_set_capacity(side, int(rows))
                 if shrink_link_before_step == s and shrink_link is not None and k in shrink_link:
                     slab.debug_set_capacity(1 if k == min(shrink_link) else 0, 8)       # both ends of ONE link
                 slab.step(*[(p, g, r) if variable else (p, g) for (p, g, r, _) in mine])
@@ -454,6 +464,28 @@ def test_c_abi_two_sets_asymmetric_searches(oracle):
         assert int(g_offs[-1]) == fx["total"]
     for k in range(3):
         assert log[k][1] == (True, False, 1)
+
+
+def test_c_abi_capacity_edges(oracle):
+    """The fixed-capacity messages of a speculative step at their edges, two slabs: capacity == the rows that travel (no padding row at all),
+    capacity one row short (the link is repaired by its two ends and the step searched again), capacity several times the rows (most of the
+    message is padding: NaN-x rows that must count for nothing), then exactly enough again -- every step reports what it should and the
+    union after the last one is the reference's digest."""
+    case = CS.by_name("uniform_fixed_1000000")
+    single = _single_device(case)
+    seen = {}
+
+    def cap_fn(step, ghosts):
+        # world 2: a rank's ghosts are the rows of its one link; the fuller direction decides what "exactly enough" is
+        full = max(ghosts)
+        seen[step] = full
+        return {1: full, 2: full - 1, 3: 5 * full, 4: full}.get(step)
+    unions, log, _, _ = _run_slabs_c(case, 2, n_steps=5, cap_fn=cap_fn)
+    _check_union(case, unions[(0, 0)], single, oracle)
+    for k in range(2):
+        assert log[k][1] == (True, False, 1), f"rank {k}: capacity == rows is not an overflow: {log[k][1]}"
+        assert log[k][2] == (True, True, 2), f"rank {k}: one row short: repaired by the two ends: {log[k][2]}"
+        assert log[k][3] == (True, False, 1) and log[k][4] == (True, False, 1), f"rank {k}: {log[k][3:]}"
 
 
 def test_c_abi_redistribute_then_search(uniform_2m, oracle):

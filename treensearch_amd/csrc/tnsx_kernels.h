@@ -120,7 +120,10 @@ struct QueryArgs {
 // atomics that hit the same cache line (measured: ~88 atomics/us per line, whatever the word), and the stride also spreads
 // the counters over different L2 channels whether these interleave at 256 B or at 4 KiB.
 static constexpr size_t CTRL_STRIDE_U32 = 1088;
-static constexpr uint32_t CTRL_SUBRANGES = 8;   // ticket counters per XCD and tier (each hands out one contiguous piece of the XCD's cells)
+#ifndef TNSX_CTRL_SUBRANGES
+#define TNSX_CTRL_SUBRANGES 8
+#endif
+static constexpr uint32_t CTRL_SUBRANGES = TNSX_CTRL_SUBRANGES;   // ticket counters per XCD and tier (each hands out one contiguous piece of the XCD's cells)
 static constexpr int POOL_REGIONS = 8, POOL_OVERFLOW = POOL_REGIONS;   // one region per XCD (fast tier) + the common region (heavy tiers, overflow)
 static constexpr size_t POOL_CURSOR_STRIDE = CTRL_STRIDE_U32 / 2;      // in 64-bit words
 static constexpr int POOL_HITS_WORD = 16, POOL_WASTE_WORD = 17;        // 64-bit words of a cursor's slot, on the line after the cursor's
