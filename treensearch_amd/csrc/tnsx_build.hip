@@ -411,8 +411,75 @@ __global__ void __launch_bounds__(256) k_extract_order(const float4* __restrict_
 	const int p = blockIdx.x * 256 + threadIdx.x;
 	if (p < n) order[p] = (int)__float_as_uint(xyzi[p].w);
 }
+// z-order in TWO passes (round 4; keys of 16 .. 24 bits, i.e. the cell-level order after a run()): the stable ranked pass on the high digit, then
+// one workgroup per bucket that counts its points per low digit in LDS, scans, and writes the ORDER directly -- the point's original index at its
+// final rank, 4 bytes -- instead of moving the point a third time and extracting the index column afterwards.  The order inside a cell of the
+// reference grid is whatever the LDS atomics give (the reference keeps the order of its own cell lists there, which is just as unspecified).
+static constexpr int BP_THREADS = 1024;
+__global__ void __launch_bounds__(BP_THREADS) k_morton_place(const float4* __restrict__ in, int* __restrict__ order_out, GridParams g, int lo_bits,
+                                                             const uint32_t* __restrict__ totals)
+{
+	extern __shared__ uint32_t bp_h[];
+	__shared__ uint32_t red[BP_THREADS / WAVE];
+	const int RADIX = 1 << lo_bits;
+	const int b = (int)blockIdx.x, lane = lane_id(), w = (int)threadIdx.x / WAVE;
+	uint32_t part = 0;
+	for (int k = (int)threadIdx.x; k < b; k += BP_THREADS) part += totals[k];
+	#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, WAVE);
+	if (lane == 0) red[w] = part;
+	const uint32_t count = totals[b];
+	for (int k = (int)threadIdx.x; k < RADIX; k += BP_THREADS) bp_h[k] = 0u;
+	__syncthreads();
+	uint32_t start = 0;
+	#pragma unroll
+	for (int k = 0; k < BP_THREADS / WAVE; k++) start += red[k];
+	if (count == 0u) return;
+	in += start;
+	const uint32_t mask = (uint32_t)(RADIX - 1);
+	for (uint32_t i = threadIdx.x; i < count; i += BP_THREADS) { const float4 q = in[i]; atomicAdd(&bp_h[(uint32_t)sort_key<true>(q.x, q.y, q.z, g) & mask], 1u); }
+	__syncthreads();
+	// exclusive scan of the counts: thread t owns PER consecutive digits
+	const int PER = RADIX >= BP_THREADS ? RADIX / BP_THREADS : 1;
+	const int mine = (int)threadIdx.x * PER < RADIX ? PER : 0;
+	uint32_t sum = 0;
+	for (int k = 0; k < mine; k++) sum += bp_h[threadIdx.x * PER + k];
+	uint32_t inc = sum;
+	#pragma unroll
+	for (int o = 1; o < WAVE; o <<= 1) { const uint32_t u = __shfl_up(inc, o, WAVE); if (lane >= o) inc += u; }
+	__syncthreads();
+	if (lane == WAVE - 1) red[w] = inc;
+	__syncthreads();
+	uint32_t ex = inc - sum;
+	#pragma unroll
+	for (int k = 0; k < BP_THREADS / WAVE; k++) if (k < w) ex += red[k];
+	for (int k = 0; k < mine; k++) { const uint32_t c = bp_h[threadIdx.x * PER + k]; bp_h[threadIdx.x * PER + k] = ex; ex += c; }
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < count; i += BP_THREADS) {   // (second read of the bucket: it is a few hundred KB, in the L2)
+		const float4 q = in[i];
+		const uint32_t pos = atomicAdd(&bp_h[(uint32_t)sort_key<true>(q.x, q.y, q.z, g) & mask], 1u);
+		order_out[start + pos] = (int)__float_as_uint(q.w);
+	}
+}
 int launch_morton_sort(const float* xyz, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, int* order_out, hipStream_t s)
 {
+	if (n >= (1 << 16) && key_bits >= 16 && key_bits <= 24) {
+		int lo_bits = key_bits - CS_MAX_BITS;
+		lo_bits = lo_bits < 8 ? 8 : lo_bits;
+		const int hi_bits = key_bits - lo_bits;   // 8 .. 11
+		const int ntiles = cs_num_tiles(n);
+		const size_t hist_cap = ((size_t)1 << CS_MAX_BITS) * (size_t)ntiles;
+		uint32_t* hist = (uint32_t*)temp;
+		uint32_t* totals = (uint32_t*)((char*)temp + ((hist_cap * sizeof(uint32_t) + 255) / 256) * 256);
+		uint32_t* strip_sums = totals + ((size_t)1 << CS_MAX_BITS);
+		const BuildGuard none{};
+		TNSX_CS_DISPATCH(hi_bits, (cs_hist<B, true>(true, xyz, b.xyzi[0], n, g, lo_bits, hist, ntiles, nullptr, none, s)));
+		TNSX_CS_DISPATCH(hi_bits, cs_scan<B>(hist, ntiles, strip_sums, totals, s));
+		TNSX_CS_DISPATCH(hi_bits, (cs_scatter<B, true>(true, false, xyz, nullptr, b.xyzi[0], b.r2[0], b.xyzi[1], b.r2[1], n, g, lo_bits, hist, totals, ntiles, nullptr, nullptr, none, s)));
+		const size_t lds = ((size_t)1 << lo_bits) * sizeof(uint32_t);
+		hipLaunchKernelGGL(k_morton_place, dim3(1 << hi_bits), dim3(BP_THREADS), lds, s, b.xyzi[1], order_out, g, lo_bits, totals);
+		return 1;
+	}
 	const int res = point_sort<true>(xyz, nullptr, n, g, key_bits, b, temp, nullptr, nullptr, BuildGuard{}, s);
 	if (n > 0) hipLaunchKernelGGL(k_extract_order, dim3((n + 255) / 256), dim3(256), 0, s, b.xyzi[res], n, order_out);
 	return res;

@@ -173,6 +173,7 @@ struct tnsx_context {
 	tnsx::GridParams grid{};
 	float grid_h = 0.0f, grid_lo[3] = { 0, 0, 0 }, grid_hi[3] = { 0, 0, 0 }, grid_r_max = 0.0f;
 	bool grid_valid = false, grid_variable = false;
+	bool grid_box_scalar = false;   // the world box the grid was laid out under came from run_scalar()'s rule (no origin) / run()'s (united with the origin)
 	bool grid_trimmed = false;      // the grid covers the bulk of the points only (trim_box)
 	uint32_t grid_gen = 0;
 	float zsort_inv_h = 0.0f;   // 1 / quantisation step of the last prepare_zsort (tnsx_stats.zsort_cell_size_inv)
@@ -798,6 +799,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			for (int d = 0; d < 3; d++) { c->grid_lo[d] = lo[d]; c->grid_hi[d] = hi[d]; }
 			c->grid_r_max = r_max;
 			c->grid_variable = variable;
+			c->grid_box_scalar = c->scalar_world_box;
 			c->grid_valid = true;
 			c->grid_trimmed = trimmed;
 			c->grid_gen++;
@@ -1387,7 +1389,10 @@ tnsx_status tnsx_run(tnsx_context* c)
 	c->stats.speculation_redos = 0;
 	// the previous run's grid can be laid over this run's points unseen if nothing it was derived from has changed on the host side
 	bool speculate = c->opt.temporal_reuse != 0 && c->grid_valid && c->cell_size > 0.0f && c->grid_variable == !c->radius_set &&
-	                 (c->radius_set ? c->grid_r_max == c->radius : true);
+	                 (c->radius_set ? c->grid_r_max == c->radius : true) &&
+	                 // run() after run_scalar() (or the other way round) on unchanged points: the reference's two paths snap the world box differently
+	                 // (TreeNSearch.cpp:415-472 vs :523-592) -- the box must be looked at again, so no speculation across a change of flavour
+	                 c->grid_box_scalar == c->scalar_world_box;
 	int64_t n_total = 0;
 	for (const PointSet& s : c->sets) n_total += s.n;
 	if (n_total == 0) speculate = false;
@@ -1495,8 +1500,10 @@ tnsx_status tnsx_prepare_zsort(tnsx_context* c)
 	hipStream_t st = c->stream;
 	// _set_up (TreeNSearch.cpp:2584) + world box (TreeNSearch.cpp:2666)
 	{ const tnsx_status r = stage_inputs(c); if (r != TNSX_OK) return r; }
-	float b8[8];
-	{ const tnsx_status r = compute_bounds(c, b8); if (r != TNSX_OK) return r; }
+	float b8[8] = { FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX, FLT_MAX, -FLT_MAX };
+	// (after a run() neither the cell size nor the world box is touched here -- the reference orders the cells of its last run, TreeNSearch.cpp:2603 --
+	//  so the bounds pass and its host round trip are skipped: 0.3 ms of a 50 M-point step that calls this every step)
+	if (!(c->cells_valid && c->cell_size > 0.0f)) { const tnsx_status r = compute_bounds(c, b8); if (r != TNSX_OK) return r; }
 	if (c->cell_size < 0.0f) {
 		// _set_up's default (TreeNSearch.cpp:300-316); prepare_zsort does not run _check
 		if (!c->radius_set && c->n_sets_with_radii != (int)c->sets.size()) {

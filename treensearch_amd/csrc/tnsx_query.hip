@@ -149,28 +149,8 @@ __device__ __forceinline__ Runs extract_runs_t(uint32_t run_start, uint32_t run_
 	R.p9 = R.total; R.d9 = 0;
 	return R;
 }
-template <bool OWN_FIRST>
-__device__ __forceinline__ uint32_t slot_to_src_t(uint32_t slot, const Runs R)
-{
-	if (!OWN_FIRST) return slot_to_src(slot, R);
-	uint32_t d = R.d0;
-	d = slot >= R.p1 ? R.d1 : d;
-	d = slot >= R.p2 ? R.d2 : d;
-	d = slot >= R.p3 ? R.d3 : d;
-	d = slot >= R.p4 ? R.d4 : d;
-	d = slot >= R.p5 ? R.d5 : d;
-	d = slot >= R.p6 ? R.d6 : d;
-	d = slot >= R.p7 ? R.d7 : d;
-	d = slot >= R.p8 ? R.d8 : d;
-	d = slot >= R.p9 ? R.d9 : d;
-	return slot + d;
-}
-
-#ifndef TNSX_DEAL_LDS
-#define TNSX_DEAL_LDS 1
-#endif
 // ---------------------------------------------------------------------------------------------------------------------
-// Candidate dealing through an LDS table (round 3).  slot_to_src_t costs nine compare + select pairs per slot and chunk -- all of
+// Candidate dealing through an LDS table (round 3).  A select chain like slot_to_src above costs nine compare + select pairs per slot and chunk -- all of
 // them instructions that touch an SGPR or VCC, 4.3 cycles each: 77 cycles per chunk, 22 % of the kernel's vector instructions
 // (profiles/r2_c2_pmc.json).  Instead every run writes the sorted positions of its candidates into a table in the wave's staging
 // area ONCE per cell: run r covers the slots [p_r, p_r+1), lane l of the piece writes p_r + d_r + l at table[p_r + l] with
@@ -280,61 +260,7 @@ __device__ __forceinline__ uint32_t* record_stage()
 	__shared__ uint32_t s_stage[Q_WAVES * SLOTS];
 	return s_stage + readfirstlane_u32(threadIdx.x / WAVE) * SLOTS;
 }
-#define TNSX_LDS_PIECE(K)                   \
-	"s_mov_b64 exec, %[m" #K "]\n\t"       \
-	"ds_write_b32 %[addr], %[v" #K "]\n\t" \
-	"v_add_u32 %[addr], 4, %[addr]\n\t"
 #define TNSX_LDS_IN(K, M, V) [m##K] "s"(M), [v##K] "v"(V)
-template <int N>
-__device__ __forceinline__ void stage_chunks(uint32_t& addr, const uint64_t* m, const uint32_t* v)
-{
-	if (N == 1) {
-		asm volatile(TNSX_LDS_PIECE(0) "s_mov_b64 exec, -1" : [addr] "+v"(addr) : TNSX_LDS_IN(0, m[0], v[0]) : "memory");
-	}
-	else if (N == 2) {
-		asm volatile(TNSX_LDS_PIECE(0) TNSX_LDS_PIECE(1) "s_mov_b64 exec, -1" : [addr] "+v"(addr) : TNSX_LDS_IN(0, m[0], v[0]), TNSX_LDS_IN(1, m[1], v[1]) : "memory");
-	}
-	else if (N == 3) {
-		asm volatile(TNSX_LDS_PIECE(0) TNSX_LDS_PIECE(1) TNSX_LDS_PIECE(2) "s_mov_b64 exec, -1"
-		             : [addr] "+v"(addr) : TNSX_LDS_IN(0, m[0], v[0]), TNSX_LDS_IN(1, m[1], v[1]), TNSX_LDS_IN(2, m[2], v[2]) : "memory");
-	}
-	else {
-		asm volatile(TNSX_LDS_PIECE(0) TNSX_LDS_PIECE(1) TNSX_LDS_PIECE(2) TNSX_LDS_PIECE(3) "s_mov_b64 exec, -1"
-		             : [addr] "+v"(addr) : TNSX_LDS_IN(0, m[0], v[0]), TNSX_LDS_IN(1, m[1], v[1]), TNSX_LDS_IN(2, m[2], v[2]), TNSX_LDS_IN(3, m[3], v[3]) : "memory");
-	}
-}
-template <int NC>
-__device__ __forceinline__ void stage_all(uint32_t& addr, const uint64_t (&m)[NC], const uint32_t* v)
-{
-	#pragma unroll
-	for (int g = 0; g < NC; g += 4) {
-		if (NC - g >= 4) stage_chunks<4>(addr, m + g, v + g);
-		else if (NC - g == 3) stage_chunks<3>(addr, m + g, v + g);
-		else if (NC - g == 2) stage_chunks<2>(addr, m + g, v + g);
-		else stage_chunks<1>(addr, m + g, v + g);
-	}
-}
-// Lane with record index i stores v to int 1 + i of the record that starts at byte `pos` of the storage behind rsrc, if i < cnt.
-// TNSX_STAGE_RANGECHECK: the bound is left to the buffer hardware -- an index-addressed (structured) buffer store is dropped when
-// index >= NUM_RECORDS (the scalar offset does not take part in the check), so writing cnt into word 2 of the V# costs one
-// scalar move instead of a compare and two exec moves.
-#ifndef TNSX_STAGE_PIPE
-#define TNSX_STAGE_PIPE 1
-#endif
-#ifndef TNSX_STAGE_RANGECHECK
-#define TNSX_STAGE_RANGECHECK 0
-#endif
-__device__ __forceinline__ void store_record64(v4i rsrc, uint32_t pos, uint32_t cnt, uint32_t i, uint32_t v)
-{
-#if TNSX_STAGE_RANGECHECK
-	rsrc.z = (int)cnt;
-	asm volatile("buffer_store_dword %[v], %[i], %[rsrc], %[pos] idxen offset:4" : : [v] "v"(v), [i] "v"(i), [rsrc] "s"(rsrc), [pos] "s"(pos) : "memory");
-#else
-	const uint64_t live = __builtin_amdgcn_ballot_w64(i < cnt);
-	asm volatile("s_mov_b64 exec, %[m]\n\tbuffer_store_dword %[v], %[i], %[rsrc], %[pos] idxen offset:4\n\ts_mov_b64 exec, -1"
-	             : : [m] "s"(live), [v] "v"(v), [i] "v"(i), [rsrc] "s"(rsrc), [pos] "s"(pos) : "memory");
-#endif
-}
 
 // One batch of <= NC*64 candidates (register resident) against the nq query points held one per lane in qv.
 //   MODE_COUNT: run_cnt (lane t) += hits of query t
@@ -599,10 +525,6 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 #define TNSX_BLOCK_STORE_HINT " nt"
 #endif
 template <int NC> struct StageSize { static constexpr uint32_t ints = NC > 8 ? 2048u : 1536u; };   // ints of a wave's staging area: > 2 x the longest record of the tier
-#ifndef TNSX_CELL_STAGE
-#define TNSX_CELL_STAGE 1
-#endif
-#if TNSX_CELL_STAGE
 // ---------------------------------------------------------------------------------------------------------------------
 // Whole-cell staging (round 3).  The records of the queries of one cell are consecutive in the pool, so the WHOLE BLOCK is built in
 // the wave's LDS staging area -- [count, ids...] [count, ids...] ... exactly as it will lie in memory -- and leaves at the end of the
@@ -767,125 +689,6 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 	ps.left = left;
 	ps.ok = ok;
 }
-#else
-template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int NC>
-__device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits,
-                                                const v2f (&cx)[(NC + 1) / 2], const v2f (&cy)[(NC + 1) / 2], const v2f (&cz)[(NC + 1) / 2],
-                                                const uint32_t (&cid)[2 * ((NC + 1) / 2)], const float (&cr2)[2 * ((NC + 1) / 2)], const float4 qv,
-                                                const float qr2, const uint32_t qidx)
-{
-	constexpr int NP = (NC + 1) / 2;
-	// Only points with original index < query_limit get lists (tnsx_set_query_count: the tail of a set can be candidates only,
-	// e.g. the ghost points of a slab).  The cell sort is stable, so inside a cell these queries come first: a prefix.
-	const uint32_t nq = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((uint32_t)lane < cur_q.y - cur_q.x && qidx < a.query_limit));
-	// ---- allocator state in plain scalars.  Records of this cell go to records[base ...] + pos0 bytes: `base` (64-bit, and the
-	//      buffer resource made from it) changes only when a new slab is taken, everything per query is 32-bit: pos0 (BYTES used
-	//      since `base`), left (ints left in the slab).
-	uint32_t left = readfirstlane_u32(ps.left);
-	uint32_t ok = readfirstlane_u32(ps.ok);          // (an explicitly uniform integer: as a bool it ends up in a VGPR / an exec-masked region)
-	uint64_t base = ((uint64_t)readfirstlane_u32(ps.cur_hi) << 32) | readfirstlane_u32(ps.cur_lo);
-	v4i rsrc = record_rsrc(a.records + base);
-	uint32_t pos0 = 0;
-
-	// lane t keeps (count, pos0) of query t (v_writelane); the count words and the offsets by original index are written for
-	// all queries together -- at the end of the cell, or before `base` changes
-	uint32_t v_cnt = 0, v_pos = 0;
-	uint32_t flushed = 0;                            // queries [0, flushed) have been written
-	auto flush = [&](uint32_t upto) {
-		if ((uint32_t)lane >= flushed && (uint32_t)lane < upto && ok != 0u) {
-			const uint64_t off = base + (v_pos >> 2);
-			a.records[off] = (int)v_cnt;
-			a.offs_by_orig[qidx] = off;
-		}
-		flushed = upto;
-	};
-
-	uint32_t* const stage = record_stage<(int)StageSize<NC>::ints>();
-	const uint32_t stage_base = readfirstlane_u32((uint32_t)(uintptr_t)stage);   // (the low half of a generic LDS address is the LDS offset)
-	uint32_t pend_v = 0, pend_cnt = 0, pend_pos = 0;   // TNSX_STAGE_PIPE: first 64 ints of the previous query's record, read back but not yet stored
-	// ---- the query loop.  (Fetching the query point with a scalar load one iteration ahead instead of v_readlane was
-	//      tried and dropped: the compiler is free to copy the destination SGPRs before the asynchronous load has landed.)
-	uint32_t hits = 0;
-	for (uint32_t t = 0; t < nq; t++) {
-		const float qx = readlane_f32(qv.x, (int)t), qy = readlane_f32(qv.y, (int)t), qz = readlane_f32(qv.z, (int)t);
-		const float r2q = VARIABLE ? readlane_f32(qr2, (int)t) : a.r2_fixed;
-		uint64_t m[NC];
-		#pragma unroll
-		for (int h = 0; h < NP; h++) {
-			const v2f d2 = dist_sq2<ARITH>(qx, qy, qz, cx[h], cy[h], cz[h]);
-			#pragma unroll
-			for (int u = 0; u < 2; u++) {
-				const int k = 2 * h + u;
-				if (k < NC) {
-					m[k] = __builtin_amdgcn_ballot_w64(d2[u] <= (SYM ? max_raw(r2q, cr2[k]) : r2q));   // (SYM: see process_batch)
-				}
-			}
-		}
-		if (SELF) {
-			// the query is always a hit of itself (d2 == 0) and sits at slot t (own-cell-first slot order)
-			asm("s_bitset0_b64 %0, %1" : "+s"(m[0]) : "s"(t));
-		}
-		// hits -> LDS staging area, lane-major
-		uint32_t addr;
-		{
-			uint32_t P = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[0] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[0], 0u));
-			#pragma unroll
-			for (int k = 1; k < NC; k++) P = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[k], P));
-			addr = stage_base + (P << 2);
-		}
-		stage_all<NC>(addr, m, cid);
-		const uint32_t cnt = (readlane_u32(addr, WAVE - 1) - stage_base) >> 2, len = cnt + 1u;
-#if TNSX_STAGE_PIPE
-		// the record staged by the PREVIOUS query leaves now -- its ds_read has had this query's tests to land (and it refers to
-		// the current base, so it goes before a possible slab change)
-		if (pend_cnt != 0u) { store_record64(rsrc, pend_pos, pend_cnt, (uint32_t)lane, pend_v); pend_cnt = 0u; }
-#endif
-		if (len > left) {
-			// rare: new slab (one atomic on the global cursor).  The queries so far refer to the old base: write them out first.
-			flush(t);
-			pool_waste(ps, left);
-			const uint32_t slab = NC > 8 ? a.pool_slab_heavy : a.pool_slab;
-			const uint32_t sz = len > slab ? len : slab;
-			const unsigned long long first = pool_take_slab(a.pool_cursor, a.pool_regions, sz, NC > 8 ? 1u : 0u);   // (more than 8 chunks: the fat tier)
-			base = ((uint64_t)readfirstlane_u32((uint32_t)(first >> 32)) << 32) | readfirstlane_u32((uint32_t)first);
-			ok = base != POOL_NONE ? 1u : 0u;
-			if (ok == 0u) base = 0;
-			rsrc = record_rsrc(a.records + base);
-			left = sz;
-			pos0 = 0;
-		}
-		if (ok != 0u) {
-			// the staged record -> global memory, 64 consecutive ints per store
-#if TNSX_STAGE_PIPE
-			pend_v = stage[lane]; pend_cnt = cnt; pend_pos = pos0;
-			for (uint32_t f = (uint32_t)WAVE; f < cnt; f += (uint32_t)WAVE) store_record64(rsrc, pos0, cnt, f + (uint32_t)lane, stage[f + (uint32_t)lane]);
-#else
-			for (uint32_t f = 0; f < cnt; f += (uint32_t)WAVE) store_record64(rsrc, pos0, cnt, f + (uint32_t)lane, stage[f + (uint32_t)lane]);
-#endif
-		}
-		// (lane select in m0: a VALU instruction of gfx9 may read only one SGPR besides it.  m0 is a reserved register that the
-		//  compiler loads right before each of its own uses -- none in this kernel -- so it is not, and cannot be, listed as clobbered)
-		asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(v_cnt), "+v"(v_pos) : "s"(cnt), "s"(pos0), "s"(t));
-		pos0 += 4u * len;
-		left -= len;
-		hits += cnt;
-	}
-#if TNSX_STAGE_PIPE
-	if (pend_cnt != 0u) store_record64(rsrc, pend_pos, pend_cnt, (uint32_t)lane, pend_v);
-#else
-	(void)pend_v; (void)pend_cnt; (void)pend_pos;
-#endif
-	flush(nq);
-	wave_hits += hits;
-	{
-		const uint64_t cur = base + (pos0 >> 2);
-		ps.cur_lo = (uint32_t)cur; ps.cur_hi = (uint32_t)(cur >> 32);
-		ps.left = left;
-		ps.ok = ok;
-	}
-}
-
-#endif   // TNSX_CELL_STAGE
 
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int NC>
 __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits)
@@ -894,10 +697,8 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 	constexpr bool OWN_FIRST = SELF;
 	const uint32_t nq = cur_q.y - cur_q.x;
 	const Runs R = extract_runs_t<OWN_FIRST>(RR.run_start, RR.run_len, cur_q.x);
-#if TNSX_DEAL_LDS
 	const uint32_t* const tbl = record_stage<(int)StageSize<NC>::ints>();
 	deal_table<OWN_FIRST>(readfirstlane_u32((uint32_t)(uintptr_t)tbl), R, (uint32_t)lane);
-#endif
 	// ---- candidates -> registers (branch-free, see process_batch)
 	v2f cx[NP], cy[NP], cz[NP];
 	uint32_t cid[2 * NP];
@@ -908,11 +709,7 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 	for (int k = 0; k < 2 * NP; k++) {
 		if (k < NC) {
 			const uint32_t slot = (uint32_t)(k * WAVE + lane);
-#if TNSX_DEAL_LDS
 			const uint32_t src = (k < NC - 1 || slot < R.total) ? tbl[slot] : R.d0;
-#else
-			const uint32_t src = (k < NC - 1 || slot < R.total) ? slot_to_src_t<OWN_FIRST>(slot, R) : R.d0;
-#endif
 			craw[k] = a.xyzi_j[src];
 			if (SYM) r2raw[k] = a.r2_j[src];
 		}
@@ -973,11 +770,7 @@ __device__ __forceinline__ uint32_t cull_round(const QueryArgs& a, const Runs R,
 	for (int k = 0; k < Q_MAXPAIRS * 2; k++) {
 		if ((uint32_t)k < nc) {
 			const uint32_t slot = base + (uint32_t)(k * WAVE + lane);
-#if TNSX_DEAL_LDS
 			const uint32_t src = slot < R.total ? tbl[slot] : R.d0;
-#else
-			const uint32_t src = slot < R.total ? slot_to_src_t<OWN_FIRST>(slot, R) : R.d0;
-#endif
 			craw[k] = a.xyzi_j[src];
 			if (SYM) r2raw[k] = a.r2_j[src];
 		}
@@ -1023,11 +816,7 @@ __device__ __forceinline__ void fast_cell_from_slots(const QueryArgs& a, const R
 		if (k < NC) {
 			const uint32_t i = (uint32_t)(k * WAVE + lane);
 			const uint32_t slot = lds_slots[i];                     // (slots past `kept` hold stale numbers: clamped below)
-#if TNSX_DEAL_LDS
 			const uint32_t src = (k < NC - 1 || i < kept) ? tbl[slot < R.total ? slot : 0u] : R.d0;
-#else
-			const uint32_t src = (k < NC - 1 || i < kept) ? slot_to_src_t<SELF>(slot < R.total ? slot : 0u, R) : R.d0;
-#endif
 			craw[k] = a.xyzi_j[src];
 			if (SYM) r2raw[k] = a.r2_j[src];
 		}
@@ -1076,9 +865,7 @@ __device__ __forceinline__ bool fast_cell_culled(const QueryArgs& a, const RunRe
 	const float r2q_max = VARIABLE ? wave_max_dpp(qr2) : a.r2_fixed;
 
 	const uint32_t* const tbl = record_stage<(int)StageSize<(FAT ? 16 : 8)>::ints>();
-#if TNSX_DEAL_LDS
 	deal_table<OWN_FIRST>(readfirstlane_u32((uint32_t)(uintptr_t)tbl), R, (uint32_t)lane);   // up to 1024 slots: inside the staging area
-#endif
 	uint32_t kept = 0;
 	for (uint32_t base = 0; base < R.total; base += (uint32_t)Q_SLOTS)
 		kept = readfirstlane_u32(cull_round<ARITH, SYM, OWN_FIRST>(a, R, lane, base, kept, lox, loy, loz, hix, hiy, hiz, r2q_max, lds_slots, tbl, SLOT_CAP));
