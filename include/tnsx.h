@@ -99,6 +99,9 @@ typedef struct tnsx_options {
 	                             nothing in the launch path reads the environment */
 	int bucket_build_min_points; /* sets with at least this many points are built with the two-pass bucket build where
 	                             their key allows it; 0 = default (65536), < 0: never (always the stable LSD passes + k_cell_table) */
+	int sparse_grid;          /* 0 = default: a grid too large for a dense cell table (a cloud that is sparse everywhere: a sheet, a filament) keeps cells of one
+	                             search radius as a SPARSE grid -- occupied-cell lists + block index, up to 2^32 cells -- instead of coarser cells; < 0: never
+	                             (coarsen the cells until a dense table fits, the behaviour of rounds 1-3) */
 	int query_formulation;    /* 0 = default: the cell kernels (candidates in the lanes).  1 = experiment of round 3, measured
 	                             SLOWER: a fixed-radius search of a set in itself first runs the group formulation --
 	                             16 query points of a cell per batch in the lanes, the tests as 16x16x4 fp32 MFMAs with an exact re-test
@@ -157,6 +160,8 @@ typedef struct tnsx_stats {
 	uint32_t n_group_pairs;       /* pairs of the last run that ran the group formulation */
 	uint32_t n_group_passed_cells; /* occupied cells it passed on to the cell kernels (too many candidates or query points, a list overflow, a point
 	                                 far outside its cell), summed over those pairs */
+	int grid_sparse;              /* 1: the grid of the last run had more cells than a dense table may have (tnsx_options.max_dense_cells); the cells kept their
+	                                 edge of one search radius and were held as key-ordered lists of occupied cells with a block index instead (slower look-ups) */
 	int one_read_builds;          /* point sets whose bucket build read the input once in the last run (windows from the previous run) */
 	int heavy_catchups;           /* pool passes whose heavy tiers (cells with > 512 candidates or > 64 query points) were not launched with the first
 	                                 tier -- the previous run of the pair had no such cell -- and had to run after the run's synchronisation */

@@ -266,3 +266,52 @@ def test_c5_full_size_200m_one_rank_through_the_slab_layer():
     slab.step(d_p, gids)
     st = ns.get_stats()
     assert st["n_neighbors"] == total and st["speculated"] == 1
+
+
+def test_sparse_grid_10m_filament(oracle):
+    """SURVEY.md section 8 / round-3 verdict item 8 at its stated size: a 10 M-point filament that winds through the whole box -- a grid of ~3 x 10^9 cells of
+    one search radius, 0.2 % of them occupied.  With sparse_grid = 1 the cells keep their edge (tnsx_stats.grid_sparse: lists of occupied cells + block index
+    instead of a dense table) and the lists equal the CPU restatement's, by count per point and by the order-independent digest; the coarse dense grid of
+    rounds 1-3 (sparse_grid = -1) gives the same digest and is timed beside it.  (The grid is three times the dense bound: the default would coarsen the
+    cells by 1.6 -- the faster choice for a cloud this thin, DESIGN.md section 9 -- and switches to the sparse grid from eight times on.)"""
+    import time
+    import torch
+    import treensearch_amd as T
+    n = 10_000_000
+    rng = np.random.default_rng(3)
+    t = np.sort(rng.random(n))
+    turns = 420.0
+    ang = 2.0 * np.pi * turns * t
+    r = np.float32(0.00075)
+    pts = np.stack([0.5 + 0.45 * np.cos(ang), 0.5 + 0.45 * np.sin(ang), 0.02 + 0.96 * t], axis=1)
+    pts += (rng.random((n, 3)) - 0.5) * (0.6 * float(r))
+    pts = np.ascontiguousarray(pts.astype(np.float32))
+    d = torch.from_numpy(pts).cuda()
+    times = {}
+    res = {}
+    for name, kw in (("sparse", {"sparse_grid": 1}), ("coarse", {"sparse_grid": -1})):
+        ns = T.TreeNSearch(**kw)
+        ns.set_search_radius(r)
+        ns.add_point_set(d)
+        ns.set_active_search(0, 0, True)
+        ns.run(); ns.run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ns.run()
+        times[name] = (time.perf_counter() - t0) / 3 * 1e3
+        st = ns.get_stats()
+        if name == "sparse":
+            assert st["grid_sparse"] == 1 and abs(st["grid_cell_size"] / float(r) - 1.0) < 1e-3, (st["grid_sparse"], st["grid_cell_size"])
+            assert st["n_occupied_cells"] * 100 < st["n_grid_cells"], "less than 1 % of the grid is occupied"
+        else:
+            assert st["grid_sparse"] == 0 and st["grid_cell_size"] > 1.2 * float(r)
+        offs, idx = ns.neighbor_csr(0, 0, sort_each=False)
+        res[name] = (offs, oracle.digest(offs, idx, already_sorted=False))
+        del ns
+    ro, ri = oracle.pair_search(pts, pts, radius=r, same_set=True)
+    want = oracle.digest(ro, ri, already_sorted=True)
+    for name in res:
+        assert np.array_equal(res[name][0], ro), f"{name}: neighbour counts differ from the CPU restatement"
+        assert res[name][1] == want, f"{name}: lists differ from the CPU restatement"
+    print(f"10 M-point filament, {int(ro[-1])} neighbours: sparse grid {times['sparse']:.2f} ms per run, coarse dense grid {times['coarse']:.2f} ms")

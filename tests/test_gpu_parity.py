@@ -409,3 +409,63 @@ def test_group_formulation_points_on_the_radius(oracle):
     ora = oracle.pair_search(pts, pts, radius=float(r), same_set=True, mode=0)
     P.assert_same_csr(lists[1], ora, "group formulation vs oracle, points on the radius")
     assert int(ora[0][-1]) >= 6 * 22 ** 3          # (the inner points see at least their six axis neighbours at d == r)
+
+
+def _filament(n, turns, seed, jitter):
+    """n points along a helix that winds through the unit cube, jittered: sparse EVERYWHERE -- a bounding box of ~10^9 cells of one radius, < 0.1 % occupied"""
+    rng = np.random.default_rng(seed)
+    t = np.sort(rng.random(n))
+    ang = 2.0 * np.pi * turns * t
+    p = np.stack([0.5 + 0.4 * np.cos(ang), 0.5 + 0.4 * np.sin(ang), 0.05 + 0.9 * t], axis=1)
+    p += (rng.random((n, 3)) - 0.5) * jitter
+    return np.ascontiguousarray(p.astype(np.float32))
+
+
+def test_sparse_grid_keeps_cells_of_one_radius(oracle):
+    """Round 4: a cloud that is sparse everywhere (a filament through the whole box) used to get coarser cells until a dense table fitted.  Now the
+    cells keep their edge of one search radius and the grid is held as key-ordered lists of occupied cells with a block index (tnsx_stats.grid_sparse);
+    lists exact against the CPU restatement, over moving points (the sparse grid is reused like any other), with per-point radii, and for a pair of
+    two different sets."""
+    import treensearch_amd as T
+    n = 300000
+    r = np.float32(0.0009)
+    pts = _filament(n, 14.0, 3, 0.5 * float(r))
+    ns = T.TreeNSearch()
+    ns.set_search_radius(r)
+    ns.add_point_set(pts)
+    ns.set_active_search(0, 0, True)
+    rng = np.random.default_rng(1)
+    for step in range(3):
+        ns.run()
+        st = ns.get_stats()
+        assert st["grid_sparse"] == 1 and st["n_grid_cells"] > (1 << 29), st["n_grid_cells"]
+        assert abs(st["grid_cell_size"] / float(r) - 1.0) < 1e-3, "the cells must stay one search radius wide"
+        assert st["n_occupied_cells"] < st["n_grid_cells"] // 1000
+        assert step == 0 or (st["speculated"] == 1 and st["speculation_redos"] == 0)
+        ro, ri = oracle.pair_search(pts, pts, radius=r, same_set=True)
+        assert ro[-1] > 10 * n, "the filament should have neighbours to find"
+        P.assert_same_csr(ns.neighbor_csr(0, 0), (ro, ri), f"filament, run {step}")
+        pts[2:] += (rng.random((n - 2, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(0.1) * r
+    # the same grid forced dense-and-coarse (rounds 1-3): identical lists
+    old = T.TreeNSearch(sparse_grid=-1)
+    old.set_search_radius(r); old.add_point_set(pts); old.set_active_search(0, 0, True); old.run()
+    assert old.get_stats()["grid_sparse"] == 0 and old.get_stats()["grid_cell_size"] > 1.5 * float(r)
+    ns.run()
+    a, b = ns.neighbor_csr(0, 0), old.neighbor_csr(0, 0)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # two sets (filament + a second, shifted one), searches 0->0, 0->1 and 1->0, per-point radii, symmetric
+    q = _filament(120000, 14.0, 4, 0.5 * float(r)) + np.float32(0.0004)
+    ra = (r * (1.0 + rng.random(n))).astype(np.float32)
+    rq = (r * (1.0 + rng.random(len(q)))).astype(np.float32)
+    nv = T.TreeNSearch(sparse_grid=1)     # (cells of 2 r: the grid is within 8 x of the dense bound, where the default coarsens instead)
+    nv.add_point_set(pts, ra); nv.add_point_set(q, rq)
+    for (i, j) in [(0, 0), (0, 1), (1, 0)]:
+        nv.set_active_search(i, j, True)
+    nv.set_symmetric_search(True)
+    for step in range(2):
+        nv.run()
+        assert nv.get_stats()["grid_sparse"] == 1
+        sets = [(pts, ra), (q, rq)]
+        for (i, j) in [(0, 0), (0, 1), (1, 0)]:
+            ref = oracle.pair_search(sets[i][0], sets[j][0], ra=sets[i][1], rb=sets[j][1], symmetric=True, same_set=(i == j))
+            P.assert_same_csr(nv.neighbor_csr(i, j), ref, f"two filaments, per-point radii, pair {i}->{j}, run {step}")

@@ -36,7 +36,7 @@ class _Options(C.Structure):
     _fields_ = [("device_id", C.c_int), ("stream", C.c_void_p), ("arith", C.c_int), ("mirror_to_host", C.c_int),
                 ("collect_stage_times", C.c_int), ("exact_layout", C.c_int), ("max_dense_cells", C.c_uint64), ("temporal_reuse", C.c_int),
                 ("sorted_lists", C.c_int), ("n_devices", C.c_int), ("device_ids", C.c_int * 8), ("query_blocks_per_cu", C.c_int),
-                ("fast_blocks_per_cu", C.c_int), ("bucket_build_min_points", C.c_int), ("query_formulation", C.c_int)]
+                ("fast_blocks_per_cu", C.c_int), ("bucket_build_min_points", C.c_int), ("sparse_grid", C.c_int), ("query_formulation", C.c_int)]
 
 
 class _CsrView(C.Structure):
@@ -56,7 +56,7 @@ class Stats(C.Structure):
                 ("n_pool_pairs", C.c_int), ("pool_retries", C.c_int), ("cold_passes", C.c_int), ("speculated", C.c_int),
                 ("speculation_redos", C.c_int), ("n_cached_sets", C.c_int), ("n_filtered_cells", C.c_uint32), ("n_devices_used", C.c_int),
                 ("world_bottom", C.c_float * 3), ("world_top", C.c_float * 3), ("world_cells_pow2", C.c_int), ("zsort_cell_size_inv", C.c_float),
-                ("grid_trimmed", C.c_int), ("n_group_pairs", C.c_uint32), ("n_group_passed_cells", C.c_uint32), ("one_read_builds", C.c_int), ("heavy_catchups", C.c_int)]
+                ("grid_trimmed", C.c_int), ("n_group_pairs", C.c_uint32), ("n_group_passed_cells", C.c_uint32), ("grid_sparse", C.c_int), ("one_read_builds", C.c_int), ("heavy_catchups", C.c_int)]
 
     def as_dict(self):
         d = {}
@@ -236,7 +236,7 @@ class TreeNSearch:
                  stream: Optional[int] = None, collect_stage_times: bool = False, max_dense_cells: int = 0,
                  exact_layout: bool = False, temporal_reuse: bool = True, sorted_lists: bool = False, devices=None,
                  query_blocks_per_cu: int = 0, fast_blocks_per_cu: int = 0, bucket_build_min_points: int = 0,
-                 query_formulation: int = 0):
+                 query_formulation: int = 0, sparse_grid: int = 0):
         """devices: a list of HIP device ordinals -> multi-device mode (host-resident inputs only, see include/tnsx.h)"""
         self._L = load_library()
         opt = _Options()
@@ -253,6 +253,7 @@ class TreeNSearch:
         opt.query_blocks_per_cu = int(query_blocks_per_cu)
         opt.fast_blocks_per_cu = int(fast_blocks_per_cu)
         opt.bucket_build_min_points = int(bucket_build_min_points)
+        opt.sparse_grid = int(sparse_grid)
         opt.query_formulation = int(query_formulation)
         if devices is not None and len(devices) > 1:
             opt.n_devices = len(devices)

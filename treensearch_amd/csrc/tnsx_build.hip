@@ -66,8 +66,8 @@ __device__ __forceinline__ uint32_t cell_key(float x, float y, float z, const Gr
 	const int ix = bin_coord(x, g.ox, g.inv_h, g.nx);
 	const int iy = bin_coord(y, g.oy, g.inv_h, g.ny);
 	const int iz = bin_coord(z, g.oz, g.inv_h, g.nz);
-	const uint32_t key = (uint32_t)((iz * g.ny + iy) * g.nx + ix);
-	return x != x ? (uint32_t)(g.nx * g.ny * g.nz) : key;
+	const uint32_t key = ((uint32_t)iz * (uint32_t)g.ny + (uint32_t)iy) * (uint32_t)g.nx + (uint32_t)ix;   // (unsigned: a sparse grid may have up to 2^32 - 16 cells)
+	return x != x ? (uint32_t)g.nx * (uint32_t)g.ny * (uint32_t)g.nz : key;
 }
 // the two sort keys: MORTON = false the cell key of the search grid, MORTON = true the Morton code of the cell on the reference's
 // grid (prepare_zsort; up to 63 bits)
@@ -553,6 +553,126 @@ void launch_cell_table(const float4* xyzi_sorted, int n, GridParams g, uint2* ta
 }
 
 // =====================================================================================================
+// SPARSE grids (round 4): no dense cell table at all.  A cloud that is sparse everywhere -- a sheet, a filament -- has a bounding box of billions of
+// cells of one search radius; rounds 1-3 coarsened the cells until a dense table fitted (exact, but every query then tests 8x the candidates per doubling).
+// Here the cells keep their edge (any grid of up to 2^32 - 16 cells: 32-bit keys) and the search structure is the list of OCCUPIED cells in key order,
+// {first sorted position, key} with a sentinel behind it (a cell ends where the next one begins), plus a block index: blk[b] = first list entry whose key
+// is >= b << shift, one entry per 2^shift keys (at most 4 M entries).  A lookup is blk[b], blk[b + 1] and a binary search over the handful of entries between
+// them (tnsx_device.h sparse_find): three or four dependent loads instead of one -- slower per cell than the dense table, and far cheaper than coarser cells.
+//   k_sparse_cells<false>  cell starts per tile of 4096 sorted points        -> counts[tile]
+//   k_sparse_scan          exclusive scan of the tile counts (one workgroup)  -> counts[tile] = first list entry of the tile, *n_occ
+//   k_sparse_cells<true>   the entries, in position (= key) order; the sentinel behind the last one
+//   k_sparse_blocks        the block index
+// NaN-x points (key == n_cells: no points) sort behind every cell; the sentinel starts where they start.
+// =====================================================================================================
+template <bool WRITE>
+__global__ void __launch_bounds__(CT_THREADS) k_sparse_cells(const float4* __restrict__ xyzi, int n, GridParams g, uint32_t* __restrict__ counts, uint2* __restrict__ occ)
+{
+	__shared__ uint32_t sk[CT_TILE + 1];                        // keys of the tile, one halo entry in front
+	__shared__ uint32_t wcnt[CT_ITEMS * (CT_THREADS / WAVE) + 1];
+	const int w = threadIdx.x / WAVE;
+	const size_t base = (size_t)blockIdx.x * CT_TILE;
+	const uint32_t n_cells = (uint32_t)g.nx * (uint32_t)g.ny * (uint32_t)g.nz;
+	#pragma unroll
+	for (int i = 0; i < CT_ITEMS; i++) {
+		const size_t p = base + (size_t)i * CT_THREADS + threadIdx.x;
+		if (p < (size_t)n) { const float4 q = xyzi[p]; sk[1 + i * CT_THREADS + threadIdx.x] = cell_key(q.x, q.y, q.z, g); }
+	}
+	if (threadIdx.x == 0 && base > 0) { const float4 q = xyzi[base - 1]; sk[0] = cell_key(q.x, q.y, q.z, g); }
+	__syncthreads();
+	uint32_t flags = 0;       // bit i: a cell starts at this thread's point of round i (real cells only)
+	uint32_t nan_start = 0;   // bit i: the NaN points start there (at most one such point in the whole array)
+	#pragma unroll
+	for (int i = 0; i < CT_ITEMS; i++) {
+		const int t = i * CT_THREADS + (int)threadIdx.x;
+		const size_t p = base + (size_t)t;
+		bool is_start = false;
+		if (p < (size_t)n) {
+			const uint32_t k = sk[1 + t];
+			const bool first_of_key = (p == 0) || (sk[t] != k);
+			is_start = first_of_key && k < n_cells;
+			nan_start |= (first_of_key && k >= n_cells ? 1u : 0u) << i;
+		}
+		flags |= (is_start ? 1u : 0u) << i;
+		const uint64_t m = __builtin_amdgcn_ballot_w64(is_start);
+		if (lane_id() == 0) wcnt[i * (CT_THREADS / WAVE) + w] = (uint32_t)__popcll(m);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t s = 0;
+		for (int q = 0; q < CT_ITEMS * (CT_THREADS / WAVE); q++) { const uint32_t t = wcnt[q]; wcnt[q] = s; s += t; }
+		wcnt[CT_ITEMS * (CT_THREADS / WAVE)] = s;
+		if (!WRITE) counts[blockIdx.x] = s;
+	}
+	if (!WRITE) return;
+	__syncthreads();
+	const uint32_t bb = counts[blockIdx.x];   // (scanned: the first list entry of this tile)
+	#pragma unroll
+	for (int i = 0; i < CT_ITEMS; i++) {
+		const bool is_start = (flags >> i) & 1u;
+		const uint64_t m = __builtin_amdgcn_ballot_w64(is_start);
+		const int t = i * CT_THREADS + (int)threadIdx.x;
+		const uint32_t rank = bb + wcnt[i * (CT_THREADS / WAVE) + w] + mbcnt64(m);
+		if (is_start) occ[rank] = make_uint2((uint32_t)(base + (size_t)t), sk[1 + t]);
+		else if ((nan_start >> i) & 1u) occ[rank] = make_uint2((uint32_t)(base + (size_t)t), 0xffffffffu);   // the sentinel: every real start lies in front of it
+	}
+	// no NaN point at all: the sentinel stands behind the last point
+	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+		const float4 q = xyzi[n - 1];
+		if (cell_key(q.x, q.y, q.z, g) < n_cells) occ[bb + wcnt[CT_ITEMS * (CT_THREADS / WAVE)]] = make_uint2((uint32_t)n, 0xffffffffu);
+	}
+}
+__global__ void __launch_bounds__(1024) k_sparse_scan(uint32_t* __restrict__ counts, int ntiles, uint32_t* __restrict__ n_occ)
+{
+	__shared__ uint32_t red[1024 / WAVE];
+	__shared__ uint32_t carry;
+	if (threadIdx.x == 0) carry = 0u;
+	__syncthreads();
+	for (int t0 = 0; t0 < ntiles; t0 += 1024) {
+		const int t = t0 + (int)threadIdx.x;
+		const uint32_t v = t < ntiles ? counts[t] : 0u;
+		uint32_t inc = v;
+		#pragma unroll
+		for (int o = 1; o < WAVE; o <<= 1) { const uint32_t u = __shfl_up(inc, o, WAVE); if (lane_id() >= o) inc += u; }
+		if (lane_id() == WAVE - 1) red[threadIdx.x / WAVE] = inc;
+		__syncthreads();
+		uint32_t before = carry;
+		for (int k = 0; k < (int)(threadIdx.x / WAVE); k++) before += red[k];
+		if (t < ntiles) counts[t] = before + inc - v;
+		__syncthreads();
+		if (threadIdx.x == 1023) carry = before + inc;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) *n_occ = carry;
+}
+// blk[b] = first entry of occ (n_occ entries + sentinel) whose key is >= b << shift, b = 0 .. n_blocks (blk[n_blocks] = n_occ): one lower bound per
+// block (a thread per entry filling the gap in front of it would be cheaper on average and arbitrarily unbalanced on a cloud that sits in a few cells)
+__global__ void __launch_bounds__(256) k_sparse_blocks(const uint2* __restrict__ occ, const uint32_t* __restrict__ n_occ_p, int shift, uint32_t n_blocks, uint32_t* __restrict__ blk)
+{
+	const uint32_t n_occ = *n_occ_p;
+	for (uint32_t b = blockIdx.x * 256u + threadIdx.x; b <= n_blocks; b += gridDim.x * 256u) {
+		uint32_t lo = 0, hi = n_occ;
+		if (b < n_blocks) {
+			const uint32_t key = b << shift;
+			while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (occ[mid].y < key) lo = mid + 1u; else hi = mid; }
+		}
+		else lo = n_occ;
+		blk[b] = lo;
+	}
+}
+void launch_sparse_cells(const float4* xyzi_sorted, int n, GridParams g, int shift, uint32_t n_blocks, void* temp, uint2* occ, uint32_t* n_occ, uint32_t* blk, hipStream_t s)
+{
+	if (n <= 0) return;
+	const int ntiles = (n + CT_TILE - 1) / CT_TILE;
+	uint32_t* counts = (uint32_t*)temp;   // (the sort is done with its tables: ntiles words)
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sparse_cells<false>), dim3(ntiles), dim3(CT_THREADS), 0, s, xyzi_sorted, n, g, counts, occ);
+	hipLaunchKernelGGL(k_sparse_scan, dim3(1), dim3(1024), 0, s, counts, ntiles, n_occ);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sparse_cells<true>), dim3(ntiles), dim3(CT_THREADS), 0, s, xyzi_sorted, n, g, counts, occ);
+	const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n_blocks + 256) / 256, 8192);
+	hipLaunchKernelGGL(k_sparse_blocks, dim3(blocks), dim3(256), 0, s, occ, n_occ, shift, n_blocks, blk);
+}
+
+// =====================================================================================================
 // The build in TWO passes with the cell table for free (round 3): bucket pass + bucket-local counting sort.
 //   pass A  the ordinary histogram / scan / ranked-scatter pass on the HIGH digit of the cell key (it also carries the run-time
 //           checks of the speculation): the points land grouped by bucket = 2^lo consecutive cells, i.e. a few x-rows of the grid
@@ -854,9 +974,16 @@ bool cell_build_uses_buckets(int n, int key_bits, bool stable_order, int bucket_
 size_t bucket_window_slots(int n, int n_buckets) { return (size_t)n + (size_t)n / 8 + (size_t)n_buckets * 72 + 64; }   // >= the sum of bucket_window_cap over any counts that sum to n
 int launch_cell_build(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, const int* ids,
                       uint32_t* orig_sorted, const BuildGuard& gd, uint32_t query_limit, bool stable_order, int bucket_min_points, uint2* table, uint2* occ,
-                      uint32_t* n_occ, int* passes_out, const BucketWindows& bw, hipStream_t s)
+                      uint32_t* n_occ, int* passes_out, const BucketWindows& bw, const SparseCells& sp, hipStream_t s)
 {
 	int hi_bits = 0, lo_bits = 0;
+	if (sp.blk) {
+		// sparse grid: stable LSD passes, then the key-ordered list of occupied cells and its block index instead of a table
+		const int res = launch_cell_sort(xyz, radii, n, g, key_bits, b, temp, ids, orig_sorted, gd, s);
+		launch_sparse_cells(b.xyzi[res], n, g, sp.shift, sp.n_blocks, temp, occ, n_occ, sp.blk, s);
+		if (passes_out) *passes_out = cell_sort_plan(key_bits).passes;
+		return res;
+	}
 	if (stable_order || !bucket_plan(key_bits, n, bucket_min_points, hi_bits, lo_bits)) {
 		const int res = launch_cell_sort(xyz, radii, n, g, key_bits, b, temp, ids, orig_sorted, gd, s);
 		launch_cell_table(b.xyzi[res], n, g, table, occ, n_occ, s);

@@ -34,6 +34,19 @@ __device__ __forceinline__ int bin_coord(float p, float o, float inv_h, int n)
 	c = c < 0 ? 0 : c;
 	return c > n - 1 ? n - 1 : c;
 }
+// sparse grid: {first, one past last} sorted position of the cell with this key, or (0, 0) -- occ is the key-ordered list of occupied cells with a sentinel
+// behind it, blk[b] the first entry whose key is >= b << shift (tnsx_build.hip, k_sparse_blocks)
+__device__ __forceinline__ uint2 sparse_find(const uint2* __restrict__ occ, const uint32_t* __restrict__ blk, int shift, uint32_t key)
+{
+	const uint32_t b = key >> shift;
+	uint32_t lo = blk[b], hi = blk[b + 1u];
+	while (lo < hi) {                       // lower bound of key in occ[lo, hi)
+		const uint32_t mid = (lo + hi) >> 1;
+		if (occ[mid].y < key) lo = mid + 1u; else hi = mid;
+	}
+	const uint2 e = occ[lo], nx = occ[lo + 1u];   // (lo <= n_occ: the sentinel's key is 0xffffffff; the slot behind it is allocated)
+	return e.y == key ? make_uint2(e.x, nx.x) : make_uint2(0u, 0u);
+}
 // spreads the low 21 bits of v to every third bit (libmorton's 3-D encoding: x -> bit 0, y -> bit 1, z -> bit 2)
 __device__ __forceinline__ uint64_t spread3(uint64_t v)
 {

@@ -89,6 +89,7 @@ struct PointSet {
 	// search structures
 	DevBuf xyzi[2], r2[2];             // ping-pong of the cell sort; [sorted_buf] holds the sorted points of this run
 	DevBuf table, occ;
+	DevBuf blk;                    // sparse grid: block index of the occupied-cell list
 	int sorted_buf = 0;
 	// The cell table is never memset per run (it may be gigabytes for a sparse domain): the entries a run sets are exactly the
 	// keys of its occupied-cell list, and the next run clears those first.  0 = all zero, 1 = `table_dirty` entries of `occ`
@@ -175,6 +176,8 @@ struct tnsx_context {
 	bool grid_valid = false, grid_variable = false;
 	bool grid_box_scalar = false;   // the world box the grid was laid out under came from run_scalar()'s rule (no origin) / run()'s (united with the origin)
 	bool grid_trimmed = false;      // the grid covers the bulk of the points only (trim_box)
+	bool grid_sparse = false;       // no dense cell table: key-ordered lists of occupied cells + block indices (tnsx_build.hip, "SPARSE grids")
+	int sparse_shift = 0; uint32_t sparse_blocks = 0;
 	uint32_t grid_gen = 0;
 	float zsort_inv_h = 0.0f;   // 1 / quantisation step of the last prepare_zsort (tnsx_stats.zsort_cell_size_inv)
 	bool auto_dense_cells = true;
@@ -780,14 +783,28 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			const double n0 = std::floor(max_ext / (double)r_max) + 2.0;
 			double h = (double)r_max * (1.0 + 8.0 * 5.9604644775390625e-08 * (n0 + 2.0)) * (1.0 + 1e-6);
 			bool fits = false;
+			// A grid whose dense table does not fit keeps its cell edge as a SPARSE grid (round 4: lists of occupied cells instead of a table) as long as
+			// its cells can be numbered with 32 bits; only beyond that are the cells coarsened (exact either way; coarser cells cost candidates).
+			// (sparse_grid > 0: always; 0: when the bound of the dense table is the automatic one -- a caller who sets max_dense_cells asked for THAT many
+			//  cells -- and the cell edge would have to double.  Measured, tools/sparse_probe.py, a 10 M-point filament through the whole box with 3 - 6 points
+			//  per cell: cells 1.6 x coarser make the run 2.04 ms, the sparse grid at one radius 4.07 ms -- such clouds pay per CELL, the coarser grid has
+			//  fewer, and the sparse grid is served by the general kernel alone.  The sparse grid wins where coarsening costs candidates by the cube.)
+			const bool sparse_ok = c->opt.sparse_grid > 0 || (c->opt.sparse_grid == 0 && c->auto_dense_cells);
+			auto cells_at = [&](double hh) { return (std::floor(ext[0] / hh) + 1.0) * (std::floor(ext[1] / hh) + 1.0) * (std::floor(ext[2] / hh) + 1.0); };
+			const double cells0 = cells_at(h);
+			const bool want_sparse = sparse_ok && cells0 > (double)cell_cap && (c->opt.sparse_grid > 0 || cells0 > 8.0 * (double)cell_cap);
+			const double limit = want_sparse ? 4294967280.0 : (double)cell_cap;   // (a grid beyond 32-bit keys is coarsened until it fits as a sparse one)
+			bool sparse = false;
 			for (int it = 0; it < 400 && !fits; it++) {
 				const double nx = std::floor(ext[0] / h) + 1.0, ny = std::floor(ext[1] / h) + 1.0, nz = std::floor(ext[2] / h) + 1.0;
-				if (nx * ny * nz <= (double)cell_cap && nx < 2.0e9 && ny < 2.0e9 && nz < 2.0e9) {
+				if (nx * ny * nz <= limit && nx < 2.0e6 && ny < 2.0e6 && nz < 2.0e6) {
 					g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz;
+					sparse = nx * ny * nz > (double)cell_cap;
 					fits = true;
 				}
 				else h *= 1.26;
 			}
+			c->grid_sparse = sparse;
 			if (!fits) TNSX_FAIL(c, TNSX_ERR_INVALID, "no search grid fits the extent of the points");
 			g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2];
 			float hf = (float)h;
@@ -804,10 +821,11 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			c->grid_trimmed = trimmed;
 			c->grid_gen++;
 		}
-		else { g.nx = g.ny = g.nz = 1; g.inv_h = 1.0f; c->grid = g; c->grid_h = 0.0f; c->grid_trimmed = false; }
+		else { g.nx = g.ny = g.nz = 1; g.inv_h = 1.0f; c->grid = g; c->grid_h = 0.0f; c->grid_trimmed = false; c->grid_sparse = false; }
 	}
 	g = c->grid;
 	n_cells = (uint64_t)g.nx * g.ny * g.nz;
+	const bool sparse = c->grid_sparse;
 	S.grid_cell_size = c->grid_h;
 	for (int d = 0; d < 3; d++) { S.world_bottom[d] = c->world[d]; S.world_top[d] = c->world[3 + d]; }
 	S.world_cells_pow2 = c->world_cells_pow2;
@@ -815,8 +833,10 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	S.grid_origin[0] = g.ox; S.grid_origin[1] = g.oy; S.grid_origin[2] = g.oz;
 	S.n_grid_cells = n_cells;
 	S.grid_trimmed = c->grid_trimmed ? 1 : 0;
+	S.grid_sparse = sparse ? 1 : 0;
 	const int key_bits = std::max(1, ceil_log2_u64(n_cells + 1));   // + 1: the key behind the last cell, where NaN points ("no point") go
 	S.key_bits = key_bits;
+	if (sparse) { c->sparse_shift = std::max(0, key_bits - 22); c->sparse_blocks = (uint32_t)(((n_cells - 1) >> c->sparse_shift) + 1); }
 	S.radix_passes = tnsx::cell_sort_plan(key_bits).passes;
 	S.speculated = speculate ? 1 : 0;
 
@@ -835,7 +855,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	auto keeps_its_build = [&](const PointSet& s) {
 		const bool same_input = s.chk_valid && s.chk_xyz == s.user_xyz && s.chk_radii == s.user_radii && s.chk_n == s.n && s.chk_double == s.is_double;
 		const bool cacheable = !s.user_ids && s.n > 0;
-		return speculate && cacheable && s.predicted_static && same_input && s.built_gen == c->grid_gen && s.table_state == 1;
+		return speculate && cacheable && s.predicted_static && same_input && s.built_gen == c->grid_gen && (sparse || s.table_state == 1);
 	};
 
 	// ---- per active pair: what its pass needs on the host side (sizes from the previous run; nothing here waits for the device).
@@ -957,18 +977,29 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			if (si < 64) rb.sets |= 1ull << si;
 			else HIPCHK(c, hipMemsetAsync(c->n_occ.as<uint32_t>() + si, 0, sizeof(uint32_t), st));
 			// the table is needed even for empty sets (they can be searched into)
-			const void* old_table = s.table.p;
-			HIPCHK(c, s.table.reserve(n_cells * sizeof(uint2)));
-			if (s.table.p != old_table || s.table_state == 2) HIPCHK(c, hipMemsetAsync(s.table.p, 0, s.table.cap, st));   // new or unknown: all of it
-			else if (s.table_state == 1 && s.table_dirty > 0) {
-				if (rb.n_clear < tnsx::RUN_BEGIN_MAX_SETS) rb.clear[rb.n_clear++] = { s.occ.as<uint2>(), s.table.as<uint2>(), s.table_dirty };
-				else tnsx::launch_table_clear(s.occ.as<uint2>(), s.table_dirty, s.table.as<uint2>(), st);
+			if (sparse) {
+				// no table: the block index is written in full by every build; an empty set gets an all-zero index + sentinel here
+				const void* old_blk = s.blk.p;
+				HIPCHK(c, s.blk.reserve(((size_t)c->sparse_blocks + 2) * sizeof(uint32_t)));
+				HIPCHK(c, s.occ.reserve(((size_t)std::max(s.n, 1) + 2) * sizeof(uint2)));
+				if (s.n == 0 || s.blk.p != old_blk) HIPCHK(c, hipMemsetAsync(s.blk.p, 0, s.blk.cap, st));
+				if (s.n == 0) { const uint2 sent[2] = { { 0u, 0xffffffffu }, { 0u, 0xffffffffu } }; HIPCHK(c, hipMemcpyAsync(s.occ.p, sent, sizeof(sent), hipMemcpyHostToDevice, st)); }
+				s.table_state = 2;   // (should the next run be dense again: a table of unknown content)
 			}
-			s.table_state = 0; s.table_dirty = 0;
+			else {
+				const void* old_table = s.table.p;
+				HIPCHK(c, s.table.reserve(n_cells * sizeof(uint2)));
+				if (s.table.p != old_table || s.table_state == 2) HIPCHK(c, hipMemsetAsync(s.table.p, 0, s.table.cap, st));   // new or unknown: all of it
+				else if (s.table_state == 1 && s.table_dirty > 0) {
+					if (rb.n_clear < tnsx::RUN_BEGIN_MAX_SETS) rb.clear[rb.n_clear++] = { s.occ.as<uint2>(), s.table.as<uint2>(), s.table_dirty };
+					else tnsx::launch_table_clear(s.occ.as<uint2>(), s.table_dirty, s.table.as<uint2>(), st);
+				}
+				s.table_state = 0; s.table_dirty = 0;
+			}
 			// the bucket build's first pass in one read: the previous build of this set on this grid left a window per bucket (see k_bucket_scatter);
 			// an overflowing window raises the guard flag like a point outside the box does
 			int nb = 0;
-			s.bk_now = s.n > 0 && tnsx::cell_build_uses_buckets(s.n, key_bits, c->opt.exact_layout != 0, c->opt.bucket_build_min_points, &nb);
+			s.bk_now = !sparse && s.n > 0 && tnsx::cell_build_uses_buckets(s.n, key_bits, c->opt.exact_layout != 0, c->opt.bucket_build_min_points, &nb);
 			s.bk_used = false;
 			if (s.bk_now) {
 				const void* old_win = s.bk_win.p;
@@ -1007,10 +1038,10 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			S.n_cached_sets++;
 			continue;
 		}
-		HIPCHK(c, s.occ.reserve((size_t)std::max(s.n, 1) * sizeof(uint2)));   // (after the clear, which reads the previous list, has been enqueued)
+		HIPCHK(c, s.occ.reserve(((size_t)std::max(s.n, 1) + 2) * sizeof(uint2)));   // (after the clear, which reads the previous list, has been enqueued; + sentinel)
 		s.built_gen = 0;
 		if (s.n == 0) continue;
-		s.table_state = 2;   // until this run's occupied-cell count has reached the host
+		if (!sparse) s.table_state = 2;   // until this run's occupied-cell count has reached the host
 		for (int k = 0; k < 2; k++) {
 			// ([1] is the intermediate array of the bucket build: its buckets lie in windows with some slack)
 			HIPCHK(c, s.xyzi[k].reserve((k == 1 && s.bk_now ? tnsx::bucket_window_slots(s.n, s.bk_buckets) : (size_t)s.n) * sizeof(float4)));
@@ -1040,7 +1071,8 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		s.sorted_buf = tnsx::launch_cell_build(s.d_xyz, variable ? s.d_radii : nullptr, s.n, g, key_bits, cb, c->sort_temp.p, s.user_ids,
 		                                       s.user_ids ? s.orig_sorted.as<uint32_t>() : nullptr, gd, q_limit, c->opt.exact_layout != 0,
 		                                       c->opt.bucket_build_min_points, s.table.as<uint2>(), s.occ.as<uint2>(), c->n_occ.as<uint32_t>() + si, &passes,
-		                                       tnsx::BucketWindows{ s.bk_used && gd.flag != nullptr, s.bk_now ? s.bk_win.as<uint2>() : nullptr, s.bk_cur.as<uint32_t>() }, st);
+		                                       tnsx::BucketWindows{ s.bk_used && gd.flag != nullptr, s.bk_now ? s.bk_win.as<uint2>() : nullptr, s.bk_cur.as<uint32_t>() },
+		                                       tnsx::SparseCells{ sparse ? s.blk.as<uint32_t>() : nullptr, c->sparse_shift, c->sparse_blocks }, st);
 		S.radix_passes = passes;
 		if (s.bk_used) S.one_read_builds++;
 	}
@@ -1078,11 +1110,12 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		//  different sets, the group formulation for a set searched in itself)
 		a.heavy0 = pr.filtered.as<uint2>();
 		a.n_heavy0 = ctrl_slot(k, tnsx::CTRL_NFILTERED);
+		if (sparse) { a.socc_i = A.occ.as<uint2>(); a.blk_i = A.blk.as<uint32_t>(); a.socc_j = B.occ.as<uint2>(); a.blk_j = B.blk.as<uint32_t>(); a.sparse_shift = c->sparse_shift; }
 		a.abort_flag = speculate ? reinterpret_cast<const uint32_t*>(d_words) : nullptr;
 		a.pool_slab = pr.pool_slab;
 		a.pool_slab_heavy = std::max<uint32_t>(pr.pool_slab, 8192u);
 		a.shared_empty = jb.pool && jb.i != jb.j ? 1u : 0u;
-		if (a.shared_empty && pr.n_query > 0) {
+		if (a.shared_empty && pr.n_query > 0 && !sparse) {
 			// the query walks the cells that have candidates at all (launch_mark_cells + launch_filter_marked, enqueued by launch_pool)
 			a.occ_i = pr.filtered.as<uint2>();
 			a.n_occ_i = ctrl_slot(k, tnsx::CTRL_NFILTERED);
@@ -1112,7 +1145,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			                        pr.shared_empty ? (size_t)pr.n_query : 0, pr.records.as<int>(), st);
 		}
 		const int t0 = tm.mark();   // (behind the last kernel of the build / of the previous pass: the bracket holds the pass's query kernels only)
-		if (pr.shared_empty && (tiers & 1)) {
+		if (pr.shared_empty && (tiers & 1) && !sparse) {   // (the presence filter's byte map is a dense structure: a sparse grid walks all occupied cells)
 			const PointSet& A = c->sets[jb.i];
 			const size_t max_cells = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pr.n_i, n_cells));
 			HIPCHK(c, pr.filtered.reserve(max_cells * sizeof(uint2)));
@@ -1132,7 +1165,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_POOL;
 			// opt-in (tnsx_options.query_formulation = 1), fixed radius, a set searched in itself: the group formulation (tnsx_query_group.hip)
 			// in front of the cell kernels, unless it was switched off for this pair
-			pr.groups_now = !variable && jb.i == jb.j && c->opt.query_formulation == 1 && !pr.groups_off && c->grid_h * c->grid_h > 1e-30f;
+			pr.groups_now = !sparse && !variable && jb.i == jb.j && c->opt.query_formulation == 1 && !pr.groups_off && c->grid_h * c->grid_h > 1e-30f;
 			qc.groups = pr.groups_now;
 			if (pr.groups_now) { HIPCHK(c, pr.filtered.reserve((size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pr.n_i, n_cells)) * sizeof(uint2))); tiers = 3; }
 			qc.tiers = tiers;
@@ -1142,7 +1175,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		pr.heavy_skipped = !(tiers & 2);
 		const int t1 = tm.mark();
 		span(ST_FILL, t0, t1);
-		uint32_t* const h_count = pr.shared_empty ? h_filt + k : (pr.groups_now && pr.n_i > 0 ? h_left + k : nullptr);   // (the two worklists share a counter, see make_args)
+		uint32_t* const h_count = (pr.shared_empty && !sparse) ? h_filt + k : (pr.groups_now && pr.n_i > 0 ? h_left + k : nullptr);   // (the two worklists share a counter, see make_args)
 		if (defer_readback && run_end.n_jobs < tnsx::RUN_END_MAX_JOBS) {
 			tnsx::RunEndJob& rj = run_end.job[run_end.n_jobs++];
 			rj.ctrl_cursor = ctrl_slot(k, tnsx::CTRL_CURSOR); rj.h_ctrl = reinterpret_cast<unsigned long long*>(h_ctrl + HC * k);
@@ -1192,7 +1225,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	// ---- were the assumptions of this attempt right?
 	for (int si = 0; si < n_sets; si++) {
 		PointSet& s = c->sets[si];
-		if (s.n > 0) { s.table_state = 1; if (!skipped[(size_t)si]) s.table_dirty = h_nocc[si]; }
+		if (s.n > 0 && !sparse) { s.table_state = 1; if (!skipped[(size_t)si]) s.table_dirty = h_nocc[si]; }
 	}
 	bool wrong = speculate && (h_words[0] & 0xffffffffull) != 0;   // a point left the box of the grid / a radius outgrew its cell edge
 #ifdef TNSX_BUILD_DEBUG_WIN

@@ -63,11 +63,14 @@ size_t cell_build_temp_bytes(int n);
 // xyzi[1] must hold bucket_window_slots(n, n_buckets) points whenever win is given.
 static constexpr int BUCKET_CURSOR_STRIDE = 32;   // 128 bytes: returning atomics on one cache line serialise
 struct BucketWindows { bool use = false; uint2* win = nullptr; uint32_t* cursors = nullptr; };
+// Sparse grid (round 4): no dense table; occ becomes the key-ordered list of occupied cells with a sentinel behind it, blk its block index
+// (n_blocks + 1 entries, one per 2^shift keys).  blk == nullptr: the dense table.
+struct SparseCells { uint32_t* blk = nullptr; int shift = 0; uint32_t n_blocks = 0; };
 bool cell_build_uses_buckets(int n, int key_bits, bool stable_order, int bucket_min_points, int* n_buckets);
 size_t bucket_window_slots(int n, int n_buckets);
 int launch_cell_build(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, const int* ids,
                       uint32_t* orig_sorted, const BuildGuard& gd, uint32_t query_limit, bool stable_order, int bucket_min_points, uint2* table, uint2* occ,
-                      uint32_t* n_occ, int* passes_out, const BucketWindows& bw, hipStream_t s);
+                      uint32_t* n_occ, int* passes_out, const BucketWindows& bw, const SparseCells& sp, hipStream_t s);
 int launch_cell_sort(const float* xyz, const float* radii, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, const int* ids,
                      uint32_t* orig_sorted, const BuildGuard& gd, hipStream_t s);
 // the same checksum on its own (sets whose build is skipped)
@@ -112,6 +115,8 @@ struct QueryArgs {
 	uint2* heavy;                      // worklist {first sorted position, key} of the cells the fast kernel skipped
 	uint32_t* n_heavy;                 // its length (zeroed before the launch)
 	uint32_t* tickets2; uint2* heavy2; uint32_t* n_heavy2;   // the same for the second tier (fat kernel -> general kernel)
+	// sparse grid (blk_j != nullptr): no tables; the cells of set j / set i are found in their key-ordered occupied-cell lists through the block indices
+	const uint2* socc_i; const uint32_t* blk_i; const uint2* socc_j; const uint32_t* blk_j; int sparse_shift;
 	const uint32_t* abort_flag;   // the run's guard word (or nullptr): non-zero = the build already knows that this attempt will be thrown away (a point outside the
 	                              // reused grid, an overflowed window of the one-read bucket pass -- the sorted arrays then have HOLES): the query kernels do nothing
 	uint2* heavy0; uint32_t* n_heavy0;   // group formulation (tnsx_query_group.hip): worklist of the cells it passes on to the three cell tiers (zeroed before)

@@ -193,6 +193,7 @@ __device__ __forceinline__ void deal_table(uint32_t tbl, const Runs R, uint32_t 
 }
 
 // 27 neighbour lookups of the cell with this key (lanes 0..26), wave-uniform key
+template <bool SPARSE = false>
 __device__ __forceinline__ void lookup_cell(const QueryArgs& a, uint32_t key, bool valid, int lane, uint32_t& s, uint32_t& e)
 {
 	s = 0; e = 0;
@@ -204,9 +205,23 @@ __device__ __forceinline__ void lookup_cell(const QueryArgs& a, uint32_t key, bo
 	const int x = cx + (lane % 3) - 1, y = cy + ((lane / 3) % 3) - 1, z = cz + (lane / 9) - 1;
 	const bool use = valid && lane < 27 && x >= 0 && x < (int)nx && y >= 0 && y < (int)ny && z >= 0 && z < (int)nz;
 	const uint32_t idx = use ? ((uint32_t)z * ny + (uint32_t)y) * nx + (uint32_t)x : 0u;   // (the dense table has at most 2^30 cells)
+	if (SPARSE) {
+		// sparse grid: the cell's entry of the key-ordered occupied-cell list, through the block index (three or four dependent loads per lane)
+		uint2 r = make_uint2(0u, 0u);
+		if (use) r = sparse_find(a.socc_j, a.blk_j, a.sparse_shift, idx);
+		s = r.x; e = r.y;
+		return;
+	}
 	const uint2 r = a.table_j[idx];
 	s = use ? r.x : 0u;
 	e = use ? r.y : 0u;
+}
+// {first, one past last} sorted position of the query cell itself (wave-uniform key)
+template <bool SPARSE = false>
+__device__ __forceinline__ uint2 own_range(const QueryArgs& a, uint32_t key)
+{
+	if (SPARSE) return sparse_find(a.socc_i, a.blk_i, a.sparse_shift, key);
+	return a.table_i[key];
 }
 
 enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_POOL = 2 };
@@ -379,7 +394,10 @@ __device__ __forceinline__ void process_batch_nc(const QueryArgs& a, const RunRe
 	}
 }
 
-template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int MODE>
+// SPARSE: the cells of a grid without a dense table (tnsx_build.hip "SPARSE grids"): look-ups through the block index.  Its own instantiation of the general
+// kernel -- the only kernel that serves such grids -- so that the dense kernels carry none of it (as a run-time branch it cost the first tier two spilled
+// VGPRs; instantiating the fast tiers too doubles the compile time for a query 15 % faster: measured, not kept)
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int MODE, bool SPARSE = false>
 __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 {
 	if (a.abort_flag && *a.abort_flag != 0u) return;   // (this attempt is already known to be wrong; its sorted arrays may have holes)
@@ -398,8 +416,8 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 	uint2 oc = ci < hi ? a.occ_i[ci] : make_uint2(0u, 0u);
 	uint2 oc_n = (ci + stride) < hi ? a.occ_i[ci + stride] : make_uint2(0u, 0u);
 	uint32_t s, e;
-	lookup_cell(a, oc.y, ci < hi, lane, s, e);
-	uint2 qrange = ci < hi ? a.table_i[oc.y] : make_uint2(0u, 0u);
+	lookup_cell<SPARSE>(a, oc.y, ci < hi, lane, s, e);
+	uint2 qrange = ci < hi ? own_range<SPARSE>(a, oc.y) : make_uint2(0u, 0u);
 
 	while (ci < hi) {
 		const uint32_t ci_n = ci + stride, ci_nn = ci_n + stride;
@@ -421,8 +439,8 @@ __global__ void __launch_bounds__(Q_THREADS) k_query(const QueryArgs a)
 		const uint2 cur_q = qrange;
 
 		// ---- issue the lookups of the NEXT cell now; they complete under this cell's arithmetic
-		lookup_cell(a, oc_n.y, ci_n < hi, lane, s, e);
-		qrange = ci_n < hi ? a.table_i[oc_n.y] : make_uint2(0u, 0u);
+		lookup_cell<SPARSE>(a, oc_n.y, ci_n < hi, lane, s, e);
+		qrange = ci_n < hi ? own_range<SPARSE>(a, oc_n.y) : make_uint2(0u, 0u);
 
 		// ---- query points of this cell, 64 at a time
 		for (uint32_t qb = cur_q.x; qb < cur_q.y; qb += WAVE) {
@@ -1171,7 +1189,8 @@ void launch_filter_marked(const uint2* occ_i, const uint32_t* n_occ_i, const uns
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int MODE>
 static void launch_query_t(const QueryArgs& a, int blocks, hipStream_t s)
 {
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<ARITH, VARIABLE, SYM, SELF, MODE>), dim3(blocks), dim3(Q_THREADS), 0, s, a);
+	if (a.blk_j) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<ARITH, VARIABLE, SYM, SELF, MODE, true>), dim3(blocks), dim3(Q_THREADS), 0, s, a);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<ARITH, VARIABLE, SYM, SELF, MODE, false>), dim3(blocks), dim3(Q_THREADS), 0, s, a);
 }
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF>
 static void launch_pool_t(const QueryArgs& a, int blocks_fast, int blocks_heavy, int tiers, hipStream_t s)
@@ -1194,6 +1213,10 @@ static void launch_query_3(const QueryArgs& a, const QueryConfig& c, int n_cus, 
 	const int blocks = ((n_cus * per_cu + 7) / 8) * 8;
 	if (c.mode == QUERY_COUNT) launch_query_t<ARITH, VARIABLE, SYM, SELF, MODE_COUNT>(a, blocks, s);
 	else if (c.mode == QUERY_FILL) launch_query_t<ARITH, VARIABLE, SYM, SELF, MODE_FILL>(a, blocks, s);
+	else if (a.blk_j) {
+		// sparse grid: the general kernel over ALL occupied cells (it takes any cell; its records come from the common region of the pool)
+		if (c.tiers & 1) launch_query_t<ARITH, VARIABLE, SYM, SELF, MODE_POOL>(a, blocks, s);
+	}
 	else {
 		const int fast_per_cu = (c.fast_blocks_per_cu >= 1 && c.fast_blocks_per_cu <= 16) ? c.fast_blocks_per_cu : 8;   // (tnsx_options.fast_blocks_per_cu)
 		launch_pool_t<ARITH, VARIABLE, SYM, SELF>(a, ((n_cus * fast_per_cu + 7) / 8) * 8, ((n_cus * 2 + 7) / 8) * 8, c.tiers, s);
