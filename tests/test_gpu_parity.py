@@ -369,7 +369,9 @@ def test_group_formulation_matches_golden(case, mode, oracle):
     for step in range(2):         # step 0: dry pass + sized pass, step 1: one pass
         ns.run()
         st = ns.get_stats()
-        assert st["n_group_pairs"] == self_pairs or step == 1      # (a pair that passed on most of its cells is back on the cell kernels in step 1)
+        # (a pair that passed on most of its cells is back on the cell kernels in step 1; a sparse grid -- the far outlier of the edge case -- is served by the
+        #  general kernel alone)
+        assert st["n_group_pairs"] == self_pairs or step == 1 or st["grid_sparse"] == 1
         res = {pr: ns.neighbor_csr(*pr) for pr in case.active}
         P.assert_matches_golden(res, load_golden(case.name), mode, oracle, case.name + " (group formulation, step %d)" % step)
 

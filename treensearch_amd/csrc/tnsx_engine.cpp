@@ -688,6 +688,156 @@ static tnsx_status copy_records(tnsx_context* c, const PairResult& pr, int* dst,
 	return TNSX_OK;
 }
 
+// slab size, regions and record storage of a pool pass.  payload[r]: ints of records region r is expected to receive (nullptr: dry
+// pass); asked[r]: what the waves asked region r for in the previous pass with the same slab size -- records plus the unused ends
+// of their slabs, which is what the region has to hold (nullptr after a dry pass, whose slabs have another size: the regions then
+// get a quarter / a half more than the records need).  generous: the common region can take EVERYTHING (the redo of a pass that
+// overflowed must not overflow again).
+static tnsx_status size_pool(tnsx_context* c, PairResult& pr, const uint64_t* payload, const uint64_t* asked, bool generous, int query_waves)
+{
+	for (int r = 0; r < PairResult::NR; r++) { pr.region_base[r] = 0; pr.region_cap[r] = 0; pr.region_used[r] = 0; }
+	if (!payload) {
+		pr.pool_slab = 16384;   // nothing is written, big slabs keep the cursor atomics rare
+		HIPCHK(c, pr.records.reserve(1024 * sizeof(int)));
+		return TNSX_OK;
+	}
+	uint64_t total = 0;
+	for (int r = 0; r < PairResult::NR; r++) total += payload[r];
+	const uint64_t expect = total + total / 8 + 1024;
+	// a wave's last slab stays half empty on average: slabs of 1/8 of a wave's share keep the holes at ~6 % of the pool
+	// (round 3: the unit of allocation is the block of a whole cell -- some hundred ints to a few thousand -- so a slab is at least 4096
+	//  ints: with the 256-int slabs a small set used to get, every cell would be an allocation of its own)
+	uint64_t slab = std::min<uint64_t>(16384, std::max<uint64_t>(4096, expect / ((uint64_t)query_waves * 8)));
+	// (the holes depend on the slab size: the previous size is kept while it is within an eighth of the ideal one)
+	if (asked && slab >= (uint64_t)pr.pool_slab - pr.pool_slab / 8 && slab <= (uint64_t)pr.pool_slab + pr.pool_slab / 8) slab = pr.pool_slab;
+	if (asked && slab != pr.pool_slab) asked = nullptr;
+	pr.pool_slab = (uint32_t)slab;
+	const uint64_t slab_heavy = std::max<uint64_t>(slab, 8192);
+	// (a wave takes a slab only if it gets a cell: small sets keep small pools)
+	const uint64_t waves_all = std::min<uint64_t>((uint64_t)query_waves, (uint64_t)pr.n_i + 8);
+	const uint64_t waves_x = std::min<uint64_t>((uint64_t)query_waves / tnsx::POOL_REGIONS, (uint64_t)pr.n_i / tnsx::POOL_REGIONS + 2);
+	// (a wave of the heavy tiers that gets a cell writes at least a handful of records; should this ever be too little, the pass is repeated)
+	const uint64_t waves_heavy = std::min<uint64_t>(std::min<uint64_t>((uint64_t)query_waves, (uint64_t)pr.n_i / 4 + 8), payload[tnsx::POOL_OVERFLOW] / 16 + 8);
+	uint64_t first = pr.shared_empty ? 64 : 0;
+	for (int r = 0; r < PairResult::NR; r++) {
+		const bool common = r == tnsx::POOL_OVERFLOW;
+		uint64_t cap;
+		// steady state: what was asked for last time + 6 % (the common region: + 6 % of everything, for what the others cannot hold);
+		// after a dry pass: the records + a quarter (the common region: a half) + a slab per wave that can get a cell
+		if (asked) {
+			cap = asked[r] + asked[r] / 16 + 1024 + (common ? expect / 16 + 4096 : 0);
+			// (the common region of a small dense set: how many waves of the heavy tiers get a cell -- and open a slab of their own, to leave
+			//  it mostly empty -- is decided by the race for the tickets and moved `asked` by 17 % between two runs of a 10 000-point set;
+			//  every wave that can get a cell may open one, up to twice what was asked for last time)
+			if (common) cap += std::min<uint64_t>(std::min<uint64_t>((uint64_t)query_waves + (uint64_t)query_waves / 4, (uint64_t)std::max(pr.n_cells_i, 1u)),
+			                                      std::max<uint64_t>(asked[r] / slab_heavy, 64)) * slab_heavy;
+		}
+		else cap = payload[r] + payload[r] / (common ? 2 : 4) + 1024 + (common ? expect / 16 + waves_heavy * slab_heavy : waves_x * slab);
+		if (generous && common) cap += expect + waves_all * slab_heavy;
+		pr.region_base[r] = first; pr.region_cap[r] = cap;
+#ifdef TNSX_BUILD_DEBUG_POOL
+		fprintf(stderr, "[tnsx] size_pool region %d: payload %llu asked %lld cap %llu slab %llu n_i %d cells_prev %u\n", r, (unsigned long long)payload[r], asked ? (long long)asked[r] : -1ll, (unsigned long long)cap, (unsigned long long)slab, pr.n_i, pr.n_cells_i);
+#endif
+		first = (first + cap + 63) & ~(uint64_t)63;
+	}
+	HIPCHK(c, pr.records.reserve(first * sizeof(int)));
+	return TNSX_OK;
+}
+
+// A run that does not reuse the previous run's grid: world box of the reference semantics, then the search grid -- the box it covers (tight bounds widened by
+// two radii, inside the world box), the cell edge (r_max with the rounding margin of the binning), dense table / trimmed to the bulk of the points / sparse /
+// coarsened.  b8: tight bounds and radius range of all points (compute_bounds).  Leaves the result in c->grid* (grid_valid, grid_gen, ...).
+static tnsx_status layout_grid(tnsx_context* c, const float b8[8], int64_t n_total, bool variable)
+{
+	tnsx::GridParams g{};
+	// ---- world box of the reference semantics (kept for zsort + the 2^15 cells/dimension limit)
+	if (n_total > 0) { const tnsx_status r = update_world_box(c, b8, !c->scalar_world_box); if (r != TNSX_OK) return r; }
+	const float r_max = variable ? b8[7] : c->radius;
+	if (n_total > 0 && !(r_max > 0.0f) ) TNSX_FAIL(c, TNSX_ERR_CONFIG, "TreeNSearch error: search radius must be > 0");
+	if (n_total > 0 && !std::isfinite(r_max)) TNSX_FAIL(c, TNSX_ERR_INVALID, "a search radius is not finite");
+	// ---- the box the grid is laid over: the tight bounds widened by two cell edges on every side, but never beyond the
+	//      world box -- as long as every point stays inside it, the reference would keep its world box too
+	//      (TreeNSearch.cpp:474-482), so a later run may reuse this grid AND the world box without seeing the bounds.
+	// ---- search grid: cell edge h >= r_max with a margin that covers the fp32 rounding of the binning, so that any
+	//      pair the fp32 predicate can accept lies in adjacent cells.  Coarsened until the dense table fits.
+	c->grid_valid = false;
+	if (n_total > 0) {
+		// the dense table costs 8 bytes per cell and set: bounded by the number of points (a sparse scene trims the grid to the
+		// bulk of its points or coarsens its cells instead of allocating gigabytes), and by the option
+		const uint64_t cell_cap = c->auto_dense_cells ? std::min<uint64_t>(c->opt.max_dense_cells, std::max<uint64_t>((uint64_t)1 << 22, 64ull * (uint64_t)n_total))
+		                                              : c->opt.max_dense_cells;
+		float blo[3] = { b8[0], b8[1], b8[2] }, bhi[3] = { b8[3], b8[4], b8[5] };
+		bool trimmed = false;
+		{
+			double cells = 1.0;
+			const double h0 = (double)r_max * 1.001;
+			for (int d = 0; d < 3; d++) cells *= std::floor(((double)bhi[d] - blo[d] + 4.0 * r_max) / h0) + 1.0;
+			if (cells > (double)cell_cap) {
+				// cells of one search radius over the bounding box do not fit: far outliers?  (trim_box)
+				float tlo[3] = { blo[0], blo[1], blo[2] }, thi[3] = { bhi[0], bhi[1], bhi[2] };
+				tnsx_status ts = TNSX_OK;
+				if (trim_box(c, n_total, h0, 2.0 * r_max, cell_cap, tlo, thi, &ts)) {
+					for (int d = 0; d < 3; d++) { blo[d] = tlo[d]; bhi[d] = thi[d]; }
+					trimmed = true;
+				}
+				if (ts != TNSX_OK) TNSX_FAIL(c, ts, "HIP error while trimming the search grid to the bulk of the points");
+			}
+		}
+		float lo[3], hi[3];
+		for (int d = 0; d < 3; d++) {
+			const float m = 2.0f * r_max;
+			lo[d] = std::max(blo[d] - m, c->world[d]);
+			hi[d] = std::min(bhi[d] + m, c->world[3 + d]);
+			if (!(lo[d] <= blo[d])) lo[d] = blo[d];            // (a world box that does not contain the points: a failed update)
+			if (!(hi[d] >= bhi[d])) hi[d] = bhi[d];
+		}
+		const double ext[3] = { (double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2] };
+		const double max_ext = std::max(ext[0], std::max(ext[1], ext[2]));
+		const double n0 = std::floor(max_ext / (double)r_max) + 2.0;
+		double h = (double)r_max * (1.0 + 8.0 * 5.9604644775390625e-08 * (n0 + 2.0)) * (1.0 + 1e-6);
+		bool fits = false;
+		// A grid whose dense table does not fit keeps its cell edge as a SPARSE grid (round 4: lists of occupied cells instead of a table) as long as
+		// its cells can be numbered with 32 bits; only beyond that are the cells coarsened (exact either way; coarser cells cost candidates).
+		// (sparse_grid > 0: always; 0: when the bound of the dense table is the automatic one -- a caller who sets max_dense_cells asked for THAT many
+		//  cells -- and the cell edge would have to double.  Measured, tools/sparse_probe.py, a 10 M-point filament through the whole box with 3 - 6 points
+		//  per cell: cells 1.6 x coarser make the run 2.04 ms, the sparse grid at one radius 4.07 ms -- such clouds pay per CELL, the coarser grid has
+		//  fewer, and the sparse grid is served by the general kernel alone.  The sparse grid wins where coarsening costs candidates by the cube.)
+		const bool sparse_ok = c->opt.sparse_grid > 0 || (c->opt.sparse_grid == 0 && c->auto_dense_cells);
+		auto cells_at = [&](double hh) { return (std::floor(ext[0] / hh) + 1.0) * (std::floor(ext[1] / hh) + 1.0) * (std::floor(ext[2] / hh) + 1.0); };
+		const double cells0 = cells_at(h);
+		const bool want_sparse = sparse_ok && cells0 > (double)cell_cap && (c->opt.sparse_grid > 0 || cells0 > 8.0 * (double)cell_cap);
+		const double limit = want_sparse ? 4294967280.0 : (double)cell_cap;   // (a grid beyond 32-bit keys is coarsened until it fits as a sparse one)
+		bool sparse = false;
+		for (int it = 0; it < 400 && !fits; it++) {
+			const double nx = std::floor(ext[0] / h) + 1.0, ny = std::floor(ext[1] / h) + 1.0, nz = std::floor(ext[2] / h) + 1.0;
+			if (nx * ny * nz <= limit && nx < 2.0e6 && ny < 2.0e6 && nz < 2.0e6) {
+				g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz;
+				sparse = nx * ny * nz > (double)cell_cap;
+				fits = true;
+			}
+			else h *= 1.26;
+		}
+		c->grid_sparse = sparse;
+		if (!fits) TNSX_FAIL(c, TNSX_ERR_INVALID, "no search grid fits the extent of the points");
+		g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2];
+		float hf = (float)h;
+		if ((double)hf < h) hf = std::nextafter(hf, FLT_MAX);
+		g.inv_h = 1.0f / hf;
+		if ((double)g.inv_h * (double)hf > 1.0) g.inv_h = std::nextafter(g.inv_h, 0.0f);   // never overestimate 1/h
+		c->grid = g;
+		c->grid_h = hf;
+		for (int d = 0; d < 3; d++) { c->grid_lo[d] = lo[d]; c->grid_hi[d] = hi[d]; }
+		c->grid_r_max = r_max;
+		c->grid_variable = variable;
+		c->grid_box_scalar = c->scalar_world_box;
+		c->grid_valid = true;
+		c->grid_trimmed = trimmed;
+		c->grid_gen++;
+	}
+	else { g.nx = g.ny = g.nz = 1; g.inv_h = 1.0f; c->grid = g; c->grid_h = 0.0f; c->grid_trimmed = false; c->grid_sparse = false; }
+	return TNSX_OK;
+}
+
 static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 {
 	*redo = false;
@@ -736,93 +886,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 
 	tnsx::GridParams g{};
 	uint64_t n_cells = 1;
-	if (!speculate) {
-		// ---- world box of the reference semantics (kept for zsort + the 2^15 cells/dimension limit)
-		if (n_total > 0) { const tnsx_status r = update_world_box(c, b8, !c->scalar_world_box); if (r != TNSX_OK) return r; }
-		const float r_max = variable ? b8[7] : c->radius;
-		if (n_total > 0 && !(r_max > 0.0f) ) TNSX_FAIL(c, TNSX_ERR_CONFIG, "TreeNSearch error: search radius must be > 0");
-		if (n_total > 0 && !std::isfinite(r_max)) TNSX_FAIL(c, TNSX_ERR_INVALID, "a search radius is not finite");
-		// ---- the box the grid is laid over: the tight bounds widened by two cell edges on every side, but never beyond the
-		//      world box -- as long as every point stays inside it, the reference would keep its world box too
-		//      (TreeNSearch.cpp:474-482), so a later run may reuse this grid AND the world box without seeing the bounds.
-		// ---- search grid: cell edge h >= r_max with a margin that covers the fp32 rounding of the binning, so that any
-		//      pair the fp32 predicate can accept lies in adjacent cells.  Coarsened until the dense table fits.
-		c->grid_valid = false;
-		if (n_total > 0) {
-			// the dense table costs 8 bytes per cell and set: bounded by the number of points (a sparse scene trims the grid to the
-			// bulk of its points or coarsens its cells instead of allocating gigabytes), and by the option
-			const uint64_t cell_cap = c->auto_dense_cells ? std::min<uint64_t>(c->opt.max_dense_cells, std::max<uint64_t>((uint64_t)1 << 22, 64ull * (uint64_t)n_total))
-			                                              : c->opt.max_dense_cells;
-			float blo[3] = { b8[0], b8[1], b8[2] }, bhi[3] = { b8[3], b8[4], b8[5] };
-			bool trimmed = false;
-			{
-				double cells = 1.0;
-				const double h0 = (double)r_max * 1.001;
-				for (int d = 0; d < 3; d++) cells *= std::floor(((double)bhi[d] - blo[d] + 4.0 * r_max) / h0) + 1.0;
-				if (cells > (double)cell_cap) {
-					// cells of one search radius over the bounding box do not fit: far outliers?  (trim_box)
-					float tlo[3] = { blo[0], blo[1], blo[2] }, thi[3] = { bhi[0], bhi[1], bhi[2] };
-					tnsx_status ts = TNSX_OK;
-					if (trim_box(c, n_total, h0, 2.0 * r_max, cell_cap, tlo, thi, &ts)) {
-						for (int d = 0; d < 3; d++) { blo[d] = tlo[d]; bhi[d] = thi[d]; }
-						trimmed = true;
-					}
-					if (ts != TNSX_OK) TNSX_FAIL(c, ts, "HIP error while trimming the search grid to the bulk of the points");
-				}
-			}
-			float lo[3], hi[3];
-			for (int d = 0; d < 3; d++) {
-				const float m = 2.0f * r_max;
-				lo[d] = std::max(blo[d] - m, c->world[d]);
-				hi[d] = std::min(bhi[d] + m, c->world[3 + d]);
-				if (!(lo[d] <= blo[d])) lo[d] = blo[d];            // (a world box that does not contain the points: a failed update)
-				if (!(hi[d] >= bhi[d])) hi[d] = bhi[d];
-			}
-			const double ext[3] = { (double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2] };
-			const double max_ext = std::max(ext[0], std::max(ext[1], ext[2]));
-			const double n0 = std::floor(max_ext / (double)r_max) + 2.0;
-			double h = (double)r_max * (1.0 + 8.0 * 5.9604644775390625e-08 * (n0 + 2.0)) * (1.0 + 1e-6);
-			bool fits = false;
-			// A grid whose dense table does not fit keeps its cell edge as a SPARSE grid (round 4: lists of occupied cells instead of a table) as long as
-			// its cells can be numbered with 32 bits; only beyond that are the cells coarsened (exact either way; coarser cells cost candidates).
-			// (sparse_grid > 0: always; 0: when the bound of the dense table is the automatic one -- a caller who sets max_dense_cells asked for THAT many
-			//  cells -- and the cell edge would have to double.  Measured, tools/sparse_probe.py, a 10 M-point filament through the whole box with 3 - 6 points
-			//  per cell: cells 1.6 x coarser make the run 2.04 ms, the sparse grid at one radius 4.07 ms -- such clouds pay per CELL, the coarser grid has
-			//  fewer, and the sparse grid is served by the general kernel alone.  The sparse grid wins where coarsening costs candidates by the cube.)
-			const bool sparse_ok = c->opt.sparse_grid > 0 || (c->opt.sparse_grid == 0 && c->auto_dense_cells);
-			auto cells_at = [&](double hh) { return (std::floor(ext[0] / hh) + 1.0) * (std::floor(ext[1] / hh) + 1.0) * (std::floor(ext[2] / hh) + 1.0); };
-			const double cells0 = cells_at(h);
-			const bool want_sparse = sparse_ok && cells0 > (double)cell_cap && (c->opt.sparse_grid > 0 || cells0 > 8.0 * (double)cell_cap);
-			const double limit = want_sparse ? 4294967280.0 : (double)cell_cap;   // (a grid beyond 32-bit keys is coarsened until it fits as a sparse one)
-			bool sparse = false;
-			for (int it = 0; it < 400 && !fits; it++) {
-				const double nx = std::floor(ext[0] / h) + 1.0, ny = std::floor(ext[1] / h) + 1.0, nz = std::floor(ext[2] / h) + 1.0;
-				if (nx * ny * nz <= limit && nx < 2.0e6 && ny < 2.0e6 && nz < 2.0e6) {
-					g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz;
-					sparse = nx * ny * nz > (double)cell_cap;
-					fits = true;
-				}
-				else h *= 1.26;
-			}
-			c->grid_sparse = sparse;
-			if (!fits) TNSX_FAIL(c, TNSX_ERR_INVALID, "no search grid fits the extent of the points");
-			g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2];
-			float hf = (float)h;
-			if ((double)hf < h) hf = std::nextafter(hf, FLT_MAX);
-			g.inv_h = 1.0f / hf;
-			if ((double)g.inv_h * (double)hf > 1.0) g.inv_h = std::nextafter(g.inv_h, 0.0f);   // never overestimate 1/h
-			c->grid = g;
-			c->grid_h = hf;
-			for (int d = 0; d < 3; d++) { c->grid_lo[d] = lo[d]; c->grid_hi[d] = hi[d]; }
-			c->grid_r_max = r_max;
-			c->grid_variable = variable;
-			c->grid_box_scalar = c->scalar_world_box;
-			c->grid_valid = true;
-			c->grid_trimmed = trimmed;
-			c->grid_gen++;
-		}
-		else { g.nx = g.ny = g.nz = 1; g.inv_h = 1.0f; c->grid = g; c->grid_h = 0.0f; c->grid_trimmed = false; c->grid_sparse = false; }
-	}
+	if (!speculate) { const tnsx_status r = layout_grid(c, b8, n_total, variable); if (r != TNSX_OK) return r; }
 	g = c->grid;
 	n_cells = (uint64_t)g.nx * g.ny * g.nz;
 	const bool sparse = c->grid_sparse;
@@ -882,60 +946,6 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	HIPCHK(c, c->pool_ctrl.reserve(tnsx::CTRL_BYTES * (jobs.size() + 1)));   // per job: cursor, hit_total, 2 x (8 tickets, n_heavy), spread out
 	auto ctrl_slot = [&](size_t k, int slot) { return c->pool_ctrl.as<uint32_t>() + (k * tnsx::CTRL_SLOTS + (size_t)slot) * tnsx::CTRL_STRIDE_U32; };
 	const int query_waves = c->n_cus * 8 * 4;
-	// slab size, regions and record storage of a pool pass.  payload[r]: ints of records region r is expected to receive (nullptr: dry
-	// pass); asked[r]: what the waves asked region r for in the previous pass with the same slab size -- records plus the unused ends
-	// of their slabs, which is what the region has to hold (nullptr after a dry pass, whose slabs have another size: the regions then
-	// get a quarter / a half more than the records need).  generous: the common region can take EVERYTHING (the redo of a pass that
-	// overflowed must not overflow again).
-	auto size_pool = [&](PairResult& pr, const uint64_t* payload, const uint64_t* asked, bool generous) -> tnsx_status {
-		for (int r = 0; r < PairResult::NR; r++) { pr.region_base[r] = 0; pr.region_cap[r] = 0; pr.region_used[r] = 0; }
-		if (!payload) {
-			pr.pool_slab = 16384;   // nothing is written, big slabs keep the cursor atomics rare
-			HIPCHK(c, pr.records.reserve(1024 * sizeof(int)));
-			return TNSX_OK;
-		}
-		uint64_t total = 0;
-		for (int r = 0; r < PairResult::NR; r++) total += payload[r];
-		const uint64_t expect = total + total / 8 + 1024;
-		// a wave's last slab stays half empty on average: slabs of 1/8 of a wave's share keep the holes at ~6 % of the pool
-		// (round 3: the unit of allocation is the block of a whole cell -- some hundred ints to a few thousand -- so a slab is at least 4096
-		//  ints: with the 256-int slabs a small set used to get, every cell would be an allocation of its own)
-		uint64_t slab = std::min<uint64_t>(16384, std::max<uint64_t>(4096, expect / ((uint64_t)query_waves * 8)));
-		// (the holes depend on the slab size: the previous size is kept while it is within an eighth of the ideal one)
-		if (asked && slab >= (uint64_t)pr.pool_slab - pr.pool_slab / 8 && slab <= (uint64_t)pr.pool_slab + pr.pool_slab / 8) slab = pr.pool_slab;
-		if (asked && slab != pr.pool_slab) asked = nullptr;
-		pr.pool_slab = (uint32_t)slab;
-		const uint64_t slab_heavy = std::max<uint64_t>(slab, 8192);
-		// (a wave takes a slab only if it gets a cell: small sets keep small pools)
-		const uint64_t waves_all = std::min<uint64_t>((uint64_t)query_waves, (uint64_t)pr.n_i + 8);
-		const uint64_t waves_x = std::min<uint64_t>((uint64_t)query_waves / tnsx::POOL_REGIONS, (uint64_t)pr.n_i / tnsx::POOL_REGIONS + 2);
-		// (a wave of the heavy tiers that gets a cell writes at least a handful of records; should this ever be too little, the pass is repeated)
-		const uint64_t waves_heavy = std::min<uint64_t>(std::min<uint64_t>((uint64_t)query_waves, (uint64_t)pr.n_i / 4 + 8), payload[tnsx::POOL_OVERFLOW] / 16 + 8);
-		uint64_t first = pr.shared_empty ? 64 : 0;
-		for (int r = 0; r < PairResult::NR; r++) {
-			const bool common = r == tnsx::POOL_OVERFLOW;
-			uint64_t cap;
-			// steady state: what was asked for last time + 6 % (the common region: + 6 % of everything, for what the others cannot hold);
-			// after a dry pass: the records + a quarter (the common region: a half) + a slab per wave that can get a cell
-			if (asked) {
-				cap = asked[r] + asked[r] / 16 + 1024 + (common ? expect / 16 + 4096 : 0);
-				// (the common region of a small dense set: how many waves of the heavy tiers get a cell -- and open a slab of their own, to leave
-				//  it mostly empty -- is decided by the race for the tickets and moved `asked` by 17 % between two runs of a 10 000-point set;
-				//  every wave that can get a cell may open one, up to twice what was asked for last time)
-				if (common) cap += std::min<uint64_t>(std::min<uint64_t>((uint64_t)query_waves + (uint64_t)query_waves / 4, (uint64_t)std::max(pr.n_cells_i, 1u)),
-				                                      std::max<uint64_t>(asked[r] / slab_heavy, 64)) * slab_heavy;
-			}
-			else cap = payload[r] + payload[r] / (common ? 2 : 4) + 1024 + (common ? expect / 16 + waves_heavy * slab_heavy : waves_x * slab);
-			if (generous && common) cap += expect + waves_all * slab_heavy;
-			pr.region_base[r] = first; pr.region_cap[r] = cap;
-#ifdef TNSX_BUILD_DEBUG_POOL
-			fprintf(stderr, "[tnsx] size_pool region %d: payload %llu asked %lld cap %llu slab %llu n_i %d cells_prev %u\n", r, (unsigned long long)payload[r], asked ? (long long)asked[r] : -1ll, (unsigned long long)cap, (unsigned long long)slab, pr.n_i, pr.n_cells_i);
-#endif
-			first = (first + cap + 63) & ~(uint64_t)63;
-		}
-		HIPCHK(c, pr.records.reserve(first * sizeof(int)));
-		return TNSX_OK;
-	};
 	for (size_t k = 0; k < jobs.size(); k++) {
 		Job& jb = jobs[k];
 		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
@@ -951,7 +961,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			// handling below turns into a real pass of the right size.
 			pr.dry = pr.need_hint == 0;
 			pr.shared_empty = jb.i != jb.j && pr.n_query > 0;
-			{ const tnsx_status r = size_pool(pr, pr.dry ? nullptr : pr.region_payload, pr.region_asked[0] || pr.region_asked[tnsx::POOL_OVERFLOW] ? pr.region_asked : nullptr, false); if (r != TNSX_OK) return r; }
+			{ const tnsx_status r = size_pool(c, pr, pr.dry ? nullptr : pr.region_payload, pr.region_asked[0] || pr.region_asked[tnsx::POOL_OVERFLOW] ? pr.region_asked : nullptr, false, query_waves); if (r != TNSX_OK) return r; }
 			// worklists of the cells the fast / fat kernels pass on (at most one entry per occupied cell)
 			const size_t max_cells = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_i, n_cells));
 			HIPCHK(c, pr.heavy.reserve(max_cells * sizeof(uint2)));
@@ -1304,7 +1314,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 #endif
 					S.pool_retries++;
 				}
-				{ const tnsx_status r = size_pool(pr, payload, was_dry ? nullptr : asked_now, !was_dry); if (r != TNSX_OK) return r; }
+				{ const tnsx_status r = size_pool(c, pr, payload, was_dry ? nullptr : asked_now, !was_dry, query_waves); if (r != TNSX_OK) return r; }
 				const tnsx_status r = launch_pool(k, 3, true);
 				if (r != TNSX_OK) return r;
 				HIPCHK(c, hipStreamSynchronize(st));
