@@ -308,7 +308,7 @@ def measured_copy_peak(torch):
     b = torch.empty_like(a)
     a.fill_(1.0)
     best = 0.0
-    for _ in range(24):
+    for _ in range(int(os.environ.get("TNSX_BENCH_PEAK_ROUNDS", "24"))):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         b.copy_(a)
