@@ -352,7 +352,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if os.environ.get("TNSX_BENCH_SHARED_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     workload = args.workload or ("c5" if args.gpus > 1 else "c2")
     zsort_user = args.zsort_input
     if args.zsort_input is None:
@@ -366,7 +366,12 @@ def main():
     if distributed:
         assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
         assert workload == "c5", "only c5 shards over several GPUs"
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # TNSX_BENCH_SHARED_GPU=1 (a dry run of the N > 1 control flow on a box with ONE GPU: RCCL refuses two ranks on one device): the ranks share
+        # GPU 0, torch.distributed runs over gloo and the slab layer's messages over the host-staged transport.  Never a measurement.
+        if os.environ.get("TNSX_BENCH_SHARED_GPU") == "1":
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
         assert args.gpus == 1, "launch N > 1 through torch.distributed.run"
     arith = T.ARITH_STRICT if args.arith == "strict" else T.ARITH_CONTRACTED
@@ -505,7 +510,10 @@ def main():
         backend, transport = args.slab_backend, None
         if backend == "abi" and distributed and world > 1:
             try:
-                transport = SlabTransportC.rccl(rank, world, device=local_rank)
+                if os.environ.get("TNSX_BENCH_SHARED_GPU") == "1":
+                    transport = SlabTransportC.host_staged(rank, world)
+                else:
+                    transport = SlabTransportC.rccl(rank, world, device=local_rank)
             except Exception as e:   # (the same on every rank: the library is missing or not)
                 backend = "torch"
                 extra["slab_backend_note"] = f"RCCL transport of the C ABI unavailable ({e}); exchange through torch.distributed"
@@ -529,7 +537,7 @@ def main():
             ns = make_engine()
             slab = SlabSearchC(float(cuts[rank]), float(cuts[rank + 1]), float(radius), ns, transport, rank, world, halo_margin=0.11)
             slab.set_watchdog(60.0)      # a step that does not complete in a minute fails with a message naming the link (instead of hanging the job)
-            extra["slab_backend"] = "C ABI: tnsx_slab_step (" + ("RCCL ncclSend / ncclRecv issued by libtnsx.so" if transport is not None else "one slab, no exchange") + ")"
+            extra["slab_backend"] = "C ABI: tnsx_slab_step (" + (("host-staged torch.distributed transport (dry run on a shared GPU)" if os.environ.get("TNSX_BENCH_SHARED_GPU") == "1" else "RCCL ncclSend / ncclRecv issued by libtnsx.so") if transport is not None else "one slab, no exchange") + ")"
         else:
             slab = SlabSearch(float(cuts[rank]), float(cuts[rank + 1]), float(radius), make_engine, halo_margin=0.11)
             ns = slab.engine
@@ -591,7 +599,7 @@ def main():
         ns.set_collect_stage_times(False)
         torch.cuda.synchronize()
     if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
