@@ -1054,7 +1054,8 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		if (!sparse) s.table_state = 2;   // until this run's occupied-cell count has reached the host
 		for (int k = 0; k < 2; k++) {
 			// ([1] is the intermediate array of the bucket build: its buckets lie in windows with some slack)
-			HIPCHK(c, s.xyzi[k].reserve((k == 1 && s.bk_now ? tnsx::bucket_window_slots(s.n, s.bk_buckets) : (size_t)s.n) * sizeof(float4)));
+			// (the windows in use were laid out for bk_n points: with fewer points now they still reach as far)
+			HIPCHK(c, s.xyzi[k].reserve((k == 1 && s.bk_now ? tnsx::bucket_window_slots(std::max(s.n, s.bk_used ? s.bk_n : 0), s.bk_buckets) : (size_t)s.n) * sizeof(float4)));
 			if (variable) HIPCHK(c, s.r2[k].reserve((size_t)s.n * sizeof(float)));
 		}
 		HIPCHK(c, c->sort_temp.reserve(tnsx::cell_build_temp_bytes(s.n)));
