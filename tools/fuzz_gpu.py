@@ -82,6 +82,9 @@ while time.time() < t_end:
     # bucket_build_min_points: 1 = the two-pass bucket build for every set whose key fits (round 3), -1 = never, 0 = the default threshold
     opts_a = dict(arith=arith, sorted_lists=bool(rng.random() < 0.3), temporal_reuse=bool(rng.random() < 0.8),
                   bucket_build_min_points=int(rng.choice([1, 1, 0, -1])), query_formulation=int(rng.random() < 0.5))
+    if args.devices <= 1 and rng.random() < 0.3:
+        # round 4: the sparse grid (lists of occupied cells + block index instead of a dense table) for every scene whose grid has more than a few thousand cells
+        opts_a.update(max_dense_cells=int(rng.choice([512, 4096, 1 << 16])), sparse_grid=1)
     A = T.TreeNSearch(**opts_a, devices=[0] * args.devices) if args.devices > 1 else T.TreeNSearch(**opts_a)
     B = T.TreeNSearch(arith=arith, exact_layout=True, temporal_reuse=False)
     pts, rad = [], []
