@@ -1,11 +1,9 @@
 ulimit -c 0
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r4h
+O=$GRAFT_REPO_ROOT/gpurun_out/${1:-r4z}
 mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_api.py tests/test_gpu_fullsize.py -x -q -k "zsort or c4 or configs3 or dam" 2>&1 | tail -5
-timeout 600 python bench.py --workload c4 --points 10000000 --steps 10 --warmup 3 --no-cpu-baseline --no-pmc > $O/bench_c4_10m_zs.json 2>/dev/null
-python - <<'PY'
-import json
-d=json.loads([l for l in open("gpurun_out/r4h/bench_c4_10m_zs.json") if l.startswith("{")][-1])
-print({k:d[k] for k in ("value","ms_per_step")}, d["stage_ms"])
-PY
+
+timeout 300 python tools/zsort_probe.py 10000000 8 2>&1 | tail -1 | tee $O/zsort_10m.txt
+
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python $GRAFT_REPO_ROOT/tools/zsort_probe.py 10000000 8 > $O/kt.log 2>&1
+cd $GRAFT_REPO_ROOT && python tools/prof_summary.py $O 2>/dev/null | grep -v "at::native\|k_query" | head -24 | tee $O/kt_summary.txt

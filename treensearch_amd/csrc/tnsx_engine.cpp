@@ -107,9 +107,6 @@ struct PointSet {
 	uint32_t bk_gen = 0;           // grid generation the windows were written for (0: none)
 	int bk_n = 0, bk_buckets = 0;  // ... and the size of the set / the number of buckets then
 	bool bk_now = false, bk_used = false;   // this attempt: the bucket build runs / with the one-read pass
-#ifdef TNSX_BUILD_DEBUG_WIN
-	std::vector<uint2> dbg_win;
-#endif
 	// zsort
 	std::vector<int> zsort_host;    // filled on demand (zsort_host_order)
 	int zsort_n = 0;
@@ -1018,9 +1015,6 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 				if (s.bk_win.p != old_win || s.bk_buckets != nb) s.bk_gen = 0;
 				s.bk_used = speculate && c->opt.temporal_reuse != 0 && s.bk_gen == c->grid_gen && s.bk_gen != 0 && rb.n_zero < tnsx::RUN_BEGIN_MAX_SETS &&
 				            (int64_t)s.n <= (int64_t)s.bk_n + s.bk_n / 16 && (int64_t)s.n >= (int64_t)s.bk_n - s.bk_n / 16;
-#ifdef TNSX_BUILD_DEBUG_WIN
-				if (s.bk_used) { s.dbg_win.resize((size_t)nb); (void)hipDeviceSynchronize(); (void)hipMemcpy(s.dbg_win.data(), s.bk_win.p, (size_t)nb * sizeof(uint2), hipMemcpyDeviceToHost); }
-#endif
 				if (s.bk_used) { rb.zero[rb.n_zero] = s.bk_cur.as<uint32_t>(); rb.n_zero_words[rb.n_zero] = (uint32_t)nb * tnsx::BUCKET_CURSOR_STRIDE; rb.n_zero++; }
 				s.bk_buckets = nb;
 			}
@@ -1239,21 +1233,6 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		if (s.n > 0 && !sparse) { s.table_state = 1; if (!skipped[(size_t)si]) s.table_dirty = h_nocc[si]; }
 	}
 	bool wrong = speculate && (h_words[0] & 0xffffffffull) != 0;   // a point left the box of the grid / a radius outgrew its cell edge
-#ifdef TNSX_BUILD_DEBUG_WIN
-	if (wrong) for (int si = 0; si < n_sets; si++) {
-		PointSet& s = c->sets[si];
-		if (!s.bk_used) continue;
-		std::vector<uint2> w = s.dbg_win; std::vector<uint32_t> cur((size_t)s.bk_buckets * tnsx::BUCKET_CURSOR_STRIDE);
-		(void)hipMemcpy(cur.data(), s.bk_cur.p, cur.size() * 4, hipMemcpyDeviceToHost);
-		int shown = 0; uint64_t tot = 0;
-		for (int b = 0; b < s.bk_buckets; b++) {
-			const uint32_t cnt = cur[(size_t)b * tnsx::BUCKET_CURSOR_STRIDE];
-			tot += cnt;
-			if ((cnt > w[(size_t)b].y || b < 24) && shown++ < 40) fprintf(stderr, "[tnsx] set %d bucket %d: asked %u of window {next-run base %u, cap %u}\n", si, b, cnt, w[(size_t)b].x, w[(size_t)b].y);
-		}
-		fprintf(stderr, "[tnsx] set %d: %d buckets, cursors sum %llu of n %d, flag word %llx (windows as they were at the start of the run)\n", si, s.bk_buckets, (unsigned long long)tot, s.n, (unsigned long long)h_words[0]);
-	}
-#endif
 	if (wrong) c->grid_valid = false;
 	// a reused trimmed grid: results are exact whatever lies outside it, but more than 0.2 % of the points in its border cells is the
 	// sign that the bulk has moved -- the next run lays the grid out afresh
