@@ -445,6 +445,36 @@ def test_zsort_resolution_follows_the_reference(oracle):
     assert np.float32(ns.get_stats()["zsort_cell_size_inv"]) == inv_fine
 
 
+@pytest.mark.parametrize("cells_per_axis", [128, 256, 512])
+def test_zsort_after_a_run_on_large_sets(cells_per_axis, oracle):
+    """From 65 536 points on the cell-level order after a run() comes from the ranked pass on the high digit plus one workgroup per bucket (k_morton_place) for keys up to
+    24 bits, and from three LSD passes for 25 - 27 bits (a reference grid of 512 cells per axis).  A cloud with a dense blob (buckets beyond what a workgroup keeps in
+    registers) on each of the three grid sizes: a permutation, Morton-monotone on the reference's grid, and apply_zsort moves the points accordingly."""
+    import treensearch_amd as T
+    rng = np.random.default_rng(cells_per_axis)
+    n = 220_000
+    pts = rng.random((n, 3), dtype=np.float32)
+    pts[:70_000] = np.float32(0.5) + (rng.random((70_000, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(0.05)
+    pts[0] = 0.0; pts[1] = 1.0                                  # (the box is the unit cube whatever the draw)
+    r = np.float32(1.0 / (1.5 * 0.78 * cells_per_axis))         # cell edge 1.5 r: 0.78 * cells_per_axis cells across the cube
+    ns = T.TreeNSearch(); ns.set_search_radius(r)
+    ns.add_point_set(pts); ns.set_active_search(0, 0, True)
+    ns.run()
+    ns.prepare_zsort()
+    st = ns.get_stats()
+    inv = np.float32(st["zsort_cell_size_inv"])
+    steps = (np.float32(st["world_top"][0]) - np.float32(st["world_bottom"][0])) * inv
+    assert cells_per_axis / 2 < float(steps) <= cells_per_axis, (float(steps), cells_per_axis)
+    order = ns.get_zsort_order(0)
+    assert np.array_equal(np.sort(order), np.arange(n)), "the order must be a permutation"
+    keys = oracle.zsort_keys(pts, np.array(st["world_bottom"], np.float32), inv)
+    assert oracle.check_zsort(keys, order) == 0
+    import torch
+    d_p = torch.from_numpy(pts.copy()).cuda()
+    ns.apply_zsort(0, d_p, 3)
+    assert np.array_equal(d_p.cpu().numpy(), pts[order])
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # World box and z-sort grid against the REFERENCE's private world box (the `world` block of every fixture: domain_float read through
 # oracle/ref_wrap.cpp after run() / run_scalar() / prepare_zsort() on a fresh instance; tests/golden/make_golden.py::make_world).
