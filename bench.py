@@ -520,10 +520,24 @@ def main():
         dec = SlabDecomposition(engine=make_engine())
         t_dec = time.perf_counter()
         if backend == "abi":
-            # decomposition entirely behind the C ABI: cuts (two all-reduces) and the all-to-all that moves every point to its owner
-            cuts = balanced_cuts_c(dec.engine, transport, rank, world, [mine], float(radius) * 1.15)
-            owned, owned_gids = redistribute_c(dec.engine, transport, rank, world, cuts, mine, gids)
-        else:
+            # decomposition entirely behind the C ABI: cuts (two all-reduces) and the all-to-all that moves every point to its owner.
+            # Should it fail on any rank (its watchdog turns a stuck exchange into an error after 120 s), ALL ranks agree on that over
+            # torch.distributed and the job goes on with the torch.distributed exchange, saying so in the line -- instead of ending without one.
+            err = None
+            try:
+                cuts = balanced_cuts_c(dec.engine, transport, rank, world, [mine], float(radius) * 1.15)
+                owned, owned_gids = redistribute_c(dec.engine, transport, rank, world, cuts, mine, gids)
+            except Exception as e:
+                err = e
+            if distributed and world > 1:
+                ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    backend = "torch"
+                    extra["slab_backend_note"] = f"decomposition behind the C ABI failed ({err if err is not None else 'on another rank'}); exchange through torch.distributed"
+            elif err is not None:
+                raise err
+        if backend != "abi":
             cuts = dec.balanced_cuts([mine], plane_width=float(radius) * 1.15)
             owned, owned_gids, _ = dec.redistribute(mine, gids, None, cuts)
         torch.cuda.synchronize()
