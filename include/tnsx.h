@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TNSX_VERSION 301
+#define TNSX_VERSION 501
 
 typedef struct tnsx_context tnsx_context;
 
@@ -103,7 +103,8 @@ typedef struct tnsx_options {
 	                             search radius as a SPARSE grid -- occupied-cell lists + block index, up to 2^32 cells -- instead of coarser cells; < 0: never
 	                             (coarsen the cells until a dense table fits, the behaviour of rounds 1-3) */
 	int query_formulation;    /* 0 = default: the cell kernels (candidates in the lanes).  1 = experiment of round 3, measured
-	                             SLOWER: a fixed-radius search of a set in itself first runs the group formulation --
+	                             SLOWER and since round 5 NOT in the default build of the library (tnsx_query_formulation_available;
+	                             build with TNSX_WITH_GROUP_FORMULATION=1): a fixed-radius search of a set in itself first runs the group formulation --
 	                             16 query points of a cell per batch in the lanes, the tests as 16x16x4 fp32 MFMAs with an exact re-test
 	                             inside the rounding band -- and the cell kernels take the cells it passes on; a pair that passes on more
 	                             than a quarter of its cells goes back to the cell kernels alone.  Results are identical either way */
@@ -173,6 +174,10 @@ tnsx_status tnsx_create(const tnsx_options* opt /* may be NULL */, tnsx_context*
 void        tnsx_destroy(tnsx_context* ctx);                                               /* TreeNSearch.h:37 */
 const char* tnsx_last_error(const tnsx_context* ctx /* NULL: creation errors */);
 int         tnsx_version(void);
+/* 1 when this build of the library carries the query formulation `f` of tnsx_options.query_formulation (0: always; 1: only when the library was
+ * built with TNSX_WITH_GROUP_FORMULATION, see treensearch_amd/build.py), else 0.  Asking a context for a formulation its library does not carry is
+ * not an error: the run uses formulation 0 (the results are identical by contract). */
+int         tnsx_query_formulation_available(int f);
 
 /* ---- point sets (TreeNSearch.cpp:35-133, 346-365) ---------------------------------------------- */
 /* returns the set id (>= 0) or -status.  radii == NULL => fixed-radius mode set. */

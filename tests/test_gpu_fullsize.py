@@ -212,15 +212,59 @@ def _chunked_properties(ns, i, j, n_j, same_set, w_a, w_b, chunk=4_000_000, owne
     return total, m_ab, m_ba, deg
 
 
-def test_c4_full_size_50m_properties_and_zsort_invariance():
-    """BASELINE.json configs[3] at its full size: 50 M-point dam break, per-point radii, symmetric search."""
+def _sampled_lists(ns, i, j, sample):
+    """Sorted neighbour lists of the query points `sample` (int64 numpy, set-local indices of set i) of pair (i, j), fetched from the device copy of the
+    pair: (offsets int64[k + 1], indices int32[E]) like oracle.pair_search returns them."""
+    import ctypes as C
+    import torch
+    v = ns.pair_view(i, j)
+    offs = torch.empty(max(v.n_points, 1), dtype=torch.int64, device="cuda")
+    recs = torch.empty(max(v.n_records, 1), dtype=torch.int32, device="cuda")
+    ns._check(ns._L.tnsx_copy_pair(ns._h, int(i), int(j), C.c_void_p(offs.data_ptr()), C.c_void_p(recs.data_ptr()), 1))
+    o = offs[torch.from_numpy(sample).cuda()]
+    counts = recs[o].to(torch.int64)
+    e = int(counts.sum().item())
+    start = torch.cumsum(counts, 0) - counts
+    src = torch.repeat_interleave(o + 1 - start, counts) + torch.arange(e, device="cuda", dtype=torch.int64)
+    idx = recs[src].to(torch.int64)
+    local = torch.repeat_interleave(torch.arange(len(sample), device="cuda", dtype=torch.int64), counts)
+    idx = (torch.sort(local * (1 << 31) + idx).values & ((1 << 31) - 1)).to(torch.int32).cpu().numpy()
+    out_offs = np.zeros(len(sample) + 1, np.int64)
+    out_offs[1:] = np.cumsum(counts.cpu().numpy())
+    return out_offs, idx
+
+
+def _assert_sample_equals_all_points_search(oracle, ns, i, j, sample, pts, what, radii=None, radius=None, symmetric=True):
+    """Round-4 verdict item 4: EXACT parity at full size on a seeded sample.  The sample's points are searched in ALL points by the CPU restatement
+    (BruteforceNSearch.cpp:78-100 semantics: every candidate that passes the predicate, nothing else decides) as a pair of two different sets, the point
+    itself is taken out by its global index (a search of a set in itself never lists the point, TreeNSearch.cpp:2468), and the result must equal the
+    engine's lists of those points entry by entry."""
+    xa = np.ascontiguousarray(pts[sample])
+    if radii is not None:
+        ro, ri = oracle.pair_search(xa, pts, ra=np.ascontiguousarray(radii[sample]), rb=radii, symmetric=symmetric, same_set=False)
+    else:
+        ro, ri = oracle.pair_search(xa, pts, radius=radius, same_set=False)
+    owner = np.repeat(np.arange(len(sample)), np.diff(ro))
+    keep = ri != sample[owner].astype(np.int32)
+    assert int((~keep).sum()) == len(sample), f"{what}: every sampled point finds itself exactly once in the all-points search"
+    ri = ri[keep]
+    want_offs = np.zeros(len(sample) + 1, np.int64)
+    want_offs[1:] = np.cumsum(np.bincount(owner[keep], minlength=len(sample)))
+    got_offs, got_idx = _sampled_lists(ns, i, j, sample)
+    assert np.array_equal(got_offs, want_offs), f"{what}: neighbour counts of the sampled points differ"
+    assert np.array_equal(got_idx, ri), f"{what}: neighbour lists of the sampled points differ"
+    return int(want_offs[-1])
+
+
+def test_c4_full_size_50m_properties_and_zsort_invariance(oracle):
+    """BASELINE.json configs[3] at its full size: 50 M-point dam break, per-point radii, symmetric search.  Size-independent properties of ALL lists, and
+    (round 5) the lists of 20 000 randomly drawn points EXACTLY against an all-points search of the CPU restatement."""
     import torch
     import treensearch_amd as T
     from treensearch_amd import datagen as D
     n = 50_000_000
     p, rad, r0 = D.dam_break_cloud(n)
     d_p, d_r = torch.from_numpy(p).cuda(), torch.from_numpy(rad).cuda()
-    del p, rad
     ids = torch.arange(n, dtype=torch.int64, device="cuda")
     ns = T.TreeNSearch()
     ns.add_point_set(d_p, d_r)
@@ -231,6 +275,10 @@ def test_c4_full_size_50m_properties_and_zsort_invariance():
     total, m_ab, m_ba, deg = _chunked_properties(ns, 0, 0, n, True, a, b)
     assert 55 * n < total < 70 * n
     assert m_ab == m_ba, "symmetric search, yet the pair set is not symmetric"
+    sample = np.sort(np.random.default_rng(505).choice(n, 20000, replace=False)).astype(np.int64)
+    e = _assert_sample_equals_all_points_search(oracle, ns, 0, 0, sample, p, "c4 at 50 M", radii=rad, symmetric=True)
+    assert 50 * len(sample) < e < 75 * len(sample)
+    del p, rad
     ns.prepare_zsort()
     ns.apply_zsort(0, d_p, 3)
     ns.apply_zsort(0, d_r, 1)
@@ -243,17 +291,19 @@ def test_c4_full_size_50m_properties_and_zsort_invariance():
     assert deg2 == deg, "neighbour counts changed under the z-sort"
 
 
-def test_c5_full_size_200m_one_rank_through_the_slab_layer():
+def test_c5_full_size_200m_one_rank_through_the_slab_layer(oracle):
     """BASELINE.json configs[4] at its full 200 M points on ONE GPU, through tnsx_slab_step (one rank: no exchange, but the whole slab
     path -- [owned | ghosts] buffers, candidates-only tail, global ids from the engine): the lists hold global ids; symmetric pair set,
-    no self, distinct entries, ~59 neighbours per point, idempotent second step."""
+    no self, distinct entries, ~59 neighbours per point, idempotent second step; (round 5) the lists of 20 000 randomly drawn points EXACTLY
+    against an all-points search of the CPU restatement (the lists hold GLOBAL ids: here the identity)."""
     import torch
     import treensearch_amd as T
     from treensearch_amd import datagen as D
     from treensearch_amd.multi import SlabSearchC
     n = 200_000_000
     r = D.radius_for_neighbors(n)
-    d_p = torch.from_numpy(D.uniform_cloud(n, 12345)).cuda()
+    pts = D.uniform_cloud(n, 12345)
+    d_p = torch.from_numpy(pts).cuda()
     gids = torch.arange(n, dtype=torch.int64, device="cuda")
     ns = T.TreeNSearch()
     slab = SlabSearchC(float("-inf"), float("inf"), float(r), ns, None, 0, 1)
@@ -263,6 +313,10 @@ def test_c5_full_size_200m_one_rank_through_the_slab_layer():
     total, m_ab, m_ba, deg = _chunked_properties(ns, sid, sid, n, True, a, b, chunk=5_000_000)
     assert 58.5 * n < total < 60.5 * n
     assert m_ab == m_ba, "the pair set is not symmetric"
+    sample = np.sort(np.random.default_rng(606).choice(n, 20000, replace=False)).astype(np.int64)
+    e = _assert_sample_equals_all_points_search(oracle, ns, sid, sid, sample, pts, "c5 at 200 M", radius=float(r))
+    assert 55 * len(sample) < e < 64 * len(sample)
+    del pts
     slab.step(d_p, gids)
     st = ns.get_stats()
     assert st["n_neighbors"] == total and st["speculated"] == 1

@@ -361,9 +361,18 @@ def test_full_size_properties_symmetry_idempotence_self_exclusion(n):
 FIXED = [c for c in SMALL if c.radii is None]
 
 
+def _need_group_formulation():
+    """Round 5: tnsx_query_group.hip is part of libtnsx.so only in builds made with TNSX_WITH_GROUP_FORMULATION=1 (treensearch_amd/build.py); the default
+    library answers 0 here and runs the cell kernels whatever query_formulation says."""
+    import treensearch_amd as T
+    if not T.load_library().tnsx_query_formulation_available(1):
+        pytest.skip("libtnsx.so was built without the group formulation (TNSX_WITH_GROUP_FORMULATION=1 python -m treensearch_amd.build)")
+
+
 @pytest.mark.parametrize("case", FIXED, ids=[c.name for c in FIXED])
 @pytest.mark.parametrize("mode", [0, 1], ids=["strict", "contracted"])
 def test_group_formulation_matches_golden(case, mode, oracle):
+    _need_group_formulation()
     ns = P.make_engine(case, mode, query_formulation=1)
     self_pairs = sum(1 for (i, j) in case.active if i == j and len(case.points[i]) > 0)
     for step in range(2):         # step 0: dry pass + sized pass, step 1: one pass
@@ -378,6 +387,7 @@ def test_group_formulation_matches_golden(case, mode, oracle):
 
 @pytest.mark.parametrize("mode", [0, 1], ids=["strict", "contracted"])
 def test_group_formulation_c2_10m_matches_reference_digest(mode, oracle):
+    _need_group_formulation()
     case = CS.by_name("uniform_fixed_10000000")
     golden = load_golden(case.name)
     ns = P.make_engine(case, mode, device_inputs=True, query_formulation=1)
@@ -393,6 +403,7 @@ def test_group_formulation_points_on_the_radius(oracle):
     of the matrix-pipe test, and the lattice is moved off the origin so that the local coordinates round.  The band must hand every
     one of them to the reference's own arithmetic."""
     import treensearch_amd as T
+    _need_group_formulation()
     r = np.float32(0.03125)
     g = np.arange(24, dtype=np.float32) * r
     pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) + np.float32([0.7, 1.3, 2.9])
@@ -471,3 +482,16 @@ def test_sparse_grid_keeps_cells_of_one_radius(oracle):
         for (i, j) in [(0, 0), (0, 1), (1, 0)]:
             ref = oracle.pair_search(sets[i][0], sets[j][0], ra=sets[i][1], rb=sets[j][1], symmetric=True, same_set=(i == j))
             P.assert_same_csr(nv.neighbor_csr(i, j), ref, f"two filaments, per-point radii, pair {i}->{j}, run {step}")
+
+
+def test_an_unavailable_formulation_falls_back_to_the_cell_kernels(oracle):
+    """A library built without the group formulation (the default since round 5) accepts query_formulation = 1 and runs the cell kernels: same lists, no
+    group pair in the statistics."""
+    import treensearch_amd as T
+    if T.load_library().tnsx_query_formulation_available(1):
+        pytest.skip("this library carries the group formulation")
+    case = CS.by_name("uniform_fixed_100000")
+    ns = P.make_engine(case, 0, query_formulation=1)
+    ns.run(); ns.run()
+    assert ns.get_stats()["n_group_pairs"] == 0
+    P.assert_matches_golden({(0, 0): ns.neighbor_csr(0, 0)}, load_golden(case.name), 0, oracle, case.name + " (formulation 1 asked of a library without it)")

@@ -226,6 +226,73 @@ def test_one_read_bucket_pass_and_its_overflow(oracle):
     assert st["one_read_builds"] == 1 and st["speculation_redos"] == 0
 
 
+def test_one_read_overflow_with_per_point_radii_user_ids_and_a_grown_set(oracle):
+    """after a window overflow of the one-read bucket pass the unwritten slots of the windows hold stale points of an earlier
+    run (or memory nobody ever wrote); pass B must not use their w component as an index into radii[] / ids[].  Per-point radii, user ids, a
+    set that first shrinks (so that the intermediate array keeps stale rows with LARGE indices) and then grows (so that it is reallocated), and a
+    mirrored cloud that overflows the windows every time: the run is repeated without speculation and the lists are exact."""
+    import torch
+    import treensearch_amd as T
+    n_max = 260000
+    rng = np.random.default_rng(23)
+
+    def cloud(n):
+        z = rng.random(n, dtype=np.float32) ** np.float32(3.0)
+        p = (np.float32(0.05) + np.float32(0.9) * np.stack([rng.random(n, dtype=np.float32), rng.random(n, dtype=np.float32), z], axis=1)).astype(np.float32)
+        p[0] = (0.0, 0.0, 0.0)
+        p[1] = (1.0, 1.0, 1.0)
+        return p
+    r0 = np.float32(0.02)
+    ids_all = (np.arange(n_max, dtype=np.int32)[::-1] * 2 + 5).copy()
+    d_pts = torch.empty((n_max, 3), dtype=torch.float32, device="cuda")
+    d_rad = torch.empty((n_max,), dtype=torch.float32, device="cuda")
+    d_ids = torch.from_numpy(ids_all).cuda()
+    ns = T.TreeNSearch()
+    s = ns.add_point_set(d_pts, d_rad, n_points=200000)
+    ns.set_active_search(s, s, True)
+    ns.set_symmetric_search(True)
+    ns.set_point_ids(s, d_ids)
+    state = {}
+
+    def load(n, pts, rad):
+        d_pts[:n].copy_(torch.from_numpy(pts)); d_rad[:n].copy_(torch.from_numpy(rad))
+        ns.resize_point_set(s, d_pts, d_rad, n_points=n)
+        state.update(n=n, pts=pts, rad=rad)
+
+    def run_and_check(tag):
+        ns.run()
+        n, pts, rad = state["n"], state["pts"], state["rad"]
+        offs, idx = ns.neighbor_csr(s, s)
+        ro, ri = oracle.pair_search(pts, pts, ra=rad, rb=rad, symmetric=True, same_set=True)
+        assert np.array_equal(offs, ro), tag
+        want = ids_all[ri]
+        lid = np.repeat(np.arange(n), np.diff(ro))
+        want = want[np.lexsort((want, lid))]
+        assert np.array_equal(idx, want), tag
+        return ns.get_stats()
+
+    def jitter():
+        state["pts"][2:] += (rng.random((state["n"] - 2, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(0.1) * r0
+        d_pts[:state["n"]].copy_(torch.from_numpy(state["pts"]))
+
+    for n in (200000, 120000, n_max):          # shrink (stale rows with indices >= n stay in the intermediate array), then grow (reallocation)
+        pts = cloud(n)
+        rad = (r0 * (np.float32(0.6) + np.float32(0.4) * rng.random(n, dtype=np.float32))).astype(np.float32)
+        rad[0] = r0                                # pins r_max, so that the grid of the first run stays valid
+        load(n, pts, rad)
+        run_and_check(f"n={n} first")
+        jitter()
+        st = run_and_check(f"n={n} jitter")
+        assert st["one_read_builds"] == 1 and st["speculation_redos"] == 0, str(st)
+        state["pts"][:, 2] = np.float32(1.0) - state["pts"][:, 2]      # mirror in z: every bucket's population changes, windows overflow
+        d_pts[:n].copy_(torch.from_numpy(state["pts"]))
+        st = run_and_check(f"n={n} mirrored")
+        assert st["speculation_redos"] == 1 and st["one_read_builds"] == 0, f"the overflow must be noticed and the run repeated: {st}"
+        jitter()
+        st = run_and_check(f"n={n} after the repair")
+        assert st["one_read_builds"] == 1 and st["speculation_redos"] == 0, str(st)
+
+
 def test_one_read_bucket_pass_leaves_nan_points_out(oracle):
     """The layout of a slab's set: n owned points (they get lists), then candidates-only rows of which a varying number are real and the rest
     NaN-x padding (no points).  The one-read pass drops the NaN rows instead of letting them overflow the window of the bucket behind the last

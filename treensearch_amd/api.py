@@ -68,7 +68,7 @@ class Stats(C.Structure):
 
 # every symbol include/tnsx.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_SYMBOLS = [
-    "tnsx_default_options", "tnsx_create", "tnsx_destroy", "tnsx_last_error", "tnsx_version",
+    "tnsx_default_options", "tnsx_create", "tnsx_destroy", "tnsx_last_error", "tnsx_version", "tnsx_query_formulation_available",
     "tnsx_add_point_set", "tnsx_resize_point_set",
     "tnsx_set_search_radius", "tnsx_set_cell_size", "tnsx_set_symmetric_search", "tnsx_set_active_search",
     "tnsx_set_active_search_all", "tnsx_set_all_searches", "tnsx_set_arithmetic", "tnsx_set_collect_stage_times",
@@ -125,6 +125,7 @@ def load_library():
     L.tnsx_destroy.restype = None
     L.tnsx_last_error.argtypes = [vp]
     L.tnsx_last_error.restype = C.c_char_p
+    L.tnsx_query_formulation_available.argtypes = [ci]
     L.tnsx_halo_pack.argtypes = [vp, vp, vp, vp, ci, C.c_float, C.c_float, vp, vp, C.c_ulonglong, C.c_ulonglong, vp, C.POINTER(C.c_uint)]
     L.tnsx_x_histogram.argtypes = [vp, vp, ci, C.c_float, C.c_float, ci, vp]
     L.tnsx_set_query_count.argtypes = [vp, ci, ci]

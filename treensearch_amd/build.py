@@ -15,7 +15,11 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libtnsx.so")
-SOURCES = ["tnsx_kernels.hip", "tnsx_build.hip", "tnsx_query.hip", "tnsx_query_group.hip", "tnsx_engine.cpp", "tnsx_multi.cpp", "tnsx_slab.cpp"]
+SOURCES = ["tnsx_kernels.hip", "tnsx_build.hip", "tnsx_query.hip", "tnsx_engine.cpp", "tnsx_multi.cpp", "tnsx_slab.cpp"]
+# The group formulation of round 3 (MFMA tiles, measured 2.6 x slower than the cell kernels: DESIGN.md section 6) is kept as a reproducible
+# refutation, not as part of the product: TNSX_WITH_GROUP_FORMULATION=1 in the environment of the BUILD adds its translation unit and the
+# -DTNSX_WITH_GROUP_FORMULATION that makes tnsx_options.query_formulation = 1 reach it (tnsx_query_formulation_available(1) tells).
+OPTIONAL_GROUP = "tnsx_query_group.hip"
 HEADERS = ["tnsx_kernels.h", "tnsx_device.h", "tnsx_pool.h", "tnsx_multi.h", os.path.join(ROOT, "include", "tnsx.h")]
 
 # -ffp-contract=off: the neighbour predicate must not be re-associated or fused behind our back
@@ -30,13 +34,44 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+def _with_group() -> bool:
+    return os.environ.get("TNSX_WITH_GROUP_FORMULATION", "0") not in ("", "0")
+
+
+def _sources():
+    return SOURCES + ([OPTIONAL_GROUP] if _with_group() else [])
+
+
+def _commands():
+    """[(source, object, command line)]: everything that decides what an object file contains."""
+    extra = os.environ.get("TNSX_EXTRA_FLAGS", "").split()     # experiments, e.g. -DTNSX_FAST_WAVES_PER_EU=5
+    if _with_group():
+        extra = ["-DTNSX_WITH_GROUP_FORMULATION"] + extra
+    out = []
+    for src in _sources():
+        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
+        per_file = ["-mllvm", "-amdgpu-mfma-vgpr-form"] if src == OPTIONAL_GROUP else []   # MFMA results straight into VGPRs (no v_accvgpr_read)
+        out.append((src, obj, [hipcc()] + FLAGS + per_file + extra + ["-I" + os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, src), "-o", obj]))
+    return out
+
+
+def _recorded(obj: str) -> str:
+    try:
+        return open(obj + ".cmd").read()
+    except OSError:
+        return ""
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    deps = [os.path.join(CSRC, s) for s in _sources()] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     deps.append(os.path.abspath(__file__))
-    return any(os.path.getmtime(d) > t for d in deps)
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    # the library on disk was linked from objects compiled with other flags (an experiment's TNSX_EXTRA_FLAGS, the group formulation on / off)
+    return _recorded(LIB) != "\n".join(" ".join(cmd) for _, _, cmd in _commands())
 
 
 def build_native(force: bool = False, verbose: bool = False) -> str:
@@ -45,24 +80,37 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     objs, procs = [], []
     dep_t = max(os.path.getmtime(h if os.path.isabs(h) else os.path.join(CSRC, h)) for h in HEADERS + [os.path.abspath(__file__)])
-    for src in SOURCES:   # one hipcc per translation unit, all at once (the query kernels alone take two minutes)
-        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
+    cmds = _commands()
+    for src, obj, cmd in cmds:   # one hipcc per translation unit, all at once (the query kernels alone take two minutes)
         objs.append(obj)
-        extra = os.environ.get("TNSX_EXTRA_FLAGS", "").split()     # experiments, e.g. -DTNSX_FAST_WAVES_PER_EU=5
-        if not force and not extra and os.path.exists(obj) and os.path.getmtime(obj) > max(dep_t, os.path.getmtime(os.path.join(CSRC, src))):
+        # an object is reused only if it is newer than everything it depends on AND was compiled with exactly this command line (recorded beside it):
+        # objects of an experiment (TNSX_EXTRA_FLAGS) never end up in a later plain build
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(dep_t, os.path.getmtime(os.path.join(CSRC, src))) and _recorded(obj) == " ".join(cmd):
             continue
-        per_file = ["-mllvm", "-amdgpu-mfma-vgpr-form"] if src == "tnsx_query_group.hip" else []   # MFMA results straight into VGPRs (no v_accvgpr_read)
-        cmd = [hipcc()] + FLAGS + per_file + extra + ["-I" + os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, src), "-o", obj]
+        if os.path.exists(obj + ".cmd"):
+            os.remove(obj + ".cmd")
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
+        procs.append((obj, cmd, subprocess.Popen(cmd)))
+    failed = None
+    for obj, cmd, p in procs:
+        if failed is not None:      # one compilation failed: do not leave the others running behind the exception
+            p.kill()
+            p.wait()
+            continue
         if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
+            failed = (p.returncode, cmd)
+            continue
+        with open(obj + ".cmd", "w") as f:
+            f.write(" ".join(cmd))
+    if failed is not None:
+        raise subprocess.CalledProcessError(failed[0], failed[1])
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(LIB + ".cmd", "w") as f:
+        f.write("\n".join(" ".join(c) for _, _, c in cmds))
     return LIB
 
 

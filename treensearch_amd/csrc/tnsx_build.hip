@@ -780,11 +780,16 @@ __global__ void __launch_bounds__(BS_THREADS) k_bucket_sort(const float4* __rest
 	//  is up and this attempt will be thrown away -- but it must not read past the window, which for the last buckets is the end of the array)
 	const uint32_t count = win ? min(totals[(size_t)b * tstride], win[b].y) : totals[(size_t)b * tstride];
 	for (int k = (int)threadIdx.x; k < RADIX; k += BS_THREADS) h[k] = 0u;
+	// One-read pass whose guard is already up (a window overflowed in k_bucket_scatter, earlier on this stream): the window has slots that nobody wrote -- stale
+	// points of a run with another n, or memory that was never written -- and their w component must not be used as an index into radii[] / ids[].  The attempt
+	// is thrown away by the host anyway: the bucket reports no cells and leaves.  (One thread reads the word for everybody: other workgroups of this launch may
+	// raise it meanwhile, and the whole workgroup has to take the same side of the barriers below.)
+	if (threadIdx.x == 0) red[2 * (BS_THREADS / WAVE) + 1] = (win && gd.flag) ? __hip_atomic_load(gd.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 	__syncthreads();
 	uint32_t start = 0;
 	#pragma unroll
 	for (int k = 0; k < BS_THREADS / WAVE; k++) start += red[k];
-	if (count == 0u) { if (threadIdx.x == 0) bucket_info[b] = make_uint2(0u, 0u); return; }
+	if (count == 0u || red[2 * (BS_THREADS / WAVE) + 1] != 0u) { if (threadIdx.x == 0) bucket_info[b] = make_uint2(0u, 0u); return; }
 	// where the bucket's points are: packed behind the buckets before it (histogram pass), or in the bucket's own window (one-read pass)
 	if (win) in += win[b].x; else in += start;
 	// ---- the bucket's points -> registers (all loads in flight at once), sweep 1: points per cell

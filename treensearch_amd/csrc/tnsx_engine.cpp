@@ -441,6 +441,13 @@ static tnsx_status sync_stream(tnsx_context* c)
 extern "C" {
 
 int tnsx_version(void) { return TNSX_VERSION; }
+int tnsx_query_formulation_available(int f)
+{
+#ifdef TNSX_WITH_GROUP_FORMULATION
+	if (f == 1) return 1;
+#endif
+	return f == 0 ? 1 : 0;
+}
 
 tnsx_status tnsx_default_options(tnsx_options* opt)
 {
@@ -1170,7 +1177,8 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_POOL;
 			// opt-in (tnsx_options.query_formulation = 1), fixed radius, a set searched in itself: the group formulation (tnsx_query_group.hip)
 			// in front of the cell kernels, unless it was switched off for this pair
-			pr.groups_now = !sparse && !variable && jb.i == jb.j && c->opt.query_formulation == 1 && !pr.groups_off && c->grid_h * c->grid_h > 1e-30f;
+			pr.groups_now = !sparse && !variable && jb.i == jb.j && c->opt.query_formulation == 1 && tnsx_query_formulation_available(1) != 0 && !pr.groups_off &&
+			                c->grid_h * c->grid_h > 1e-30f;
 			qc.groups = pr.groups_now;
 			if (pr.groups_now) { HIPCHK(c, pr.filtered.reserve((size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pr.n_i, n_cells)) * sizeof(uint2))); tiers = 3; }
 			qc.tiers = tiers;

@@ -1,16 +1,18 @@
 // gfx950 kernels: THE QUERY (27-cell distance test; single-pass pool mode and count / fill passes).
 //
-// Query design (one wave64 per occupied cell of the query set; no LDS, no MFMA):
+// Query design (one wave64 per occupied cell of the query set; no MFMA; LDS only as per-wave staging: the deal table of a cell's candidates and the
+// block of its records, see "Candidate dealing through an LDS table" and "Whole-cell staging" below):
 //   * the 27 neighbour cells of the candidate set are looked up by 27 lanes in one round trip and merged into 9
 //     x-contiguous runs of the sorted candidate array (row-major keys: x-neighbours are adjacent in sorted order);
-//   * the concatenation of the 9 runs is dealt to the lanes slot by slot (slot = chunk*64 + lane); every lane finds the
-//     run of its slot with 8 scalar-operand compares, so ALL candidate loads (one coalesced 16-byte load per lane and
-//     chunk) are issued back to back and land directly in registers -- one memory round trip per cell;
+//   * the concatenation of the 9 runs is dealt to the lanes slot by slot (slot = chunk*64 + lane) through a table of sorted positions that every
+//     run writes into the wave's LDS staging area once per cell (the general kernel: 8 scalar-operand compares per slot), so ALL candidate loads
+//     (one coalesced 16-byte load per lane and chunk) are issued back to back and land directly in registers -- one memory round trip per cell;
 //   * the occupied-cell list entry is prefetched two cells ahead and the 27 lookups one cell ahead, so that the only
 //     exposed latency per cell is the candidate load, which the other resident waves hide;
 //   * the cell's query points are broadcast one at a time (v_readlane); each is tested against all register-resident
 //     candidates, two chunks per packed-fp32 instruction (v_pk_add/mul/fma_f32), and the hits are compacted with
-//     ballot + mbcnt straight into the query's CSR record (fill) or just counted (count);
+//     ballot + mbcnt into the block of the cell's records in LDS, which leaves with full-wave non-temporal stores (pool mode), or straight into
+//     the query's CSR record (fill), or are just counted (count);
 //   * work assignment is XCD-aware: workgroup b runs on XCD b % 8, and every XCD owns one contiguous eighth of the
 //     (roughly key-ordered) occupied-cell list, so the three z-planes a wave touches stay in that XCD's L2.
 // The distance arithmetic is spelled op by op (file compiled with -ffp-contract=off) and is bit-identical to the
@@ -1236,7 +1238,9 @@ static void launch_query_1(const QueryArgs& a, const QueryConfig& c, int n_cus, 
 }
 void launch_query(const QueryArgs& a, const QueryConfig& c, int n_compute_units, hipStream_t s)
 {
+#ifdef TNSX_WITH_GROUP_FORMULATION   // (tnsx_query_group.hip is part of the library only in builds that ask for it: measured 2.6 x slower)
 	if (c.mode == QUERY_POOL && c.groups && !c.variable) { launch_query_groups(a, c, n_compute_units, s); return; }
+#endif
 	if (c.arith == 0) launch_query_1<0>(a, c, n_compute_units, s); else launch_query_1<1>(a, c, n_compute_units, s);
 }
 
