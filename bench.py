@@ -301,6 +301,24 @@ def secondary_workload(name, points, arith):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def one_gpu_reference(n_total):
+    """What the N-GPU figure of c5 is to be divided by: the SAME workload (all of its points, one slab, through tnsx_slab_step) on ONE GPU.  `bench.py --gpus 1`
+    runs c2 (the N = 1 rule of the bench contract), so the number is quoted from the committed single-GPU run of c5 and labelled as such; `bench.py
+    --workload c5 [--points N]` on one GPU reproduces it."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "bench_r4_c5_200m_1gpu.json")
+    try:
+        with open(path) as f:
+            ref = json.loads(f.read().strip().splitlines()[-1])
+        if int(ref["config"]["points_total"]) != int(n_total):
+            return {"quoted": False, "note": f"no committed single-GPU run of c5 at {n_total} points (profiles/bench_r4_c5_200m_1gpu.json is at {ref['config']['points_total']}); "
+                                             "run `python bench.py --workload c5 --points N` on one GPU"}
+        return {"quoted": True, "source": "profiles/bench_r4_c5_200m_1gpu.json (builder-run on a 1-GPU box in round 4: another box, not this run)",
+                "ms_per_step": ref["ms_per_step"], "value": ref["value"], "unit": ref["unit"],
+                "note": "speed-up at N GPUs = this line's value / this value (both: all points of the workload per step)"}
+    except Exception as e:   # (the file is part of the repository; a checkout without profiles/ still gets its line)
+        return {"quoted": False, "note": f"profiles/bench_r4_c5_200m_1gpu.json not readable ({e})"}
+
+
 def measured_copy_peak(torch):
     """device-to-device copy of 2 GiB (read + write), best of 24: the ceiling a streaming kernel reaches on THIS box"""
     n = 1 << 29
@@ -498,7 +516,7 @@ def main():
         desc = (f"{n}-point SPH dam break (70 % dense column, 25 % floor layer, 5 % spray), per-point radii r0*(1+u) with r0={float(r0):.6f}, "
                 f"symmetric search; every step: perturb <= 0.1 r0, prepare_zsort, apply_zsort(xyz), apply_zsort(radii), run; BASELINE.json configs[3]")
     else:   # c5
-        from treensearch_amd.multi import SlabDecomposition, SlabSearch, SlabSearchC, SlabTransportC, balanced_cuts_c, redistribute_c
+        from treensearch_amd.multi import SlabDecomposition, SlabSearch, SlabSearchC, SlabTransportC, balanced_cuts_c, redistribute_c, transport_check_c
         n_total = points_total or 200_000_000
         radius = D.radius_for_neighbors(n_total)
         lo_i, hi_i = (n_total * rank) // world, (n_total * (rank + 1)) // world            # generated: a contiguous index range per rank
@@ -551,6 +569,12 @@ def main():
             ns = make_engine()
             slab = SlabSearchC(float(cuts[rank]), float(cuts[rank + 1]), float(radius), ns, transport, rank, world, halo_margin=0.11)
             slab.set_watchdog(60.0)      # a step that does not complete in a minute fails with a message naming the link (instead of hanging the job)
+            # what a reader of the line needs to believe that N ranks exchanged halos: the communicator's own rank count and an all-reduce of ones over it
+            inf0 = slab.info()
+            extra["transport"] = {"kind": {0: "none (one slab)", 1: "RCCL", 2: "in-process", 3: "application (host-staged torch.distributed)"}.get(int(inf0.transport_kind), "?"),
+                                  "ranks_by_communicator": int(inf0.transport_ranks),
+                                  "ranks_by_allreduce_of_ones": transport_check_c(ns, transport, rank, world) if transport is not None else 1}
+            extra["rccl_nranks"] = int(inf0.transport_ranks) if int(inf0.transport_kind) == 1 else None
             extra["slab_backend"] = "C ABI: tnsx_slab_step (" + (("host-staged torch.distributed transport (dry run on a shared GPU)" if os.environ.get("TNSX_BENCH_SHARED_GPU") == "1" else "RCCL ncclSend / ncclRecv issued by libtnsx.so") if transport is not None else "one slab, no exchange") + ")"
         else:
             slab = SlabSearch(float(cuts[rank]), float(cuts[rank + 1]), float(radius), make_engine, halo_margin=0.11)
@@ -602,16 +626,41 @@ def main():
     # ---- stage pass: the same steps again with hipEvents around every stage (on the engine's stream; the query's bracket holds its kernels only),
     #      AFTER the timed loop: the stage times of the roofline come from here, the timed loop itself records no events
     stage_steps = 0 if args.no_stage_pass else min(max(args.steps, 1), 10)
+    exchange_ms = 0.0
+    slab_c = slab if (workload == "c5" and hasattr(slab, "set_collect_times")) else None    # (the slab layer behind the C ABI)
     if stage_steps:
         ns.set_collect_stage_times(True)
+        if slab_c is not None:
+            slab_c.set_collect_times(True)                # an event pair around the grouped ncclSend / ncclRecv of every step
         step(args.warmup + args.steps)                    # (the first run with events creates them)
         for k in range(args.warmup + args.steps + 1, args.warmup + args.steps + 1 + stage_steps):
             step(k)
             rs = ns.get_stats_raw()
             for key in STAGES:
                 acc[key] += getattr(rs, key)
+            if slab_c is not None:
+                exchange_ms += float(slab_c.info().exchange_ms_last)
         ns.set_collect_stage_times(False)
+        if slab_c is not None:
+            slab_c.set_collect_times(False)
         torch.cuda.synchronize()
+    if workload == "c5":
+        # per rank: owned points, ghosts received in the last step, exchange time per step (stage pass), bytes sent so far -- gathered so that the
+        # line shows what every rank did, not only rank 0
+        inf = slab_c.info() if slab_c is not None else None
+        mine_row = torch.tensor([float(n_owned), float(inf.n_ghost) if inf is not None else -1.0, exchange_ms / max(stage_steps, 1) if inf is not None else -1.0,
+                                 float(inf.bytes_sent) if inf is not None else -1.0, float(inf.speculative_last) if inf is not None else -1.0], dtype=torch.float64)
+        rows = [mine_row]
+        if distributed and world > 1:
+            on_gpu = dist.get_backend() == "nccl"
+            buf = [torch.zeros(5, dtype=torch.float64, device="cuda" if on_gpu else "cpu") for _ in range(world)]
+            dist.all_gather(buf, mine_row.cuda() if on_gpu else mine_row)
+            rows = [b.cpu() for b in buf]
+        extra["per_rank"] = {"owned_points": [int(r[0]) for r in rows], "ghost_points_last_step": [int(r[1]) for r in rows],
+                             "exchange_ms_per_step": [round(float(r[2]), 4) for r in rows], "bytes_sent_total": [int(r[3]) for r in rows],
+                             "last_step_speculative": [int(r[4]) for r in rows],
+                             "note": "exchange_ms_per_step: hipEvent pair around the transport's exchange call (one grouped ncclSend / ncclRecv per step) in the stage pass "
+                                     "behind the timed loop; -1: the exchange ran in treensearch_amd/multi.py (no such bracket)"}
     if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -662,6 +711,8 @@ def main():
         "cold_run": {"ms": round(cold_ms, 3), "dry_passes": cold_stats["cold_passes"],
                      "note": "first step of the process: allocations + one count-only pass per pair + the sized pass"},
     }
+    if workload == "c5" and world > 1:
+        out["one_gpu_same_workload"] = one_gpu_reference(n_total)
     if "zsort_ms_per_step" in extra and extra["zsort_ms_per_step"]:
         out["stage_ms"]["zsort_prepare_and_apply"] = round(float(np.mean(extra["zsort_ms_per_step"])), 4)
     if rank == 0:

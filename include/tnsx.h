@@ -296,6 +296,11 @@ typedef struct tnsx_slab_info {
 	int redone_last;             /* 1: a capacity was exceeded, the overflowed link(s) were repaired and the search repeated */
 	int rounds_last;             /* exchange rounds of the last step (exact step: 2, speculative: 1, + 1 repair round) */
 	unsigned long long bytes_sent;   /* so far */
+	int transport_kind;          /* 0: none (one slab), 1: RCCL (tnsx_slab_transport_rccl), 2: in-process (tnsx_slab_transport_local), 3: the application's own */
+	int transport_ranks;         /* ranks the transport spans as far as the library can tell: ncclCommCount of the RCCL communicator, the size of a local
+	                                group, 1 without a transport, -1 for an application's transport (tnsx_slab_transport_check counts those) */
+	float exchange_ms_last;      /* tnsx_slab_set_collect_times(1): time the exchange rounds of the last step took on the stream (hipEvent pairs around the
+	                                transport's exchange calls; a speculative step has one round), else 0 */
 } tnsx_slab_info;
 
 /* RCCL: rank 0 makes the 128-byte id, the application hands it to every rank (MPI_Bcast, torch.distributed.broadcast, a file, ...) */
@@ -347,6 +352,12 @@ tnsx_status tnsx_slab_step(tnsx_slab* slab, int n_sets, const float* const* xyz,
                            const int* n_points);
 int         tnsx_slab_engine_set(const tnsx_slab* slab, int set_index);   /* the engine's id of [owned | ghosts] of that set, -1 before its first step */
 tnsx_status tnsx_slab_get_info(const tnsx_slab* slab, tnsx_slab_info* out);
+/* 1: from the next step on every exchange round is bracketed by a pair of hipEvents on the stream (tnsx_slab_info.exchange_ms_last).  Off by default: an
+ * event record between two launches costs a bubble of several microseconds -- benchmarks switch it on for extra steps behind their timed loop. */
+tnsx_status tnsx_slab_set_collect_times(tnsx_slab* slab, int on);
+/* Collective self check of a transport: all-reduces the number 1 over its ranks on the engine's stream and returns the sum -- `world` when every rank of
+ * the job really is on the other end (a benchmark line can then say that N ranks took part without anybody having to trust the launcher). */
+tnsx_status tnsx_slab_transport_check(tnsx_context* engine, const tnsx_slab_transport* transport, int rank, int world, int* ranks_seen);
 tnsx_status tnsx_slab_debug_set_capacity(tnsx_slab* slab, int side, unsigned rows);   /* tests: shrink the agreed capacity of one link (0 = left) */
 
 #ifdef __cplusplus

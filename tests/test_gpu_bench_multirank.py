@@ -30,3 +30,12 @@ def test_bench_two_ranks_on_a_shared_gpu():
     assert 0.4 < d["config"]["cuts"][0] < 0.6 and 900000 < d["config"]["points_rank0"] < 1100000
     assert 57.0 < d["config"]["neighbors_per_query"] < 61.0        # (the 2 M-point cloud of configs[4]'s scaled instance: 58.7 neighbours per point)
     assert d["steady_state"]["runs_repeated_after_a_failed_assumption"] <= 1 and d["value"] > 0
+    # round 5: the line checks itself -- who exchanged what with whom, and what a speed-up is to be measured against
+    tr = d["config"]["transport"]
+    assert tr["ranks_by_allreduce_of_ones"] == 2, tr                      # every rank of the job was on the other end of the transport
+    assert tr["kind"].startswith("application") and d["config"]["rccl_nranks"] is None     # (the dry run's transport is not RCCL, and the line says so)
+    pr = d["config"]["per_rank"]
+    assert len(pr["owned_points"]) == 2 and sum(pr["owned_points"]) == 2000000
+    assert all(20000 < g < 120000 for g in pr["ghost_points_last_step"]), pr   # one halo of 1.11 r of a 1 M-point slab: ~57 k ghosts (capacity-padded rows included)
+    assert all(ms > 0.0 for ms in pr["exchange_ms_per_step"]) and all(b > 0 for b in pr["bytes_sent_total"])
+    assert d["one_gpu_same_workload"]["quoted"] is False                  # (no committed single-GPU run at 2 M points; at 200 M the line quotes profiles/bench_r4_c5_200m_1gpu.json)

@@ -1,0 +1,620 @@
+// Round 5, verdict item 1: the query formulation with HALF-EDGE FINE CELLS over an LDS-STAGED TILE, as a complete stand-alone kernel
+// (real fine-cell sort, real tiles, real [count, j...] records in a bump-allocated pool, verified against an all-candidates reference kernel)
+// so that it can be timed and profiled before anything is threaded through the engine.
+//
+// Geometry.  Fine cells of edge h/2 (h >= r): the neighbours of a point lie in the 5 x 5 x 5 fine cells around its own = 15.6 h^3 instead of
+// the 27 h^3 of the cell kernels: 221 candidates per query instead of 383 at C2's density (14.14 points per h^3).
+// Tile.  Points are sorted by fine key, x fastest.  A workgroup (4 waves) owns TX consecutive fine cells of one (y, z) row of the fine grid;
+// their candidates are the 25 rows (y +- 2, z +- 2) over x0 - 2 .. x0 + TX + 1: 25 CONTIGUOUS runs of the sorted array.  They are staged in LDS
+// TRANSPOSED, slab by slab: slot order [x][y'][z'], so that the candidates of a query in cell x are ONE contiguous range of slots,
+// [off[x - 2], off[x + 3]) -- no runs to deal, no validity masks (whatever lies behind the range is a slab farther away than r, or padding).
+// Two arrangements of the lanes over that tile:
+//   A  candidates in the lanes (64 per chunk, ds_read_b128 once per fine cell), the cell's queries broadcast one at a time, hits compacted
+//      lane-major into the block of records (exactly the inner loop of k_query_pool_fast, on 3.95 chunks instead of 6.42);
+//   B  a query per QUARTER WAVE (16 lanes walk the query's range 16 candidates per step, four queries in lock step), hits appended to per-lane
+//      lists in LDS (exec <- hit; ds_write_b32; v_add), lists copied into the block of records at the end of a round.
+// (One query per LANE -- the sketch of the round-4 verdict -- needs a hit list per lane: 64 lanes x ~100 entries = 13-26 KB of LDS per wave on top
+//  of the tile, i.e. one wave per SIMD; and 64 lanes in lock step over ranges of 221 +- 15 slots idle 13 % of the time.  B is that formulation with
+//  the list problem solved: a lane sees at most one hit per step, so 16 steps bound its list.)
+//
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o fine_query fine_query.hip ;  run: ./fine_query [n_points] [A|B|AB] [reps]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+static constexpr int WAVE = 64;
+
+struct FGrid { float ox, oy, oz, inv_hf; int nx, ny, nz; };
+__host__ __device__ inline int fbin(float p, float o, float inv, int n)
+{
+	const float f = (p - o) * inv;   // (compiled with -ffp-contract=off on both sides)
+	int c = (int)f;
+	c = c < 0 ? 0 : c;
+	return c > n - 1 ? n - 1 : c;
+}
+
+// ---- tile geometry
+static constexpr int TX = 32;                 // fine cells of a tile along x (8 per wave)
+static constexpr int WAVES = 4, THREADS = WAVES * WAVE;
+static constexpr int CPW = TX / WAVES;        // cells per wave
+static constexpr int W = TX + 4;              // slabs of a tile
+static constexpr int NCELL = W * 25;
+static constexpr int KSCAN = (NCELL + THREADS - 1) / THREADS;   // cells per thread in the prefix
+static constexpr int CAP = 1856;              // points a tile can hold (C2 density: 1593 +- 40)
+static constexpr int PAD = 128;               // NaN slots behind the last point (what the lock step of arrangement B can read past a short range)
+static constexpr int LIST_STEPS = 20;         // arrangement B: entries of a lane's hit list = steps of a round (320 candidates)
+static constexpr int STAGE = 1024;            // ints of a wave's block of records
+static constexpr int ROWS_PER_WAVE = 7;       // 25 rows over 4 waves
+static constexpr int ROW_ITERS = 2;           // 64-point pieces of a row loaded up front (a row of a tile holds (TX + 4) * 1.77 = 64 points)
+static constexpr int NREG = 64;               // regions of the record pool (one cursor each, 128 bytes apart)
+static constexpr uint32_t SLAB = 8192;        // ints a wave takes from its region per atomic
+
+struct FArgs {
+	const float4* pts; const uint32_t* fstart; FGrid g; float r2;
+	int* records; uint64_t* offs; unsigned long long* cursors; unsigned long long region_cap;
+	uint32_t ntx, n_tiles; uint32_t* ticket; unsigned long long* stats;   // stats[0] hits, [1] tiles that did not fit, [2] pool failures
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ float rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// wave-wide inclusive scan (DPP: four steps inside the rows of 16 lanes, two broadcasts across them)
+__device__ __forceinline__ uint32_t wave_iscan(uint32_t v)
+{
+	asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+	             "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+	             "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+	             "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+	             "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+	             : "+v"(v));
+	return v;
+}
+
+template <int ARITH>
+__device__ __forceinline__ v2f dist_sq2(float qx, float qy, float qz, v2f cx, v2f cy, v2f cz)
+{
+	const v2f dx = (v2f)(qx) - cx, dy = (v2f)(qy) - cy, dz = (v2f)(qz) - cz;
+	if (ARITH == 0) return (dx * dx + dy * dy) + dz * dz;
+	return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS of a workgroup
+// ---------------------------------------------------------------------------------------------------------------------
+template <int ARR> struct Lds {
+	float4 tile[CAP + PAD];
+	int delta[NCELL];          // slot of a point = its sorted position + delta[cell of the tile]
+	uint32_t off[W + 1];       // first slot of slab x
+	uint32_t qs[TX + 1];       // sorted position of the first query of cell x of the tile
+	uint32_t wsum[WAVES];
+	uint32_t tile_id, total;
+	uint32_t stage[WAVES][STAGE];
+	uint32_t lists[ARR ? WAVES : 1][ARR ? LIST_STEPS * WAVE : 1];   // arrangement B: entry k of lane l at [k * 64 + l]
+	uint4 qinfo[ARR ? WAVES : 1][ARR ? WAVE : 1];                  // arrangement B: {slot of the query, first candidate slot, candidates, -}
+};
+
+// stages the tile (fy, fz, x0): returns false when it does not fit
+template <int ARR> __device__ __forceinline__ bool stage_tile(const FArgs& a, Lds<ARR>& L, int x0, int fy, int fz)
+{
+	const int tid = (int)threadIdx.x, lane = lane_id(), w = tid / WAVE;
+	const FGrid g = a.g;
+	// ---- phase 1: points per cell of the tile, prefix in slab order
+	uint32_t s[KSCAN], c[KSCAN];
+	#pragma unroll
+	for (int k = 0; k < KSCAN; k++) {
+		const int e = tid * KSCAN + k;
+		const int xs = e / 25, r = e % 25;
+		const int gx = x0 - 2 + xs, gy = fy - 2 + r / 5, gz = fz - 2 + r % 5;
+		const bool in = e < NCELL && gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny && gz >= 0 && gz < g.nz;
+		const uint32_t key = in ? ((uint32_t)gz * g.ny + gy) * g.nx + gx : 0u;
+		const uint32_t s0 = a.fstart[key], s1 = a.fstart[key + 1u];
+		s[k] = s0; c[k] = in ? s1 - s0 : 0u;
+	}
+	if (tid <= TX) {   // the queries: cells x0 .. x0 + TX - 1 of row (fy, fz)
+		const int gx = x0 + tid;
+		const uint32_t rowkey = ((uint32_t)fz * g.ny + fy) * g.nx;
+		L.qs[tid] = a.fstart[rowkey + (uint32_t)(gx < g.nx ? gx : g.nx)];
+	}
+	uint32_t sum = 0;
+	#pragma unroll
+	for (int k = 0; k < KSCAN; k++) sum += c[k];
+	const uint32_t inc = wave_iscan(sum);
+	if (lane == WAVE - 1) L.wsum[w] = inc;
+	__syncthreads();
+	uint32_t ex = inc - sum;
+	#pragma unroll
+	for (int k = 0; k < WAVES; k++) if (k < w) ex += L.wsum[k];
+	#pragma unroll
+	for (int k = 0; k < KSCAN; k++) {
+		const int e = tid * KSCAN + k;
+		if (e < NCELL) {
+			L.delta[e] = (int)ex - (int)s[k];
+			if (e % 25 == 0) L.off[e / 25] = ex;
+		}
+		ex += c[k];
+	}
+	if (tid == THREADS - 1) { L.off[W] = ex; L.total = ex; }
+	__syncthreads();
+	const uint32_t total = rfl(L.total);
+	if (total > (uint32_t)CAP) return false;
+	// ---- phase 2: the 25 rows -> slots.  All loads of a thread are issued before the first is used (one round trip per tile).
+	const int gx_lo = x0 - 2 < 0 ? 0 : x0 - 2, gx_hi = x0 + TX + 1 > g.nx - 1 ? g.nx - 1 : x0 + TX + 1;
+	float4 pt[ROWS_PER_WAVE][ROW_ITERS];
+	uint32_t pos[ROWS_PER_WAVE][ROW_ITERS], rend[ROWS_PER_WAVE];
+	#pragma unroll
+	for (int j = 0; j < ROWS_PER_WAVE; j++) {
+		const int r = w + WAVES * j;
+		const int gy = fy - 2 + r / 5, gz = fz - 2 + r % 5;
+		const bool in = r < 25 && gy >= 0 && gy < g.ny && gz >= 0 && gz < g.nz;
+		const uint32_t rowkey = in ? ((uint32_t)gz * g.ny + gy) * g.nx : 0u;
+		const uint32_t rs = in ? a.fstart[rowkey + gx_lo] : 0u, re = in ? a.fstart[rowkey + gx_hi + 1u] : 0u;
+		rend[j] = re;
+		#pragma unroll
+		for (int it = 0; it < ROW_ITERS; it++) {
+			const uint32_t p = rs + (uint32_t)(it * WAVE + lane);
+			pos[j][it] = p;
+			pt[j][it] = a.pts[p < re ? p : (re > rs ? re - 1u : 0u)];
+		}
+	}
+	#pragma unroll
+	for (int j = 0; j < ROWS_PER_WAVE; j++) {
+		const int r = w + WAVES * j;
+		#pragma unroll
+		for (int it = 0; it < ROW_ITERS; it++) {
+			if (pos[j][it] < rend[j]) {
+				const int cx = fbin(pt[j][it].x, g.ox, g.inv_hf, g.nx) - (x0 - 2);
+				L.tile[(int)pos[j][it] + L.delta[cx * 25 + r]] = pt[j][it];
+			}
+		}
+		for (uint32_t p = pos[j][ROW_ITERS - 1] + WAVE; p < rend[j]; p += WAVE) {   // (a row longer than the pieces loaded up front)
+			const float4 q = a.pts[p];
+			const int cx = fbin(q.x, g.ox, g.inv_hf, g.nx) - (x0 - 2);
+			L.tile[(int)p + L.delta[cx * 25 + r]] = q;
+		}
+	}
+	if (tid < PAD) L.tile[total + tid] = make_float4(NAN, NAN, NAN, __uint_as_float(0xffffffffu));
+	__syncthreads();
+	return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// record pool: per-wave slabs, the wave's block of records leaves with full-wave stores
+// ---------------------------------------------------------------------------------------------------------------------
+struct Pool { uint64_t base; uint32_t left, ok; };
+__device__ __forceinline__ v4i record_rsrc(const int* base, uint32_t n)
+{
+	const uint64_t b = (uint64_t)base;
+	v4i r;
+	r.x = (int)(uint32_t)b; r.y = (int)(((uint32_t)(b >> 32) & 0xffffu) | (4u << 16)); r.z = (int)n; r.w = 0x00020000;
+	return r;
+}
+// the block stage[0, block) of this wave -> the pool; returns where it went (or ~0)
+__device__ __forceinline__ uint64_t flush_block(const FArgs& a, Pool& ps, const uint32_t* stage, uint32_t block, int lane)
+{
+	if (block > ps.left) {
+		const uint32_t sz = block > SLAB ? block : SLAB;
+		unsigned long long first = ~0ull;
+		if (lane == 0) {
+			const uint32_t r = blockIdx.x % NREG;
+			const unsigned long long old = atomicAdd(a.cursors + (size_t)r * 16, (unsigned long long)sz);
+			if (old + sz <= a.region_cap) first = (unsigned long long)r * a.region_cap + old;
+			else atomicAdd(a.stats + 2, 1ull);
+		}
+		const uint64_t got = ((uint64_t)rfl((uint32_t)(first >> 32)) << 32) | rfl((uint32_t)first);
+		ps.ok = got != ~0ull ? 1u : 0u;
+		ps.base = ps.ok ? got : 0;
+		ps.left = sz;
+	}
+	const uint64_t dst = ps.base;
+	if (ps.ok) {
+		const v4i rsrc = record_rsrc(a.records + dst, block);
+		for (uint32_t f = 0; f < block; f += 4u * WAVE) {
+			const uint32_t i = f + (uint32_t)lane;
+			const uint32_t v0 = stage[i], v1 = stage[i + 64u], v2 = stage[i + 128u], v3 = stage[i + 192u];
+			asm volatile("buffer_store_dword %[v0], %[i0], %[rsrc], 0 idxen nt\n\tbuffer_store_dword %[v1], %[i1], %[rsrc], 0 idxen nt\n\t"
+			             "buffer_store_dword %[v2], %[i2], %[rsrc], 0 idxen nt\n\tbuffer_store_dword %[v3], %[i3], %[rsrc], 0 idxen nt"
+			             : : [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [i0] "v"(i), [i1] "v"(i + 64u), [i2] "v"(i + 128u), [i3] "v"(i + 192u),
+			                 [rsrc] "s"(rsrc) : "memory");
+		}
+	}
+	ps.base += block; ps.left -= block;
+	return ps.ok ? dst : ~0ull;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// arrangement A: candidates in the lanes
+// ---------------------------------------------------------------------------------------------------------------------
+#define LDS_PIECE(K) "s_mov_b64 exec, %[m" #K "]\n\tds_write_b32 %[addr], %[v" #K "] offset:4\n\tv_add_u32 %[addr], 4, %[addr]\n\t"
+#define LDS_IN(K, M, V) [m##K] "s"(M), [v##K] "v"(V)
+template <int N> __device__ __forceinline__ void stage_chunks(uint32_t& addr, const uint64_t* m, const uint32_t* v)
+{
+	if (N == 1) asm volatile(LDS_PIECE(0) "s_mov_b64 exec, -1" : [addr] "+v"(addr) : LDS_IN(0, m[0], v[0]) : "memory");
+	else if (N == 2) asm volatile(LDS_PIECE(0) LDS_PIECE(1) "s_mov_b64 exec, -1" : [addr] "+v"(addr) : LDS_IN(0, m[0], v[0]), LDS_IN(1, m[1], v[1]) : "memory");
+	else if (N == 3) asm volatile(LDS_PIECE(0) LDS_PIECE(1) LDS_PIECE(2) "s_mov_b64 exec, -1" : [addr] "+v"(addr) : LDS_IN(0, m[0], v[0]), LDS_IN(1, m[1], v[1]), LDS_IN(2, m[2], v[2]) : "memory");
+	else asm volatile(LDS_PIECE(0) LDS_PIECE(1) LDS_PIECE(2) LDS_PIECE(3) "s_mov_b64 exec, -1"
+	                  : [addr] "+v"(addr) : LDS_IN(0, m[0], v[0]), LDS_IN(1, m[1], v[1]), LDS_IN(2, m[2], v[2]), LDS_IN(3, m[3], v[3]) : "memory");
+}
+template <int NC> __device__ __forceinline__ void stage_all(uint32_t& addr, const uint64_t (&m)[NC], const uint32_t* v)
+{
+	#pragma unroll
+	for (int g = 0; g < NC; g += 4) {
+		if (NC - g >= 4) stage_chunks<4>(addr, m + g, v + g);
+		else if (NC - g == 3) stage_chunks<3>(addr, m + g, v + g);
+		else if (NC - g == 2) stage_chunks<2>(addr, m + g, v + g);
+		else stage_chunks<1>(addr, m + g, v + g);
+	}
+}
+
+struct WaveOut {   // the block of records a wave is building
+	uint32_t spos, t0, v_pos;   // ints staged; first query (lane) of the block; lane t: where record t starts in its block
+	uint32_t hits;
+};
+// the staged block holds the records of the wave's queries [t0, t1) (query index = lane): out it goes, offsets by original id
+__device__ __forceinline__ void flush_queries(const FArgs& a, Pool& ps, WaveOut& o, const uint32_t* stage, uint32_t t1, uint32_t qid, int lane)
+{
+	if (o.spos == 0u) { o.t0 = t1; return; }
+	const uint64_t dst = flush_block(a, ps, stage, o.spos, lane);
+	if (dst != ~0ull && (uint32_t)lane >= o.t0 && (uint32_t)lane < t1) a.offs[qid] = dst + o.v_pos;
+	o.hits += o.spos - (t1 - o.t0);
+	o.t0 = t1; o.spos = 0;
+}
+
+// one fine cell: its nq queries (lanes tq0 .. tq0 + nq of the wave's query numbering) against the candidates [c0, c0 + 64 NC)
+template <int ARITH, int NC>
+__device__ __forceinline__ void cell_A(const FArgs& a, Lds<0>& L, Pool& ps, WaveOut& o, uint32_t c0, uint32_t qslot0, uint32_t tq0, uint32_t nq, const float4 qv,
+                                       uint32_t qid, int lane, int w)
+{
+	constexpr int NP = (NC + 1) / 2;
+	v2f cx[NP], cy[NP], cz[NP];
+	uint32_t cid[2 * NP];
+	#pragma unroll
+	for (int k = 0; k < 2 * NP; k++) {
+		float4 c = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, __uint_as_float(0xffffffffu));
+		if (k < NC) c = L.tile[c0 + (uint32_t)(k * WAVE + lane)];
+		cx[k >> 1][k & 1] = c.x; cy[k >> 1][k & 1] = c.y; cz[k >> 1][k & 1] = c.z;
+		cid[k] = __float_as_uint(c.w);
+	}
+	uint32_t* const stage = L.stage[w];
+	const uint32_t stage_base = rfl((uint32_t)(uintptr_t)stage);
+	const uint32_t max_len = NC * WAVE + 1u;
+	for (uint32_t t = 0; t < nq; t++) {
+		const uint32_t tl = tq0 + t;   // the query's lane
+		if (o.spos + max_len > (uint32_t)STAGE) flush_queries(a, ps, o, stage, tl, qid, lane);
+		const float qx = rlf(qv.x, (int)tl), qy = rlf(qv.y, (int)tl), qz = rlf(qv.z, (int)tl);
+		uint64_t m[NC];
+		#pragma unroll
+		for (int h = 0; h < NP; h++) {
+			const v2f d2 = dist_sq2<ARITH>(qx, qy, qz, cx[h], cy[h], cz[h]);
+			#pragma unroll
+			for (int u = 0; u < 2; u++) { const int k = 2 * h + u; if (k < NC) m[k] = __builtin_amdgcn_ballot_w64(d2[u] <= a.r2); }
+		}
+		// the query itself: slot qslot0 + t of the tile = candidate number qslot0 + t - c0
+		{
+			const uint32_t pos = qslot0 + t - c0, ks = pos >> 6;
+			#pragma unroll
+			for (int k = 0; k < NC; k++) if (ks == (uint32_t)k) asm("s_bitset0_b64 %0, %1" : "+s"(m[k]) : "s"(pos & 63u));
+		}
+		const uint32_t rec = stage_base + (o.spos << 2);
+		uint32_t addr;
+		{
+			uint32_t P = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[0] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[0], 0u));
+			#pragma unroll
+			for (int k = 1; k < NC; k++) P = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[k], P));
+			asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(addr) : "v"(P), "s"(rec));
+		}
+		stage_all<NC>(addr, m, cid);
+		const uint32_t cnt = (rl(addr, WAVE - 1) - rec) >> 2;
+		{
+			uint32_t tmp;
+			asm volatile("s_mov_b32 m0, %[rec]\n\ts_mov_b64 exec, 1\n\tv_mov_b32 %[t], %[c]\n\tds_write_addtid_b32 %[t]\n\ts_mov_b64 exec, -1"
+			             : [t] "=&v"(tmp) : [rec] "s"(rec), [c] "s"(cnt) : "memory");
+		}
+		asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(o.v_pos) : "s"(o.spos), "s"(tl));
+		o.spos += cnt + 1u;
+	}
+}
+
+template <int ARITH>
+__device__ __forceinline__ void wave_A(const FArgs& a, Lds<0>& L, Pool& ps, int lane, int w)
+{
+	// the wave's queries: cells [CPW * w, CPW * w + CPW) of the tile = consecutive sorted points; query index = lane (at most 64 per pass)
+	const uint32_t qb = rfl(L.qs[CPW * w]), qe = rfl(L.qs[CPW * w + CPW]);
+	for (uint32_t q0 = qb; q0 < qe; q0 += WAVE) {
+		const uint32_t nqw = qe - q0 < (uint32_t)WAVE ? qe - q0 : (uint32_t)WAVE;
+		// every lane: its query's cell, slot and coordinates
+		const uint32_t p = q0 + ((uint32_t)lane < nqw ? (uint32_t)lane : 0u);
+		int xc = 0;
+		#pragma unroll
+		for (int j = 1; j < CPW; j++) xc += L.qs[CPW * w + j] <= p ? 1 : 0;
+		xc += CPW * w;
+		const uint32_t slot = p + (uint32_t)L.delta[(xc + 2) * 25 + 12];
+		const float4 qv = L.tile[slot];
+		const uint32_t qid = __float_as_uint(qv.w);
+		WaveOut o = { 0u, 0u, 0u, 0u };
+		for (int j = 0; j < CPW; j++) {
+			const int x = CPW * w + j;
+			const uint32_t qs0 = rfl(L.qs[x]), qs1 = rfl(L.qs[x + 1]);
+			const uint32_t cb = qs0 > q0 ? qs0 : q0, ce = qs1 < q0 + nqw ? qs1 : q0 + nqw;   // queries of cell x in this pass
+			if (ce <= cb) continue;
+			const uint32_t c0 = rfl(L.off[x]), c1 = rfl(L.off[x + 5]);
+			const uint32_t nc = (c1 - c0 + WAVE - 1) / WAVE;
+			const uint32_t qslot0 = cb + rfl((uint32_t)L.delta[(x + 2) * 25 + 12]);
+			switch (nc) {
+			case 0: case 1: cell_A<ARITH, 1>(a, L, ps, o, c0, qslot0, cb - q0, ce - cb, qv, qid, lane, w); break;
+			case 2: cell_A<ARITH, 2>(a, L, ps, o, c0, qslot0, cb - q0, ce - cb, qv, qid, lane, w); break;
+			case 3: cell_A<ARITH, 3>(a, L, ps, o, c0, qslot0, cb - q0, ce - cb, qv, qid, lane, w); break;
+			case 4: cell_A<ARITH, 4>(a, L, ps, o, c0, qslot0, cb - q0, ce - cb, qv, qid, lane, w); break;
+			case 5: cell_A<ARITH, 5>(a, L, ps, o, c0, qslot0, cb - q0, ce - cb, qv, qid, lane, w); break;
+			case 6: cell_A<ARITH, 6>(a, L, ps, o, c0, qslot0, cb - q0, ce - cb, qv, qid, lane, w); break;
+			default: cell_A<ARITH, 8>(a, L, ps, o, c0, qslot0, cb - q0, ce - cb, qv, qid, lane, w); break;   // (up to 512 candidates; more: not in this harness)
+			}
+		}
+		flush_queries(a, ps, o, L.stage[w], nqw, qid, lane);
+		if (lane == 0 && o.hits) atomicAdd(a.stats, (unsigned long long)o.hits);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// arrangement B: a query per quarter wave
+// ---------------------------------------------------------------------------------------------------------------------
+template <int ARITH>
+__device__ __forceinline__ void wave_B(const FArgs& a, Lds<1>& L, Pool& ps, int lane, int w)
+{
+	const uint32_t qb = rfl(L.qs[CPW * w]), qe = rfl(L.qs[CPW * w + CPW]);
+	uint32_t* const stage = L.stage[w];
+	uint32_t* const lists = L.lists[w];
+	const uint32_t list_base = rfl((uint32_t)(uintptr_t)lists) + 4u * (uint32_t)lane;
+	const int lane16 = lane & 15, quarter = lane >> 4;
+	for (uint32_t q0 = qb; q0 < qe; q0 += WAVE) {
+		const uint32_t nqw = qe - q0 < (uint32_t)WAVE ? qe - q0 : (uint32_t)WAVE;
+		// ---- per query (lane = query index): cell, slot, candidate range -> LDS
+		{
+			const uint32_t p = q0 + ((uint32_t)lane < nqw ? (uint32_t)lane : 0u);
+			int xc = 0;
+			#pragma unroll
+			for (int j = 1; j < CPW; j++) xc += L.qs[CPW * w + j] <= p ? 1 : 0;
+			xc += CPW * w;
+			const uint32_t slot = p + (uint32_t)L.delta[(xc + 2) * 25 + 12];
+			const uint32_t c0 = L.off[xc], c1 = L.off[xc + 5];
+			L.qinfo[w][lane] = make_uint4(slot, c0, (uint32_t)lane < nqw ? c1 - c0 : 0u, 0u);
+		}
+		uint32_t spos = 0, t0 = 0, v_pos = 0, hits = 0;
+		const uint32_t my_qid = __float_as_uint(L.tile[L.qinfo[w][lane].x].w);   // lane = query index: for the offsets
+		auto flush = [&](uint32_t t1) {
+			if (spos == 0u) { t0 = t1; return; }
+			const uint64_t dst = flush_block(a, ps, stage, spos, lane);
+			if (dst != ~0ull && (uint32_t)lane >= t0 && (uint32_t)lane < t1) a.offs[my_qid] = dst + v_pos;
+			hits += spos - (t1 - t0);
+			t0 = t1; spos = 0;
+		};
+		for (uint32_t r0 = 0; r0 < nqw; r0 += 4u) {
+			// ---- the round's four queries, one per quarter
+			const uint4 qi = L.qinfo[w][r0 + (uint32_t)quarter < (uint32_t)WAVE ? r0 + (uint32_t)quarter : 0u];
+			const bool live = r0 + (uint32_t)quarter < nqw;
+			const float4 qv = L.tile[qi.x];
+			const float r2 = live ? a.r2 : -1.0f;
+			const uint32_t qid = __float_as_uint(qv.w);
+			const uint32_t T = live ? qi.z : 0u;
+			const uint32_t tm = max(max(rl(T, 0), rl(T, 16)), max(rl(T, 32), rl(T, 48)));
+			uint32_t steps = (tm + 15u) >> 4;
+			if (steps > (uint32_t)LIST_STEPS) { steps = LIST_STEPS; if (lane == 0) atomicAdd(a.stats + 3, 1ull); }   // (not handled in this harness: counted)
+			const float4* cp = L.tile + qi.y + (uint32_t)lane16;
+			uint32_t laddr = list_base;
+			float4 c = cp[0];
+			for (uint32_t s = 0; s < steps; s++) {
+				const float4 cn = cp[(s + 1u) * 16u];   // (next step's candidate in flight; behind the last range lies padding)
+				const float dx = qv.x - c.x, dy = qv.y - c.y, dz = qv.z - c.z;
+				float d2;
+				if (ARITH == 0) d2 = (dx * dx + dy * dy) + dz * dz; else d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+				const uint32_t cidv = __float_as_uint(c.w);
+				// exec <- hit (and not the query itself); one list entry; the lane's list pointer moves on
+				asm volatile("v_cmpx_le_f32 vcc, %[d2], %[r2]\n\tv_cmpx_ne_u32 vcc, %[cid], %[qid]\n\tds_write_b32 %[la], %[cid]\n\tv_add_u32 %[la], 256, %[la]\n\ts_mov_b64 exec, -1"
+				             : [la] "+v"(laddr) : [d2] "v"(d2), [r2] "v"(r2), [cid] "v"(cidv), [qid] "v"(qid) : "memory", "vcc");
+				c = cn;
+			}
+			// ---- lists -> the block of records
+			const uint32_t cnt = (laddr - list_base) >> 8;                    // entries of this lane
+			const uint32_t inc = wave_iscan(cnt);                             // hits of all lanes up to this one
+			const uint32_t total = rl(inc, WAVE - 1);
+			if (spos + total + 4u > (uint32_t)STAGE) flush(r0);
+			// record of quarter q: [count][entries of its 16 lanes]; the four records follow each other
+			const uint32_t pos = spos + (inc - cnt) + (uint32_t)quarter + 1u;   // this lane's first entry
+			const uint32_t b0 = 0u, b1 = rl(inc, 15), b2 = rl(inc, 31), b3 = rl(inc, 47);
+			if (lane16 == 0) {
+				const uint32_t qstart = quarter == 0 ? b0 : quarter == 1 ? b1 : quarter == 2 ? b2 : b3;
+				const uint32_t qend = quarter == 0 ? b1 : quarter == 1 ? b2 : quarter == 2 ? b3 : total;
+				stage[spos + qstart + (uint32_t)quarter] = qend - qstart;
+			}
+			const uint32_t kmax = steps;   // (no lane has more entries than there were steps)
+			for (uint32_t k = 0; k < kmax; k++) {
+				if (k < cnt) stage[pos + k] = lists[k * WAVE + lane];
+			}
+			// where the records of the round's queries start in the block (lane = query index)
+			{
+				const uint32_t st[4] = { spos + b0, spos + b1 + 1u, spos + b2 + 2u, spos + b3 + 3u };
+				#pragma unroll
+				for (int q = 0; q < 4; q++) if ((uint32_t)lane == r0 + (uint32_t)q) v_pos = st[q];
+			}
+			const uint32_t nlive = nqw - r0 < 4u ? nqw - r0 : 4u;
+			spos += total + 4u;
+			if (nlive < 4u) {   // (dead quarters wrote a count word of 0 behind the live records: drop them)
+				spos -= 4u - nlive;
+			}
+		}
+		flush(nqw);
+		if (lane == 0 && hits) atomicAdd(a.stats, (unsigned long long)hits);
+	}
+}
+
+template <int ARR, int ARITH>
+__global__ void __launch_bounds__(THREADS) k_fine_query(const FArgs a)
+{
+	__shared__ __attribute__((aligned(16))) unsigned char lds_raw[sizeof(Lds<ARR>)];
+	Lds<ARR>& L = *reinterpret_cast<Lds<ARR>*>(lds_raw);
+	const int lane = lane_id(), w = (int)threadIdx.x / WAVE;
+	Pool ps = { 0ull, 0u, 0u };
+	for (;;) {
+		if (threadIdx.x == 0) L.tile_id = atomicAdd(a.ticket, 1u);
+		__syncthreads();
+		const uint32_t t = rfl(L.tile_id);
+		if (t >= a.n_tiles) break;
+		const int tx = (int)(t % a.ntx), fy = (int)((t / a.ntx) % (uint32_t)a.g.ny), fz = (int)(t / (a.ntx * (uint32_t)a.g.ny));
+		const int x0 = tx * TX;
+		// (a tile without queries costs one look-up)
+		const uint32_t rowkey = ((uint32_t)fz * a.g.ny + fy) * a.g.nx;
+		const uint32_t nq = rfl(a.fstart[rowkey + (uint32_t)(x0 + TX < a.g.nx ? x0 + TX : a.g.nx)] - a.fstart[rowkey + x0]);
+		if (nq == 0u) { __syncthreads(); continue; }
+		if (!stage_tile(a, L, x0, fy, fz)) {
+			if (threadIdx.x == 0) atomicAdd(a.stats + 1, 1ull);
+			__syncthreads();
+			continue;
+		}
+		if constexpr (ARR == 0) wave_A<ARITH>(a, L, ps, lane, w); else wave_B<ARITH>(a, L, ps, lane, w);
+		__syncthreads();   // (the tile is overwritten by the next one)
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// reference: a thread per query, all points of its 125 fine cells from global memory -> count, sum and xor of the neighbour ids
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void k_reference(const float4* __restrict__ pts, const uint32_t* __restrict__ fstart, FGrid g, float r2, int n, uint32_t* __restrict__ cnt,
+                            unsigned long long* __restrict__ sum, uint32_t* __restrict__ xr)
+{
+	const int p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= n) return;
+	const float4 q = pts[p];
+	const int cx = fbin(q.x, g.ox, g.inv_hf, g.nx), cy = fbin(q.y, g.oy, g.inv_hf, g.ny), cz = fbin(q.z, g.oz, g.inv_hf, g.nz);
+	uint32_t c = 0, x = 0;
+	unsigned long long s = 0;
+	for (int z = cz - 2; z <= cz + 2; z++) for (int y = cy - 2; y <= cy + 2; y++) {
+		if (z < 0 || z >= g.nz || y < 0 || y >= g.ny) continue;
+		const int xl = cx - 2 < 0 ? 0 : cx - 2, xh = cx + 2 > g.nx - 1 ? g.nx - 1 : cx + 2;
+		const uint32_t rowkey = ((uint32_t)z * g.ny + y) * g.nx;
+		for (uint32_t j = fstart[rowkey + xl]; j < fstart[rowkey + xh + 1]; j++) {
+			if ((int)j == p) continue;
+			const float4 cnd = pts[j];
+			const float dx = q.x - cnd.x, dy = q.y - cnd.y, dz = q.z - cnd.z;
+			const float d2 = (dx * dx + dy * dy) + dz * dz;
+			if (d2 <= r2) { c++; s += __float_as_uint(cnd.w); x ^= __float_as_uint(cnd.w) * 2654435761u; }
+		}
+	}
+	const uint32_t id = __float_as_uint(q.w);
+	cnt[id] = c; sum[id] = s; xr[id] = x;
+}
+__global__ void k_check(const int* __restrict__ records, const uint64_t* __restrict__ offs, int n, const uint32_t* __restrict__ cnt,
+                        const unsigned long long* __restrict__ sum, const uint32_t* __restrict__ xr, unsigned long long* __restrict__ bad)
+{
+	const int id = blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= n) return;
+	const uint64_t o = offs[id];
+	bool ok = o != ~0ull;
+	if (ok) {
+		const int c = records[o];
+		ok = (uint32_t)c == cnt[id];
+		if (ok) {
+			unsigned long long s = 0; uint32_t x = 0;
+			for (int k = 0; k < c; k++) { const uint32_t j = (uint32_t)records[o + 1 + k]; s += j; x ^= j * 2654435761u; }
+			ok = s == sum[id] && x == xr[id];
+		}
+	}
+	if (!ok) atomicAdd(bad, 1ull);
+}
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static inline uint64_t splitmix() { uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+
+int main(int argc, char** argv)
+{
+	const int n = argc > 1 ? atoi(argv[1]) : 10000000;
+	const char* which = argc > 2 ? argv[2] : "AB";
+	const int reps = argc > 3 ? atoi(argv[3]) : 10;
+	const double nb = 59.25;
+	const float r = (float)cbrt(nb * 3.0 / (4.0 * M_PI * (double)n));
+	const float hf = 0.5f * r * 1.0002f;
+	FGrid g; g.ox = g.oy = g.oz = 0.0f; g.inv_hf = 1.0f / hf;
+	g.nx = g.ny = g.nz = (int)(1.0f / hf) + 1;
+	const size_t ncells = (size_t)g.nx * g.ny * g.nz;
+	printf("n = %d, r = %g, fine grid %d^3 = %zu cells (%.2f points per fine cell)\n", n, r, g.nx, ncells, (double)n / ncells);
+	// ---- points, fine-cell sort on the host
+	std::vector<float> xyz((size_t)n * 3);
+	for (size_t i = 0; i < xyz.size(); i++) xyz[i] = (float)((splitmix() >> 40) * (1.0 / 16777216.0));
+	std::vector<uint32_t> key(n), fstart(ncells + 2, 0);
+	for (int i = 0; i < n; i++) {
+		const int cx = fbin(xyz[3 * (size_t)i], g.ox, g.inv_hf, g.nx), cy = fbin(xyz[3 * (size_t)i + 1], g.oy, g.inv_hf, g.ny), cz = fbin(xyz[3 * (size_t)i + 2], g.oz, g.inv_hf, g.nz);
+		key[i] = ((uint32_t)cz * g.ny + cy) * g.nx + cx;
+		fstart[key[i] + 1]++;
+	}
+	for (size_t c = 0; c < ncells; c++) fstart[c + 1] += fstart[c];
+	fstart[ncells + 1] = fstart[ncells];
+	std::vector<float4> sorted(n);
+	{
+		std::vector<uint32_t> cur(fstart.begin(), fstart.begin() + ncells);
+		for (int i = 0; i < n; i++) { const uint32_t p = cur[key[i]]++; float wf; const uint32_t wi = (uint32_t)i; memcpy(&wf, &wi, 4); sorted[p] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], wf); }
+	}
+	float4* d_pts; uint32_t* d_fstart;
+	CK(hipMalloc(&d_pts, sizeof(float4) * (size_t)n)); CK(hipMalloc(&d_fstart, sizeof(uint32_t) * fstart.size()));
+	CK(hipMemcpy(d_pts, sorted.data(), sizeof(float4) * (size_t)n, hipMemcpyHostToDevice));
+	CK(hipMemcpy(d_fstart, fstart.data(), sizeof(uint32_t) * fstart.size(), hipMemcpyHostToDevice));
+	// ---- reference
+	uint32_t *d_cnt, *d_xr; unsigned long long* d_sum;
+	CK(hipMalloc(&d_cnt, 4 * (size_t)n)); CK(hipMalloc(&d_xr, 4 * (size_t)n)); CK(hipMalloc(&d_sum, 8 * (size_t)n));
+	hipLaunchKernelGGL(k_reference, dim3((n + 255) / 256), dim3(256), 0, 0, d_pts, d_fstart, g, r * r, n, d_cnt, d_sum, d_xr);
+	CK(hipDeviceSynchronize());
+	std::vector<uint32_t> h_cnt(n);
+	CK(hipMemcpy(h_cnt.data(), d_cnt, 4 * (size_t)n, hipMemcpyDeviceToHost));
+	unsigned long long ref_total = 0;
+	for (int i = 0; i < n; i++) ref_total += h_cnt[i];
+	printf("reference: %llu neighbours (%.2f per point)\n", ref_total, (double)ref_total / n);
+	// ---- pool
+	const unsigned long long pool_ints = ref_total + (unsigned long long)n + (unsigned long long)SLAB * 4096ull * 2ull + (ref_total >> 3);
+	const unsigned long long region_cap = (pool_ints / NREG + 1024) & ~255ull;
+	int* d_rec; uint64_t* d_offs; unsigned long long *d_cursors, *d_stats, *d_bad; uint32_t* d_ticket;
+	CK(hipMalloc(&d_rec, 4 * region_cap * NREG)); CK(hipMalloc(&d_offs, 8 * (size_t)n));
+	CK(hipMalloc(&d_cursors, 8 * 16 * NREG)); CK(hipMalloc(&d_stats, 8 * 8)); CK(hipMalloc(&d_bad, 8)); CK(hipMalloc(&d_ticket, 4));
+	FArgs a;
+	a.pts = d_pts; a.fstart = d_fstart; a.g = g; a.r2 = r * r; a.records = d_rec; a.offs = d_offs; a.cursors = d_cursors; a.region_cap = region_cap;
+	a.ntx = (uint32_t)((g.nx + TX - 1) / TX); a.n_tiles = a.ntx * (uint32_t)g.ny * (uint32_t)g.nz; a.ticket = d_ticket; a.stats = d_stats;
+	hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+	int per_cu = 0;
+	printf("LDS per workgroup: A %zu bytes, B %zu bytes; tiles %u\n", sizeof(Lds<0>), sizeof(Lds<1>), a.n_tiles);
+	for (const char* wc = which; *wc; wc++) {
+		const int arr = *wc == 'B' ? 1 : 0;
+		const void* fn = arr ? (const void*)k_fine_query<1, 0> : (const void*)k_fine_query<0, 0>;
+		CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, THREADS, 0));
+		const int blocks = prop.multiProcessorCount * (per_cu > 0 ? per_cu : 1);
+		hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+		float best = 1e30f, sum_ms = 0;
+		for (int it = 0; it < reps + 2; it++) {
+			CK(hipMemsetAsync(d_cursors, 0, 8 * 16 * NREG, 0)); CK(hipMemsetAsync(d_stats, 0, 64, 0)); CK(hipMemsetAsync(d_ticket, 0, 4, 0));
+			if (it == 0) CK(hipMemsetAsync(d_offs, 0xff, 8 * (size_t)n, 0));
+			CK(hipEventRecord(e0, 0));
+			if (arr) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fine_query<1, 0>), dim3(blocks), dim3(THREADS), 0, 0, a);
+			else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fine_query<0, 0>), dim3(blocks), dim3(THREADS), 0, 0, a);
+			CK(hipEventRecord(e1, 0));
+			CK(hipEventSynchronize(e1));
+			float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+			if (it >= 2) { best = ms < best ? ms : best; sum_ms += ms; }
+		}
+		unsigned long long st[8];
+		CK(hipMemcpy(st, d_stats, 64, hipMemcpyDeviceToHost));
+		CK(hipMemset(d_bad, 0, 8));
+		hipLaunchKernelGGL(k_check, dim3((n + 255) / 256), dim3(256), 0, 0, d_rec, d_offs, n, d_cnt, d_sum, d_xr, d_bad);
+		unsigned long long bad; CK(hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost));
+		printf("arrangement %c: %d workgroups/CU, %.3f ms mean, %.3f ms best over %d launches; hits %llu (%s), tiles that did not fit %llu, pool failures %llu, rounds cut short %llu, points with wrong lists %llu\n",
+		       arr ? 'B' : 'A', per_cu, sum_ms / reps, best, reps, st[0], st[0] == ref_total ? "== reference" : "DIFFERENT", st[1], st[2], st[3], bad);
+	}
+	return 0;
+}

@@ -82,6 +82,7 @@ ABI_SYMBOLS = [
     "tnsx_slab_transport_local", "tnsx_slab_transport_release", "tnsx_slab_balanced_cuts", "tnsx_slab_create", "tnsx_slab_destroy",
     "tnsx_slab_last_error", "tnsx_slab_set_active_search", "tnsx_slab_step", "tnsx_slab_engine_set", "tnsx_slab_get_info",
     "tnsx_slab_debug_set_capacity", "tnsx_slab_set_watchdog", "tnsx_slab_redistribute_begin", "tnsx_slab_redistribute_finish",
+    "tnsx_slab_set_collect_times", "tnsx_slab_transport_check",
 ]
 
 
@@ -97,7 +98,7 @@ class SlabOp(C.Structure):
 
 class SlabInfo(C.Structure):
     _fields_ = [("n_owned", C.c_int), ("n_ghost", C.c_int), ("speculative_last", C.c_int), ("redone_last", C.c_int), ("rounds_last", C.c_int),
-                ("bytes_sent", C.c_ulonglong)]
+                ("bytes_sent", C.c_ulonglong), ("transport_kind", C.c_int), ("transport_ranks", C.c_int), ("exchange_ms_last", C.c_float)]
 
 _lib = None
 
@@ -182,6 +183,8 @@ def load_library():
     L.tnsx_slab_get_info.argtypes = [vp, C.POINTER(SlabInfo)]
     L.tnsx_slab_debug_set_capacity.argtypes = [vp, ci, C.c_uint]
     L.tnsx_slab_set_watchdog.argtypes = [vp, C.c_double]
+    L.tnsx_slab_set_collect_times.argtypes = [vp, ci]
+    L.tnsx_slab_transport_check.argtypes = [vp, tp, ci, ci, C.POINTER(ci)]
     L.tnsx_slab_redistribute_begin.argtypes = [vp, tp, ci, ci, C.POINTER(C.c_float), vp, vp, vp, ci, C.POINTER(vp), C.POINTER(ci)]
     L.tnsx_slab_redistribute_finish.argtypes = [vp, vp, vp, vp]
     _lib = L

@@ -50,6 +50,7 @@ struct RcclApi {
 	ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
 	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
 	ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;   // optional
+	ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;   // optional
 	ncclResult_t (*GroupStart)() = nullptr;
 	ncclResult_t (*GroupEnd)() = nullptr;
 	ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -71,6 +72,7 @@ struct RcclApi {
 		TNSX_SYM(AllReduce, "ncclAllReduce") TNSX_SYM(GetErrorString, "ncclGetErrorString")
 #undef TNSX_SYM
 		CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(lib, "ncclCommAbort"));
+		CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));
 		return true;
 	}
 };
@@ -278,6 +280,9 @@ struct tnsx_slab {
 	tnsx_slab_info info{};
 	std::string last_error;
 	double watchdog_s = 120.0;    // bound of every wait on the stream (tnsx_slab_set_watchdog)
+	bool collect_times = false;   // tnsx_slab_set_collect_times: an event pair around every exchange round, read at the end of the step
+	hipEvent_t ev[2][3] = { { nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr } };   // [begin | end][round of the step]
+	int ev_rounds = 0;
 };
 
 namespace {
@@ -417,7 +422,27 @@ int do_exchange(tnsx_slab* s, const std::vector<tnsx_slab_op>& ops)
 	if (ops.empty() || !s->tr.exchange) return 0;
 	s->info.rounds_last++;
 	for (const tnsx_slab_op& o : ops) s->info.bytes_sent += o.send_bytes;
-	return s->tr.exchange(s->tr.user, s->rank, s->world, ops.data(), (int)ops.size(), s->stream);
+	// (stage pass of a benchmark: how long the messages of this round occupy the stream -- a step has at most three rounds)
+	const int slot = s->collect_times && s->ev_rounds < 3 ? s->ev_rounds : -1;
+	if (slot >= 0) {
+		for (int b = 0; b < 2; b++) if (!s->ev[b][slot] && hipEventCreate(&s->ev[b][slot]) != hipSuccess) return 1;
+		if (hipEventRecord(s->ev[0][slot], s->stream) != hipSuccess) return 1;
+	}
+	const int rc = s->tr.exchange(s->tr.user, s->rank, s->world, ops.data(), (int)ops.size(), s->stream);
+	if (slot >= 0 && rc == 0) { if (hipEventRecord(s->ev[1][slot], s->stream) != hipSuccess) return 1; s->ev_rounds++; }
+	return rc;
+}
+// what kind of transport a table of functions is, and how many ranks it spans as far as the library can tell
+void describe_transport(const tnsx_slab_transport& tr, int world, tnsx_slab_info& info)
+{
+	info.transport_kind = !tr.exchange ? 0 : (tr.exchange == rccl_exchange ? 1 : (tr.exchange == local_exchange ? 2 : 3));
+	info.transport_ranks = info.transport_kind == 0 ? 1 : -1;
+	if (info.transport_kind == 1) {
+		RcclTransport* t = static_cast<RcclTransport*>(tr.user);
+		int n = -1;
+		if (t && t->comm && g_rccl.CommCount && g_rccl.CommCount(t->comm, &n) == ncclSuccess) info.transport_ranks = n;
+	}
+	else if (info.transport_kind == 2) info.transport_ranks = world;
 }
 
 }  // namespace
@@ -582,6 +607,7 @@ tnsx_status tnsx_slab_create(tnsx_context* engine, const tnsx_slab_transport* tr
 	s->device = tnsx_internal_device(engine);
 	if (!s->stream) { delete s; return TNSX_ERR_STATE; }   // (a multi-device context shards host data itself: tnsx_options.n_devices)
 	if (!s->variable && tnsx_set_search_radius(engine, radius) != TNSX_OK) { delete s; return TNSX_ERR_CONFIG; }
+	describe_transport(s->tr, world, s->info);
 	*out = s;
 	return TNSX_OK;
 }
@@ -599,6 +625,7 @@ void tnsx_slab_destroy(tnsx_slab* s)
 		(void)tnsx_resize_point_set(s->engine, st.set_id, nullptr, nullptr, 0, TNSX_F32 | TNSX_DEVICE | (s->variable ? TNSX_VARIABLE : 0u));
 	}
 	if (s->h_small) (void)hipHostFree(s->h_small);
+	for (int b = 0; b < 2; b++) for (int k = 0; k < 3; k++) if (s->ev[b][k]) (void)hipEventDestroy(s->ev[b][k]);
 	delete s;
 }
 
@@ -640,6 +667,8 @@ tnsx_status tnsx_slab_step(tnsx_slab* s, int n_sets, const float* const* xyz, co
 	const bool side_on[2] = { has_side(s, 0), has_side(s, 1) };
 	s->info.rounds_last = 0;
 	s->info.redone_last = 0;
+	s->ev_rounds = 0;
+	s->info.exchange_ms_last = 0.0f;
 	SHIP(s, hipMemsetAsync(s->d_small.p, 0, (size_t)n_sets * 8 * 4, s->stream));
 	bool spec = s->speculative && (side_on[0] || side_on[1]);
 	for (int k = 0; k < n_sets && spec; k++) for (int side = 0; side < 2; side++) if (side_on[side] && !s->sets[(size_t)k].caps_known[side]) spec = false;
@@ -771,7 +800,40 @@ tnsx_status tnsx_slab_step(tnsx_slab* s, int n_sets, const float* const* xyz, co
 		if (small_host(s, (size_t)k)[5]) return sfail(s, TNSX_ERR_LIST_TOO_LONG, "a global id does not fit the 32-bit neighbour indices of the reference's list layout");
 	}
 	s->info.n_owned = s->sets[0].n_owned; s->info.n_ghost = s->sets[0].n_ghost;
+	// (every path above ends with a wait for the stream: the events of this step's exchange rounds have completed)
+	for (int k = 0; k < s->ev_rounds; k++) {
+		float ms = 0.0f;
+		if (hipEventElapsedTime(&ms, s->ev[0][k], s->ev[1][k]) == hipSuccess) s->info.exchange_ms_last += ms;
+	}
 	return TNSX_OK;
+}
+
+tnsx_status tnsx_slab_set_collect_times(tnsx_slab* s, int on)
+{
+	if (!s) return TNSX_ERR_INVALID;
+	s->collect_times = on != 0;
+	return TNSX_OK;
+}
+
+tnsx_status tnsx_slab_transport_check(tnsx_context* engine, const tnsx_slab_transport* transport, int rank, int world, int* ranks_seen)
+{
+	if (!engine || !ranks_seen || world < 1 || rank < 0 || rank >= world) return TNSX_ERR_INVALID;
+	*ranks_seen = 1;
+	if (!transport || !transport->allreduce) return world == 1 ? TNSX_OK : TNSX_ERR_INVALID;
+	hipStream_t st = static_cast<hipStream_t>(tnsx_internal_stream(engine));
+	if (!st) return TNSX_ERR_STATE;
+	if (hipSetDevice(tnsx_internal_device(engine)) != hipSuccess) return TNSX_ERR_HIP;
+	uint32_t* d = nullptr;
+	if (hipMalloc(&d, sizeof(uint32_t)) != hipSuccess) return TNSX_ERR_HIP;
+	const uint32_t one = 1u;
+	uint32_t sum = 0u;
+	tnsx_status rc = TNSX_OK;
+	if (hipMemcpyAsync(d, &one, sizeof one, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = TNSX_ERR_HIP;
+	if (rc == TNSX_OK && transport->allreduce(transport->user, rank, world, d, 1, TNSX_SLAB_SUM_U32, st) != 0) rc = TNSX_ERR_HIP;
+	if (rc == TNSX_OK && (wait_stream(st, 60.0) != 0 || hipMemcpy(&sum, d, sizeof sum, hipMemcpyDeviceToHost) != hipSuccess)) rc = TNSX_ERR_TIMEOUT;
+	(void)hipFree(d);
+	if (rc == TNSX_OK) *ranks_seen = (int)sum;
+	return rc;
 }
 
 tnsx_status tnsx_slab_set_watchdog(tnsx_slab* s, double seconds)

@@ -785,6 +785,16 @@ def redistribute_c(engine, transport: Optional["SlabTransportC"], rank: int, wor
     return (o_pts, o_gid) if radii is None else (o_pts, o_gid, o_rad)
 
 
+def transport_check_c(engine, transport: Optional["SlabTransportC"], rank: int, world: int) -> int:
+    """tnsx_slab_transport_check: all-reduces the number 1 over the transport's ranks (collective) -> how many ranks are on the other end."""
+    import ctypes as C
+    seen = C.c_int(0)
+    st = engine._L.tnsx_slab_transport_check(engine._h, C.byref(transport.t) if transport is not None else None, int(rank), int(world), C.byref(seen))
+    if st != 0:
+        raise RuntimeError(f"tnsx_slab_transport_check failed with status {st}")
+    return int(seen.value)
+
+
 class SlabSearchC:
     """SlabSearch on the C entry points (tnsx_slab_create / tnsx_slab_step).  Same calling convention as SlabSearch:
     step(pts, gids[, radii]) or step((pts, gids[, radii]), ...); the lists are read from `engine` with the set ids of `set_id(k)`."""
@@ -827,6 +837,10 @@ class SlabSearchC:
 
     def set_active_search(self, i: int, j: int, active: bool = True) -> None:
         self._check(self._L.tnsx_slab_set_active_search(self._h, int(i), int(j), int(bool(active))))
+
+    def set_collect_times(self, on: bool) -> None:
+        """hipEvent pairs around the exchange rounds of every step from now on (info().exchange_ms_last); off in timed loops"""
+        self._check(self._L.tnsx_slab_set_collect_times(self._h, int(bool(on))))
 
     def _check(self, st):
         if st != 0:
