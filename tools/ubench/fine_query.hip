@@ -328,7 +328,7 @@ __device__ __forceinline__ void cell_A(const FArgs& a, Lds<0>& L, Pool& ps, Wave
 }
 
 template <int ARITH>
-__device__ __forceinline__ void wave_A(const FArgs& a, Lds<0>& L, Pool& ps, int lane, int w)
+__device__ __forceinline__ void wave_A(const FArgs& a, Lds<0>& L, Pool& ps, uint32_t& wave_hits, int lane, int w)
 {
 	// the wave's queries: cells [CPW * w, CPW * w + CPW) of the tile = consecutive sorted points; query index = lane (at most 64 per pass)
 	const uint32_t qb = rfl(L.qs[CPW * w]), qe = rfl(L.qs[CPW * w + CPW]);
@@ -363,7 +363,7 @@ __device__ __forceinline__ void wave_A(const FArgs& a, Lds<0>& L, Pool& ps, int 
 			}
 		}
 		flush_queries(a, ps, o, L.stage[w], nqw, qid, lane);
-		if (lane == 0 && o.hits) atomicAdd(a.stats, (unsigned long long)o.hits);
+		wave_hits += o.hits;
 	}
 }
 
@@ -371,7 +371,7 @@ __device__ __forceinline__ void wave_A(const FArgs& a, Lds<0>& L, Pool& ps, int 
 // arrangement B: a query per quarter wave
 // ---------------------------------------------------------------------------------------------------------------------
 template <int ARITH>
-__device__ __forceinline__ void wave_B(const FArgs& a, Lds<1>& L, Pool& ps, int lane, int w)
+__device__ __forceinline__ void wave_B(const FArgs& a, Lds<1>& L, Pool& ps, uint32_t& wave_hits, int lane, int w)
 {
 	const uint32_t qb = rfl(L.qs[CPW * w]), qe = rfl(L.qs[CPW * w + CPW]);
 	uint32_t* const stage = L.stage[w];
@@ -455,36 +455,41 @@ __device__ __forceinline__ void wave_B(const FArgs& a, Lds<1>& L, Pool& ps, int 
 			}
 		}
 		flush(nqw);
-		if (lane == 0 && hits) atomicAdd(a.stats, (unsigned long long)hits);
+		wave_hits += hits;
 	}
 }
 
 template <int ARR, int ARITH>
 __global__ void __launch_bounds__(THREADS) k_fine_query(const FArgs a)
 {
-	__shared__ __attribute__((aligned(16))) unsigned char lds_raw[sizeof(Lds<ARR>)];
-	Lds<ARR>& L = *reinterpret_cast<Lds<ARR>*>(lds_raw);
+	constexpr int LA = ARR == 1 ? 1 : 0;   // (the staging-only variant has arrangement A's LDS footprint)
+	__shared__ __attribute__((aligned(16))) unsigned char lds_raw[sizeof(Lds<LA>)];
+	Lds<LA>& L = *reinterpret_cast<Lds<LA>*>(lds_raw);
 	const int lane = lane_id(), w = (int)threadIdx.x / WAVE;
 	Pool ps = { 0ull, 0u, 0u };
-	for (;;) {
-		if (threadIdx.x == 0) L.tile_id = atomicAdd(a.ticket, 1u);
-		__syncthreads();
-		const uint32_t t = rfl(L.tile_id);
-		if (t >= a.n_tiles) break;
+	uint32_t wave_hits = 0;
+	// every workgroup walks its own contiguous range of tiles (x fastest, then y: consecutive tiles share four of their five candidate rows in y, which
+	// stay in the L2 of the workgroup's XCD).  No ticket: one atomic per tile on one word is ~88 tiles per microsecond for the whole chip.
+	const uint32_t per = (a.n_tiles + gridDim.x - 1) / gridDim.x;
+	const uint32_t t_begin = blockIdx.x * per, t_end = t_begin + per < a.n_tiles ? t_begin + per : a.n_tiles;
+	for (uint32_t t = t_begin; t < t_end; t++) {
 		const int tx = (int)(t % a.ntx), fy = (int)((t / a.ntx) % (uint32_t)a.g.ny), fz = (int)(t / (a.ntx * (uint32_t)a.g.ny));
 		const int x0 = tx * TX;
 		// (a tile without queries costs one look-up)
 		const uint32_t rowkey = ((uint32_t)fz * a.g.ny + fy) * a.g.nx;
 		const uint32_t nq = rfl(a.fstart[rowkey + (uint32_t)(x0 + TX < a.g.nx ? x0 + TX : a.g.nx)] - a.fstart[rowkey + x0]);
-		if (nq == 0u) { __syncthreads(); continue; }
+		if (nq == 0u) continue;
 		if (!stage_tile(a, L, x0, fy, fz)) {
 			if (threadIdx.x == 0) atomicAdd(a.stats + 1, 1ull);
 			__syncthreads();
 			continue;
 		}
-		if constexpr (ARR == 0) wave_A<ARITH>(a, L, ps, lane, w); else wave_B<ARITH>(a, L, ps, lane, w);
+		if constexpr (ARR == 0) wave_A<ARITH>(a, L, ps, wave_hits, lane, w);
+		else if constexpr (ARR == 1) wave_B<ARITH>(a, L, ps, wave_hits, lane, w);
+		else { if (L.tile[threadIdx.x].x == 12345.0f) wave_hits++; }   // (ARR == 2: the staging alone)
 		__syncthreads();   // (the tile is overwritten by the next one)
 	}
+	if (lane == 0 && wave_hits) atomicAdd(a.stats, (unsigned long long)wave_hits);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -579,7 +584,7 @@ int main(int argc, char** argv)
 	for (int i = 0; i < n; i++) ref_total += h_cnt[i];
 	printf("reference: %llu neighbours (%.2f per point)\n", ref_total, (double)ref_total / n);
 	// ---- pool
-	const unsigned long long pool_ints = ref_total + (unsigned long long)n + (unsigned long long)SLAB * 4096ull * 2ull + (ref_total >> 3);
+	const unsigned long long pool_ints = ref_total + (unsigned long long)n + (unsigned long long)SLAB * 4096ull * 4ull + (ref_total >> 2);
 	const unsigned long long region_cap = (pool_ints / NREG + 1024) & ~255ull;
 	int* d_rec; uint64_t* d_offs; unsigned long long *d_cursors, *d_stats, *d_bad; uint32_t* d_ticket;
 	CK(hipMalloc(&d_rec, 4 * region_cap * NREG)); CK(hipMalloc(&d_offs, 8 * (size_t)n));
@@ -591,8 +596,8 @@ int main(int argc, char** argv)
 	int per_cu = 0;
 	printf("LDS per workgroup: A %zu bytes, B %zu bytes; tiles %u\n", sizeof(Lds<0>), sizeof(Lds<1>), a.n_tiles);
 	for (const char* wc = which; *wc; wc++) {
-		const int arr = *wc == 'B' ? 1 : 0;
-		const void* fn = arr ? (const void*)k_fine_query<1, 0> : (const void*)k_fine_query<0, 0>;
+		const int arr = *wc == 'B' ? 1 : (*wc == 'S' ? 2 : 0);
+		const void* fn = arr == 1 ? (const void*)k_fine_query<1, 0> : (arr == 2 ? (const void*)k_fine_query<2, 0> : (const void*)k_fine_query<0, 0>);
 		CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, THREADS, 0));
 		const int blocks = prop.multiProcessorCount * (per_cu > 0 ? per_cu : 1);
 		hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -601,7 +606,8 @@ int main(int argc, char** argv)
 			CK(hipMemsetAsync(d_cursors, 0, 8 * 16 * NREG, 0)); CK(hipMemsetAsync(d_stats, 0, 64, 0)); CK(hipMemsetAsync(d_ticket, 0, 4, 0));
 			if (it == 0) CK(hipMemsetAsync(d_offs, 0xff, 8 * (size_t)n, 0));
 			CK(hipEventRecord(e0, 0));
-			if (arr) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fine_query<1, 0>), dim3(blocks), dim3(THREADS), 0, 0, a);
+			if (arr == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fine_query<1, 0>), dim3(blocks), dim3(THREADS), 0, 0, a);
+			else if (arr == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fine_query<2, 0>), dim3(blocks), dim3(THREADS), 0, 0, a);
 			else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fine_query<0, 0>), dim3(blocks), dim3(THREADS), 0, 0, a);
 			CK(hipEventRecord(e1, 0));
 			CK(hipEventSynchronize(e1));
@@ -613,8 +619,9 @@ int main(int argc, char** argv)
 		CK(hipMemset(d_bad, 0, 8));
 		hipLaunchKernelGGL(k_check, dim3((n + 255) / 256), dim3(256), 0, 0, d_rec, d_offs, n, d_cnt, d_sum, d_xr, d_bad);
 		unsigned long long bad; CK(hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost));
+		if (arr == 2) { printf("staging only: %d workgroups/CU, %.3f ms mean, %.3f ms best over %d launches\n", per_cu, sum_ms / reps, best, reps); continue; }
 		printf("arrangement %c: %d workgroups/CU, %.3f ms mean, %.3f ms best over %d launches; hits %llu (%s), tiles that did not fit %llu, pool failures %llu, rounds cut short %llu, points with wrong lists %llu\n",
-		       arr ? 'B' : 'A', per_cu, sum_ms / reps, best, reps, st[0], st[0] == ref_total ? "== reference" : "DIFFERENT", st[1], st[2], st[3], bad);
+		       arr == 1 ? 'B' : (arr == 2 ? 'S' : 'A'), per_cu, sum_ms / reps, best, reps, st[0], st[0] == ref_total ? "== reference" : "DIFFERENT", st[1], st[2], st[3], bad);
 	}
 	return 0;
 }
