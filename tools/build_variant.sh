@@ -11,5 +11,5 @@ for f in tnsx_query.hip tnsx_build.hip tnsx_engine.cpp; do
   /opt/rocm/bin/hipcc $FL "$@" -c treensearch_amd/csrc/$f -o ab_libs/obj_$name/${f%.*}.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab_libs/libtnsx_$name.so ab_libs/obj_$name/tnsx_query.o ab_libs/obj_$name/tnsx_build.o ab_libs/obj_$name/tnsx_engine.o treensearch_amd/lib/tnsx_kernels.o treensearch_amd/lib/tnsx_query_group.o treensearch_amd/lib/tnsx_multi.o treensearch_amd/lib/tnsx_slab.o -ldl -lpthread
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab_libs/libtnsx_$name.so ab_libs/obj_$name/tnsx_query.o ab_libs/obj_$name/tnsx_build.o ab_libs/obj_$name/tnsx_engine.o treensearch_amd/lib/tnsx_kernels.o treensearch_amd/lib/tnsx_multi.o treensearch_amd/lib/tnsx_slab.o -ldl -lpthread
 echo built ab_libs/libtnsx_$name.so

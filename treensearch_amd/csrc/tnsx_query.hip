@@ -42,6 +42,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef TNSX_FAT_CULL
 #define TNSX_FAT_CULL 1   // the second tier repeats the cull (its cells are those of which > 512 candidates survive) and loops over the survivors only
 #endif
+#ifndef TNSX_LANE_OPAQUE
+#define TNSX_LANE_OPAQUE 1   // round 5: lane-derived constants of the cell bodies are recomputed per cell instead of living in (and spilling from) a dozen VGPRs
+#endif
 #ifndef TNSX_CULL
 #define TNSX_CULL 1   // first tier: cells with 513..1024 candidates are culled against the bounding box of their query points (fast_cell_culled)
 #endif
@@ -214,6 +217,23 @@ __device__ __forceinline__ void lookup_cell(const QueryArgs& a, uint32_t key, bo
 		s = r.x; e = r.y;
 		return;
 	}
+	const uint2 r = a.table_j[idx];
+	s = use ? r.x : 0u;
+	e = use ? r.y : 0u;
+}
+// The same for the fast kernels, with the lane's three offsets packed into one register (dx | dy << 2 | dz << 4, each 0..2; lanes >= 27: 63): the compiler keeps
+// lane % 3, lane / 3 % 3 and lane / 9 of the version above in three VGPRs for the life of the kernel, and at five waves per SIMD that is what spills in the
+// instantiations with per-point radii (round 5).  The caller makes `pack` opaque per cell, so that it is unpacked (three v_bfe) where it is used.
+__device__ __forceinline__ uint32_t neighbour_pack(int lane) { return lane < 27 ? (uint32_t)(lane % 3) | ((uint32_t)((lane / 3) % 3) << 2) | ((uint32_t)(lane / 9) << 4) : 63u; }
+__device__ __forceinline__ void lookup_cell_packed(const QueryArgs& a, uint32_t key, bool valid, uint32_t pack, uint32_t& s, uint32_t& e)
+{
+	const uint32_t nx = (uint32_t)a.g.nx, ny = (uint32_t)a.g.ny, nz = (uint32_t)a.g.nz;
+	const int cx = (int)(key % nx);
+	const int cy = (int)((key / nx) % ny);
+	const int cz = (int)(key / (nx * ny));
+	const int x = cx + (int)(pack & 3u) - 1, y = cy + (int)((pack >> 2) & 3u) - 1, z = cz + (int)(pack >> 4) - 1;   // (pack == 63: z = cz + 2, never used)
+	const bool use = valid && pack != 63u && x >= 0 && x < (int)nx && y >= 0 && y < (int)ny && z >= 0 && z < (int)nz;
+	const uint32_t idx = use ? ((uint32_t)z * ny + (uint32_t)y) * nx + (uint32_t)x : 0u;
 	const uint2 r = a.table_j[idx];
 	s = use ? r.x : 0u;
 	e = use ? r.y : 0u;
@@ -784,14 +804,17 @@ __device__ __forceinline__ uint32_t cull_round(const QueryArgs& a, const Runs R,
                                                uint32_t slot_cap)
 {
 	const uint32_t nc = (R.total - base + WAVE - 1) / WAVE;   // chunks of this round that hold candidates (the rest is skipped)
-	float4 craw[Q_MAXPAIRS * 2];
+	// (only the coordinates: the cull never looks at a candidate's index, and the eight registers a dwordx4 load would keep for it are what spilled around
+	//  this path in the instantiations with per-point radii)
+	struct Xyz { float x, y, z; };
+	Xyz craw[Q_MAXPAIRS * 2];
 	float r2raw[Q_MAXPAIRS * 2];
 	#pragma unroll
 	for (int k = 0; k < Q_MAXPAIRS * 2; k++) {
 		if ((uint32_t)k < nc) {
 			const uint32_t slot = base + (uint32_t)(k * WAVE + lane);
 			const uint32_t src = slot < R.total ? tbl[slot] : R.d0;
-			craw[k] = a.xyzi_j[src];
+			craw[k] = *reinterpret_cast<const Xyz*>(a.xyzi_j + src);
 			if (SYM) r2raw[k] = a.r2_j[src];
 		}
 	}
@@ -799,7 +822,7 @@ __device__ __forceinline__ uint32_t cull_round(const QueryArgs& a, const Runs R,
 	for (int k = 0; k < Q_MAXPAIRS * 2; k++) {
 		if ((uint32_t)k < nc) {
 			const uint32_t slot = base + (uint32_t)(k * WAVE + lane);
-			const float4 c = craw[k];
+			const Xyz c = craw[k];
 			const float bx = fmaxf(fmaxf(__fsub_rn(lox, c.x), __fsub_rn(c.x, hix)), 0.0f);
 			const float by = fmaxf(fmaxf(__fsub_rn(loy, c.y), __fsub_rn(c.y, hiy)), 0.0f);
 			const float bz = fmaxf(fmaxf(__fsub_rn(loz, c.z), __fsub_rn(c.z, hiz)), 0.0f);
@@ -961,12 +984,18 @@ __device__ __forceinline__ void fast_cell_nc(const QueryArgs& a, const RunRef RR
 #ifndef TNSX_FAST_WAVES_PER_EU
 #define TNSX_FAST_WAVES_PER_EU 5
 #endif
+
 #ifndef TNSX_FAT_WAVES_PER_EU
 #define TNSX_FAT_WAVES_PER_EU 3
 #endif
+// Round 5: no first-tier instantiation spills any more (tools/kernel_resources.py: scratch 0; the fixed-radius / self kernel of C2 went from 96 to 84 VGPRs) -- the
+// lane-derived constants of the cell bodies are recomputed per cell (TNSX_LANE_OPAQUE), the neighbour offsets of the look-ups are one packed register, the cull loads
+// coordinates only.  One instantiation is still a register short at five waves: per-point radii + symmetric + two different sets + contracted arithmetic (both sets'
+// pointers live in scalar registers, and what does not fit there sits in vector registers); it alone may drop to four waves (<= 128 VGPRs) instead of spilling.
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF, bool FAT>
 #if TNSX_FAST_WAVES_PER_EU > 0
-__attribute__((amdgpu_waves_per_eu(FAT ? TNSX_FAT_WAVES_PER_EU : TNSX_FAST_WAVES_PER_EU, FAT ? TNSX_FAT_WAVES_PER_EU : TNSX_FAST_WAVES_PER_EU)))
+__attribute__((amdgpu_waves_per_eu(FAT ? TNSX_FAT_WAVES_PER_EU : ((ARITH == 1 && VARIABLE && SYM && !SELF) ? TNSX_FAST_WAVES_PER_EU - 1 : TNSX_FAST_WAVES_PER_EU),
+                                   FAT ? TNSX_FAT_WAVES_PER_EU : TNSX_FAST_WAVES_PER_EU)))
 #endif
 __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a)
 {
@@ -1032,7 +1061,8 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 	uint2 oc_next = entry(first_next);
 	uint32_t key = readfirstlane_u32(oc.y), p0 = readfirstlane_u32(oc.x);
 	uint32_t s, e;
-	lookup_cell(a, key, true, lane, s, e);
+	const uint32_t nb_pack = neighbour_pack(lane);
+	lookup_cell_packed(a, key, true, nb_pack, s, e);
 	uint2 qrange = a.table_i[key];
 
 	for (;;) {
@@ -1058,19 +1088,40 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 		}
 		const uint2 cur_q = qrange;
 		// ---- lookups of the next cell: in flight while this one is processed
-		lookup_cell(a, key_next, have_next, lane, s, e);
+		{
+#if TNSX_LANE_OPAQUE
+			// (unpacked here, once per cell: see lookup_cell_packed.  The one instantiation that is still a register short at five waves -- per-point radii,
+			//  symmetric, two different sets -- does not even keep the packed word: it derives it from the lane number again, eight instructions per cell)
+			uint32_t pk;
+			if (VARIABLE && SYM && !SELF && !FAT) { int l2 = lane; asm volatile("" : "+v"(l2)); pk = neighbour_pack(l2); }
+			else { pk = nb_pack; asm volatile("" : "+v"(pk)); }
+#else
+			const uint32_t pk = nb_pack;
+#endif
+			lookup_cell_packed(a, key_next, have_next, pk, s, e);
+		}
 		qrange = a.table_i[have_next ? key_next : key];
 
 		const uint32_t nq = cur_q.y - cur_q.x;
 		bool pass_on = RR.total > 2u * (uint32_t)Q_SLOTS || nq > (uint32_t)WAVE;
 		bool fat_culled = false;
+#if TNSX_LANE_OPAQUE
+		// The cell bodies use slot numbers k * 64 + lane for a dozen values of k (the validity of a last chunk, the survivors of the cull).  Left alone the
+		// compiler computes all of them once, in front of this loop, and keeps them in a dozen VGPRs for the life of the kernel -- at the 96 registers of five
+		// waves per SIMD the rest then spills (48 bytes per lane with per-point radii, 16 .. 64 for pairs of two sets).  A lane number that is opaque per cell makes
+		// them what they are: one v_or_b32 where they are used.  (round 5; scratch 0 for every first-tier instantiation)
+		int lane_c = lane;
+		asm volatile("" : "+v"(lane_c));
+#else
+		const int lane_c = lane;
+#endif
 		if (!pass_on && !FAT && RR.total > (uint32_t)(VARIABLE ? TNSX_CULL_FROM_VARIABLE : TNSX_CULL_FROM)) {
 			// more candidates than the loop holds: cull them against the bounding box of the query points; the cell is done
 			// here if at most 512 survive
-			pass_on = !(TNSX_CULL && fast_cell_culled<ARITH, VARIABLE, SYM, SELF, false>(a, RR, lane, cur_q, ps, wave_hits, my_slots));
+			pass_on = !(TNSX_CULL && fast_cell_culled<ARITH, VARIABLE, SYM, SELF, false>(a, RR, lane_c, cur_q, ps, wave_hits, my_slots));
 		}
 		else if (!pass_on && FAT && TNSX_CULL && TNSX_FAT_CULL && RR.total > (uint32_t)Q_SLOTS) {
-			fat_culled = fast_cell_culled<ARITH, VARIABLE, SYM, SELF, true>(a, RR, lane, cur_q, ps, wave_hits, my_slots);
+			fat_culled = fast_cell_culled<ARITH, VARIABLE, SYM, SELF, true>(a, RR, lane_c, cur_q, ps, wave_hits, my_slots);
 		}
 		if (pass_on) {
 			// not for this tier: goes to the next tier's worklist.  Collected one entry per lane and appended 64 at a time: the
@@ -1086,17 +1137,17 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 		}
 		else if (RR.total == 0u) {
 			// no candidate at all (set_j is another, sparser or empty set): nq empty records, one int each
-			const uint32_t qs0 = cur_q.x + ((uint32_t)lane < nq ? (uint32_t)lane : 0u);
+			const uint32_t qs0 = cur_q.x + ((uint32_t)lane_c < nq ? (uint32_t)lane_c : 0u);
 			const uint32_t qi0 = a.orig_i ? a.orig_i[qs0] : __float_as_uint(a.xyzi_i[qs0].w);
-			const uint32_t nqv = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((uint32_t)lane < nq && qi0 < a.query_limit));   // (a prefix, see fast_query_loop)
+			const uint32_t nqv = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((uint32_t)lane_c < nq && qi0 < a.query_limit));   // (a prefix, see fast_query_loop)
 			bool okz;
-			const uint64_t off = pool_alloc<FAT>(a, ps, nqv, lane, okz);
-			if ((uint32_t)lane < nqv && okz) {
-				a.records[off + lane] = 0;
-				a.offs_by_orig[qi0] = off + lane;
+			const uint64_t off = pool_alloc<FAT>(a, ps, nqv, lane_c, okz);
+			if ((uint32_t)lane_c < nqv && okz) {
+				a.records[off + lane_c] = 0;
+				a.offs_by_orig[qi0] = off + lane_c;
 			}
 		}
-		else fast_cell_nc<ARITH, VARIABLE, SYM, SELF, FAT>(a, RR, lane, cur_q, ps, wave_hits);
+		else fast_cell_nc<ARITH, VARIABLE, SYM, SELF, FAT>(a, RR, lane_c, cur_q, ps, wave_hits);
 
 		if (!have_next) break;
 		key = key_next; p0 = p0_next;
