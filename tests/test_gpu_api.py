@@ -445,14 +445,16 @@ def test_zsort_resolution_follows_the_reference(oracle):
     assert np.float32(ns.get_stats()["zsort_cell_size_inv"]) == inv_fine
 
 
-@pytest.mark.parametrize("cells_per_axis", [128, 256, 512])
-def test_zsort_after_a_run_on_large_sets(cells_per_axis, oracle):
+@pytest.mark.parametrize("cells_per_axis,n", [(128, 220_000), (256, 220_000), (512, 220_000), (512, 3_000_000), (1024, 1_000_000)],
+                         ids=["128", "256", "512", "512-3m", "1024-1m"])
+def test_zsort_after_a_run_on_large_sets(cells_per_axis, n, oracle):
     """From 65 536 points on the cell-level order after a run() comes from the ranked pass on the high digit plus one workgroup per bucket (k_morton_place) for keys up to
-    24 bits, and from three LSD passes for 25 - 27 bits (a reference grid of 512 cells per axis).  A cloud with a dense blob (buckets beyond what a workgroup keeps in
-    registers) on each of the three grid sizes: a permutation, Morton-monotone on the reference's grid, and apply_zsort moves the points accordingly."""
+    24 bits, and -- round 5 -- from {key, index} pairs through single-pass digit sorts (decoupled look-back, tnsx_build.hip "Z-order of WIDE keys") for 25 - 30 bits (a
+    reference grid of 512 or 1024 cells per axis; 3 M points are 367 tiles whose totals travel through the look-back).  A cloud with a dense blob (buckets beyond what a
+    workgroup keeps in registers) on each grid size: a permutation, Morton-monotone on the reference's grid, stable where the path promises it, and apply_zsort moves the
+    points accordingly."""
     import treensearch_amd as T
     rng = np.random.default_rng(cells_per_axis)
-    n = 220_000
     pts = rng.random((n, 3), dtype=np.float32)
     pts[:70_000] = np.float32(0.5) + (rng.random((70_000, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(0.05)
     pts[0] = 0.0; pts[1] = 1.0                                  # (the box is the unit cube whatever the draw)
@@ -469,6 +471,12 @@ def test_zsort_after_a_run_on_large_sets(cells_per_axis, oracle):
     assert np.array_equal(np.sort(order), np.arange(n)), "the order must be a permutation"
     keys = oracle.zsort_keys(pts, np.array(st["world_bottom"], np.float32), inv)
     assert oracle.check_zsort(keys, order) == 0
+    if cells_per_axis >= 512:
+        # the wide-key path is a STABLE sort of the points by the Morton code of their cell: points of one cell keep their input order
+        ks = keys[order]
+        same = ks[1:] == ks[:-1]
+        assert bool(np.all(order[1:][same] > order[:-1][same])), "the single-pass digit sorts must be stable"
+        assert int(same.sum()) > n // 100, "the cloud has cells with several points (else the check above checks nothing)"
     import torch
     d_p = torch.from_numpy(pts.copy()).cuda()
     ns.apply_zsort(0, d_p, 3)

@@ -514,6 +514,247 @@ __global__ void __launch_bounds__(BP_THREADS) __attribute__((amdgpu_waves_per_eu
 		}
 	}
 }
+// =====================================================================================================
+// Z-order of WIDE keys (25 .. 30 bits: the cell-level order of a 50 M-point set, 512 cells per axis) -- round 5: {key, index} PAIRS through
+// SINGLE-PASS digit sorts ("onesweep": one upfront histogram read for all digits, decoupled look-back instead of a histogram pass + scan
+// kernels per digit).  Against the three point-moving LSD passes this path replaces (3 x (k_cs_hist + two scan kernels + k_cs_scatter) + k_extract_order,
+// 2.0 ms at 50 M points):
+//   * the z-order needs the ORDER, not the points: an element is 8 bytes {30-bit Morton key, original index}, not 16 -- and the key is computed once;
+//   * k_zs_keys reads the points ONCE, writes the pairs and counts every digit of every pass on the way (per-workgroup partial histograms in LDS,
+//     a small reduction kernel turns them into the global digit bases); no pass reads its input twice;
+//   * k_zs_pass sorts a tile of 8192 pairs by one digit: stable rank by ballot matching per wave (as k_cs_scatter), tile totals per digit published to a
+//     status word {flag, count}, the totals of the tiles before it collected by LOOK-BACK (tiles take their number from a ticket, so every tile a
+//     workgroup waits for is already running), the tile sorted in LDS and written out run by run: a digit's run of a tile is 16 pairs = 128 contiguous
+//     bytes on average -- full-line writes instead of the 50 M partial-line requests per pass that bound the scattered stores of the LSD passes;
+//   * the last pass writes the index column only: the order.
+// =====================================================================================================
+static constexpr int ZS_THREADS = 512, ZS_WAVES = ZS_THREADS / WAVE, ZS_ITEMS = 16, ZS_TILE = ZS_THREADS * ZS_ITEMS;
+static constexpr int ZS_MAX_PASSES = 4, ZS_MAX_BITS = 10;
+static constexpr int ZS_KEY_THREADS = 256, ZS_KEY_ITEMS = 16, ZS_KEY_TILE = ZS_KEY_THREADS * ZS_KEY_ITEMS, ZS_KEY_GRID = 1024;
+static constexpr uint32_t ZS_FLAG_AGG = 1u << 30, ZS_FLAG_INC = 2u << 30, ZS_VALUE = (1u << 30) - 1u;
+struct ZsPlan { int passes; int bits[ZS_MAX_PASSES]; int shift[ZS_MAX_PASSES]; };
+static ZsPlan zs_plan(int key_bits)
+{
+	ZsPlan p{};
+	p.passes = (key_bits + ZS_MAX_BITS - 1) / ZS_MAX_BITS;
+	int left = key_bits, sh = 0;
+	for (int i = 0; i < p.passes; i++) {
+		int b = (left + (p.passes - i) - 1) / (p.passes - i);
+		b = b < 8 ? 8 : b;
+		p.bits[i] = b; p.shift[i] = sh; sh += b; left -= b;
+	}
+	return p;
+}
+static int zs_key_grid(int n) { const int t = (n + ZS_KEY_TILE - 1) / ZS_KEY_TILE; return t < ZS_KEY_GRID ? (t < 1 ? 1 : t) : ZS_KEY_GRID; }
+static int zs_tiles(int n) { return (n + ZS_TILE - 1) / ZS_TILE; }
+// temp: [partial histograms: grid x passes x 2^ZS_MAX_BITS][digit bases: passes x 2^ZS_MAX_BITS][tickets: ZS_MAX_PASSES][status: passes x tiles x 2^bits]
+size_t zsort_temp_bytes(int n)
+{
+	const size_t R = (size_t)1 << ZS_MAX_BITS;
+	return ((size_t)ZS_KEY_GRID * ZS_MAX_PASSES * R + (size_t)ZS_MAX_PASSES * R + 64 + (size_t)ZS_MAX_PASSES * (size_t)zs_tiles(n > 0 ? n : 1) * R) * sizeof(uint32_t) + 256;
+}
+struct ZsPlanDev { int passes; int bits[ZS_MAX_PASSES]; int shift[ZS_MAX_PASSES]; };
+__global__ void __launch_bounds__(ZS_KEY_THREADS) k_zs_keys(const float* __restrict__ xyz, int n, GridParams g, ZsPlanDev plan, uint2* __restrict__ pairs, uint32_t* __restrict__ part)
+{
+	__shared__ uint32_t h[ZS_MAX_PASSES << ZS_MAX_BITS];
+	constexpr int R = 1 << ZS_MAX_BITS;
+	for (int k = threadIdx.x; k < plan.passes * R; k += ZS_KEY_THREADS) h[k] = 0u;
+	__syncthreads();
+	const int ntiles = (n + ZS_KEY_TILE - 1) / ZS_KEY_TILE;
+	for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+		const size_t base = (size_t)tile * ZS_KEY_TILE;
+		const uint32_t rem = (uint32_t)((size_t)n - base < (size_t)ZS_KEY_TILE ? (size_t)n - base : (size_t)ZS_KEY_TILE);
+		F3 q[ZS_KEY_ITEMS];
+		#pragma unroll
+		for (int i = 0; i < ZS_KEY_ITEMS; i++) {   // all loads up front, clamped
+			const uint32_t li = (uint32_t)i * ZS_KEY_THREADS + threadIdx.x;
+			q[i] = (reinterpret_cast<const F3*>(xyz) + base)[li < rem ? li : rem - 1u];
+		}
+		#pragma unroll
+		for (int i = 0; i < ZS_KEY_ITEMS; i++) {
+			const uint32_t li = (uint32_t)i * ZS_KEY_THREADS + threadIdx.x;
+			const uint32_t key = morton_low(q[i].x, q[i].y, q[i].z, g);   // (30 bits; a NaN x: all ones -- behind everything, like the full key)
+			if (li < rem) pairs[base + li] = make_uint2(key, (uint32_t)(base + li));
+			const uint64_t live = __ballot(li < rem);
+			if (live != 0ull) {
+				const int first = __builtin_ctzll(live);
+				for (int p = 0; p < plan.passes; p++) {
+					const uint32_t d = (key >> plan.shift[p]) & ((1u << plan.bits[p]) - 1u);
+					const uint32_t d0 = readlane_u32(d, first);
+					if (__ballot(li < rem && d == d0) == live) { if (lane_id() == first) atomicAdd(&h[p * R + d0], (uint32_t)__popcll(live)); }
+					else if (li < rem) atomicAdd(&h[p * R + d], 1u);
+				}
+			}
+		}
+	}
+	__syncthreads();
+	for (int k = threadIdx.x; k < plan.passes * R; k += ZS_KEY_THREADS) part[(size_t)blockIdx.x * (ZS_MAX_PASSES * R) + k] = h[k];
+}
+// digit totals of every pass: column sums of the partial histograms (the exclusive scan over the digit values is done by every tile of k_zs_pass itself: 512
+// values).  A workgroup owns 64 digit values of one pass, four threads share a column.
+__global__ void __launch_bounds__(256) k_zs_totals(const uint32_t* __restrict__ part, int n_part, uint32_t* __restrict__ totals)
+{
+	constexpr int R = 1 << ZS_MAX_BITS;
+	__shared__ uint32_t red[4][64];
+	const int p = blockIdx.y, d = blockIdx.x * 64 + (threadIdx.x & 63), kg = threadIdx.x >> 6;
+	uint32_t c = 0;
+	for (int k = kg; k < n_part; k += 4) c += part[(size_t)k * (ZS_MAX_PASSES * R) + p * R + d];
+	red[kg][threadIdx.x & 63] = c;
+	__syncthreads();
+	if (kg == 0) totals[p * R + d] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+template <int BITS, bool LAST>
+__global__ void __launch_bounds__(ZS_THREADS) k_zs_pass(const uint2* __restrict__ in, uint2* __restrict__ out, int* __restrict__ order_out, int n, int shift,
+                                                        const uint32_t* __restrict__ totals, uint32_t* __restrict__ status, uint32_t* __restrict__ ticket)
+{
+	constexpr int RADIX = 1 << BITS;
+	constexpr int PER = RADIX / ZS_THREADS > 0 ? RADIX / ZS_THREADS : 1;   // digit values per thread (1 or 2)
+	static_assert(RADIX <= 2 * ZS_THREADS, "at most two digit values per thread");
+	__shared__ uint16_t wcount[ZS_WAVES][RADIX];   // (16 bits: a tile has 8192 elements -- with 32-bit counters the 9-bit pass is 2 KB over what lets two workgroups share a CU)
+	__shared__ uint32_t gdelta[RADIX];
+	__shared__ uint2 stage[ZS_TILE];
+	__shared__ uint32_t wsum[2 * ZS_WAVES];
+	__shared__ uint32_t s_tile;
+	const int w = (int)readfirstlane_u32(threadIdx.x / WAVE), lane = lane_id();
+	if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+	for (int k = threadIdx.x; k < ZS_WAVES * RADIX; k += ZS_THREADS) (&wcount[0][0])[k] = 0;
+	__syncthreads();
+	const uint32_t tile = readfirstlane_u32(s_tile);
+	const size_t tbase = (size_t)tile * ZS_TILE;
+	const uint32_t trem = (uint32_t)((size_t)n - tbase < (size_t)ZS_TILE ? (size_t)n - tbase : (size_t)ZS_TILE);   // elements of this tile
+	// ---- this wave's ZS_ITEMS * 64 consecutive elements, all loads up front
+	const uint32_t woff = (uint32_t)w * (ZS_ITEMS * WAVE);
+	const uint32_t rem = trem > woff ? (trem - woff < (uint32_t)(ZS_ITEMS * WAVE) ? trem - woff : (uint32_t)(ZS_ITEMS * WAVE)) : 0u;
+	uint2 e[ZS_ITEMS];
+	#pragma unroll
+	for (int i = 0; i < ZS_ITEMS; i++) {
+		const uint32_t li = (uint32_t)(i * WAVE + lane);
+		e[i] = in[tbase + (rem ? woff + (li < rem ? li : rem - 1u) : 0u)];
+	}
+	// ---- stable rank inside the wave's sub-tile (rounds of 64 in index order; ballot matching of the digit's bits)
+	uint32_t dig_rank[ZS_ITEMS];
+	#pragma unroll
+	for (int i = 0; i < ZS_ITEMS; i++) {
+		const bool valid = (uint32_t)(i * WAVE + lane) < rem;
+		const uint32_t d = (e[i].x >> shift) & (uint32_t)(RADIX - 1);
+		uint64_t peers = __ballot(valid);
+		#pragma unroll
+		for (int b = 0; b < BITS; b++) {
+			const bool bit = (d >> b) & 1u;
+			const uint64_t m = __ballot(valid && bit);
+			peers &= bit ? m : ~m;
+		}
+		const uint32_t r = mbcnt64(peers);
+		const uint32_t cnt = (uint32_t)__popcll(peers);
+		uint32_t prev = 0;
+		if (valid) prev = wcount[w][d];
+		wave_lds_fence();
+		if (valid && r == 0) wcount[w][d] = (uint16_t)(prev + cnt);
+		wave_lds_fence();
+		dig_rank[i] = d | ((prev + r) << 16);
+	}
+	__syncthreads();
+	// ---- per digit value: the tile's count, its start inside the sorted tile, and -- by look-back -- the count of all tiles before this one
+	uint32_t cnt_d[PER], sum = 0;
+	#pragma unroll
+	for (int k = 0; k < PER; k++) {
+		const int d = (int)threadIdx.x * PER + k;
+		uint32_t c = 0;
+		if (d < RADIX) {
+			#pragma unroll
+			for (int ww = 0; ww < ZS_WAVES; ww++) c += wcount[ww][d];
+			// (published before anything else: the tiles behind this one are waiting for it)
+			__hip_atomic_store(status + (size_t)tile * RADIX + d, (tile == 0u ? ZS_FLAG_INC : ZS_FLAG_AGG) | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		cnt_d[k] = c; sum += c;
+	}
+	// (two scans over the digit values at once: the tile's counts -> where a digit starts inside the sorted tile; the set's totals -> where it starts in the output)
+	uint32_t tot_d[PER], gsum = 0;
+	#pragma unroll
+	for (int k = 0; k < PER; k++) { const int d = (int)threadIdx.x * PER + k; tot_d[k] = d < RADIX ? totals[d] : 0u; gsum += tot_d[k]; }
+	uint32_t inc = sum, ginc = gsum;
+	#pragma unroll
+	for (int o = 1; o < WAVE; o <<= 1) { const uint32_t u = __shfl_up(inc, o, WAVE), gu = __shfl_up(ginc, o, WAVE); if (lane >= o) { inc += u; ginc += gu; } }
+	if (lane == WAVE - 1) { wsum[w] = inc; wsum[ZS_WAVES + w] = ginc; }
+	__syncthreads();
+	uint32_t tstart = inc - sum, gstart = ginc - gsum;
+	#pragma unroll
+	for (int ww = 0; ww < ZS_WAVES; ww++) if (ww < w) { tstart += wsum[ww]; gstart += wsum[ZS_WAVES + ww]; }
+	#pragma unroll
+	for (int k = 0; k < PER; k++) {
+		const int d = (int)threadIdx.x * PER + k;
+		if (d < RADIX) {
+			uint32_t before = 0;
+			if (tile != 0u) {
+				for (uint32_t t = tile - 1u;; t--) {
+					uint32_t v;
+					do { v = __hip_atomic_load(status + (size_t)t * RADIX + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((v >> 30) == 0u);
+					before += v & ZS_VALUE;
+					if ((v >> 30) == 2u) break;
+				}
+				__hip_atomic_store(status + (size_t)tile * RADIX + d, ZS_FLAG_INC | (before + cnt_d[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			gdelta[d] = gstart + before - tstart;   // global position of an element = its index in the sorted tile + this
+			// where each wave's elements of this digit start inside the sorted tile
+			uint32_t s0 = tstart;
+			#pragma unroll
+			for (int ww = 0; ww < ZS_WAVES; ww++) { const uint32_t c = wcount[ww][d]; wcount[ww][d] = (uint16_t)s0; s0 += c; }
+			tstart += cnt_d[k]; gstart += tot_d[k];
+		}
+	}
+	__syncthreads();
+	// ---- the tile, sorted by this digit, in LDS
+	#pragma unroll
+	for (int i = 0; i < ZS_ITEMS; i++)
+		if ((uint32_t)(i * WAVE + lane) < rem) stage[wcount[w][dig_rank[i] & 0xffffu] + (dig_rank[i] >> 16)] = e[i];
+	__syncthreads();
+	// ---- and out: consecutive threads write consecutive elements of a digit's run
+	#pragma unroll
+	for (int i = 0; i < ZS_ITEMS; i++) {
+		const uint32_t j = (uint32_t)i * ZS_THREADS + threadIdx.x;
+		if (j < trem) {
+			const uint2 v = stage[j];
+			const uint32_t pos = j + gdelta[(v.x >> shift) & (uint32_t)(RADIX - 1)];
+			if (LAST) order_out[pos] = (int)v.y; else out[pos] = v;
+		}
+	}
+}
+template <int BITS>
+static void zs_pass(bool last, const uint2* in, uint2* out, int* order_out, int n, int shift, const uint32_t* base, uint32_t* status, uint32_t* ticket, hipStream_t s)
+{
+	if (last) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zs_pass<BITS, true>), dim3(zs_tiles(n)), dim3(ZS_THREADS), 0, s, in, out, order_out, n, shift, base, status, ticket);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zs_pass<BITS, false>), dim3(zs_tiles(n)), dim3(ZS_THREADS), 0, s, in, out, order_out, n, shift, base, status, ticket);
+}
+static void launch_zsort_pairs(const float* xyz, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, int* order_out, hipStream_t s)
+{
+	constexpr size_t R = (size_t)1 << ZS_MAX_BITS;
+	const ZsPlan plan = zs_plan(key_bits);
+	ZsPlanDev pd{};
+	pd.passes = plan.passes;
+	for (int i = 0; i < plan.passes; i++) { pd.bits[i] = plan.bits[i]; pd.shift[i] = plan.shift[i]; }
+	const int kgrid = zs_key_grid(n), tiles = zs_tiles(n);
+	uint32_t* part = (uint32_t*)temp;
+	uint32_t* base = part + (size_t)ZS_KEY_GRID * ZS_MAX_PASSES * R;
+	uint32_t* ticket = base + (size_t)ZS_MAX_PASSES * R;
+	uint32_t* status = ticket + 64;
+	// the status words of all passes and the tickets: zero (one fill; a tile's word becomes non-zero exactly once)
+	(void)hipMemsetAsync(ticket, 0, (64 + (size_t)plan.passes * (size_t)tiles * R) * sizeof(uint32_t), s);
+	uint2* buf[2] = { reinterpret_cast<uint2*>(b.xyzi[0]), reinterpret_cast<uint2*>(b.xyzi[1]) };   // (the ping-pong arrays of the search structure: 16 bytes per point each)
+	hipLaunchKernelGGL(k_zs_keys, dim3(kgrid), dim3(ZS_KEY_THREADS), 0, s, xyz, n, g, pd, buf[0], part);
+	hipLaunchKernelGGL(k_zs_totals, dim3((unsigned)(R / 64), (unsigned)plan.passes), dim3(256), 0, s, part, kgrid, base);
+	int cur = 0;
+	for (int p = 0; p < plan.passes; p++) {
+		const bool last = p == plan.passes - 1;
+		uint32_t* st = status + (size_t)p * (size_t)tiles * R;
+		switch (plan.bits[p]) {
+		case 8:  zs_pass<8>(last, buf[cur], buf[cur ^ 1], order_out, n, plan.shift[p], base + p * R, st, ticket + p, s); break;
+		case 9:  zs_pass<9>(last, buf[cur], buf[cur ^ 1], order_out, n, plan.shift[p], base + p * R, st, ticket + p, s); break;
+		default: zs_pass<10>(last, buf[cur], buf[cur ^ 1], order_out, n, plan.shift[p], base + p * R, st, ticket + p, s); break;
+		}
+		cur ^= 1;
+	}
+}
+
 int launch_morton_sort(const float* xyz, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, int* order_out, hipStream_t s)
 {
 	if (n >= (1 << 16) && key_bits >= 16 && key_bits <= 24) {
@@ -531,6 +772,10 @@ int launch_morton_sort(const float* xyz, int n, GridParams g, int key_bits, cons
 		TNSX_CS_DISPATCH(hi_bits, (cs_scatter<B, true>(true, false, xyz, nullptr, b.xyzi[0], b.r2[0], b.xyzi[1], b.r2[1], n, g, lo_bits, hist, totals, ntiles, nullptr, nullptr, none, s)));
 		const size_t lds = ((size_t)1 << lo_bits) * sizeof(uint32_t);
 		hipLaunchKernelGGL(k_morton_place, dim3(1 << hi_bits), dim3(BP_THREADS), lds, s, b.xyzi[1], order_out, g, lo_bits, totals);
+		return 1;
+	}
+	if (n >= (1 << 16) && key_bits > 24 && key_bits <= 30) {   // round 5: {key, index} pairs through single-pass digit sorts (above)
+		launch_zsort_pairs(xyz, n, g, key_bits, b, temp, order_out, s);
 		return 1;
 	}
 	const int res = point_sort<true>(xyz, nullptr, n, g, key_bits, b, temp, nullptr, nullptr, BuildGuard{}, s);

@@ -1576,7 +1576,7 @@ tnsx_status tnsx_prepare_zsort(tnsx_context* c)
 		s.zsort_ready = true;
 		if (s.n == 0) continue;
 		for (int k = 0; k < 2; k++) HIPCHK(c, s.xyzi[k].reserve((size_t)s.n * sizeof(float4)));
-		HIPCHK(c, c->sort_temp.reserve(tnsx::cell_sort_temp_bytes(s.n)));
+		HIPCHK(c, c->sort_temp.reserve(std::max(tnsx::cell_sort_temp_bytes(s.n), tnsx::zsort_temp_bytes(s.n))));
 		HIPCHK(c, s.zsort_dev.reserve((size_t)s.n * sizeof(int)));
 		// Morton key of the point's cell on the reference grid (cell-level order, stable => deterministic): the same
 		// point-moving radix sort as the search structure, the order is the index column of the sorted points

@@ -79,6 +79,7 @@ void launch_set_checksum(const float* xyz, const float* radii, int n, unsigned l
 // order; prepare_zsort): g.ox/oy/oz = world bottom, g.inv_h = 1 / cell size, g.nx = cells per axis (a power of two), 3 * log2(nx)
 // key bits.  order_out[p] = original index of the p-th point in z-order.
 int launch_morton_sort(const float* xyz, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, int* order_out, hipStream_t s);
+size_t zsort_temp_bytes(int n);   // temp of launch_morton_sort: max(cell_sort_temp_bytes(n), this)
 // Cell table: table[key] = (first sorted position, one past last); occ = {first sorted position, key} of every occupied cell
 // (order of blocks of 4096 points is arbitrary), *n_occ = their number (must be zeroed before)
 void launch_cell_table(const float4* xyzi_sorted, int n, GridParams g, uint2* table, uint2* occ, uint32_t* n_occ, hipStream_t s);

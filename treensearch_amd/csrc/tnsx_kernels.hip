@@ -237,11 +237,38 @@ __global__ void __launch_bounds__(256) k_permute_t(const T* __restrict__ in, T* 
 	const size_t rec = g / words, wd = g % words;
 	out[g] = in[(size_t)perm[rec] * words + wd];
 }
+// records of 1, 2, 3 or 4 words (radii, ids, xyz, float4 -- what apply_zsort is called with in an SPH step): a RECORD per thread, one read of the permutation and one
+// (wide) load / store per record, four records in flight per thread.  (round 5: the word-per-thread kernel above read perm[] once per word and kept one load in flight)
+template <int WORDS>
+__global__ void __launch_bounds__(256) k_permute_rec(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const int* __restrict__ perm, int n)
+{
+	struct Rec { uint32_t w[WORDS]; };
+	constexpr int PER = 4;
+	const size_t base = (size_t)blockIdx.x * (256 * PER) + threadIdx.x;
+	int src[PER];
+	#pragma unroll
+	for (int k = 0; k < PER; k++) { const size_t r = base + (size_t)k * 256; src[k] = perm[r < (size_t)n ? r : (size_t)n - 1]; }
+	Rec v[PER];
+	#pragma unroll
+	for (int k = 0; k < PER; k++) v[k] = reinterpret_cast<const Rec*>(in)[src[k]];
+	#pragma unroll
+	for (int k = 0; k < PER; k++) { const size_t r = base + (size_t)k * 256; if (r < (size_t)n) reinterpret_cast<Rec*>(out)[r] = v[k]; }
+}
 void launch_permute_bytes(const void* in, void* out, const int* new_to_old, int n, size_t rec_bytes, hipStream_t s)
 {
 	if (n <= 0 || rec_bytes == 0) return;
 	const bool aligned4 = (rec_bytes % 4 == 0) && (((uintptr_t)in | (uintptr_t)out) % 4 == 0);
-	if (aligned4) {
+	if (aligned4 && rec_bytes <= 16) {
+		const dim3 grid((unsigned)(((size_t)n + 1023) / 1024));
+		const uint32_t* i4 = (const uint32_t*)in; uint32_t* o4 = (uint32_t*)out;
+		switch (rec_bytes / 4) {
+		case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_permute_rec<1>), grid, dim3(256), 0, s, i4, o4, new_to_old, n); break;
+		case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_permute_rec<2>), grid, dim3(256), 0, s, i4, o4, new_to_old, n); break;
+		case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_permute_rec<3>), grid, dim3(256), 0, s, i4, o4, new_to_old, n); break;
+		default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_permute_rec<4>), grid, dim3(256), 0, s, i4, o4, new_to_old, n); break;
+		}
+	}
+	else if (aligned4) {
 		const int words = (int)(rec_bytes / 4);
 		const size_t total = (size_t)n * words;
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_permute_t<uint32_t>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const uint32_t*)in, (uint32_t*)out,
