@@ -284,7 +284,8 @@ enum { TNSX_SLAB_SUM_U32 = 0, TNSX_SLAB_MIN_F32 = 1, TNSX_SLAB_MAX_F32 = 2 };
  * after what `stream` (a hipStream_t) already holds and must be complete, or ordered on `stream`, when they return. */
 typedef struct tnsx_slab_transport {
 	void* user;
-	int (*exchange)(void* user, int rank, int world, const tnsx_slab_op* ops, int n_ops, void* stream);   /* all ops of one round, 0 = ok */
+	int (*exchange)(void* user, int rank, int world, const tnsx_slab_op* ops, int n_ops, void* stream);   /* all ops of one round, 0 = ok, 3 = timed out
+	                                                                                                        (reported as TNSX_ERR_TIMEOUT), else failed */
 	int (*allreduce)(void* user, int rank, int world, void* dev_buf, int count, int op, void* stream);    /* in place, 32-bit elements */
 	void (*release)(void* user);
 	void (*abort)(void* user);   /* may be NULL.  Called by the watchdog when an exchange did not complete in time: must make the pending operations of
@@ -332,6 +333,9 @@ typedef struct tnsx_slab_redist tnsx_slab_redist;
 tnsx_status tnsx_slab_redistribute_begin(tnsx_context* engine, const tnsx_slab_transport* transport, int rank, int world, const float* cuts,
                                          const float* xyz, const long long* gids, const float* radii, int n_points, tnsx_slab_redist** out, int* n_owned);
 tnsx_status tnsx_slab_redistribute_finish(tnsx_slab_redist* r, float* xyz_out, long long* gids_out, float* radii_out);
+/* bound of the two waits of tnsx_slab_redistribute_begin (default 120 s; <= 0: for ever; process-wide).  On expiry the transport's abort is called when it has one;
+ * when it has none the buffers the stream may still touch are leaked rather than freed under it. */
+tnsx_status tnsx_slab_set_redistribute_watchdog(double seconds);
 
 /* A slab with two neighbours must be at least one halo wide (ghosts come from the adjacent slabs only): TNSX_ERR_INVALID otherwise.
  * Creation errors are described by tnsx_slab_last_error(NULL).  The engine must outlive the slab: tnsx_slab_destroy turns the engine's sets that
@@ -342,7 +346,8 @@ void        tnsx_slab_destroy(tnsx_slab* slab);
 const char* tnsx_slab_last_error(const tnsx_slab* slab /* NULL: the last creation / decomposition error of this thread */);
 /* Watchdog: every wait of tnsx_slab_step on the stream (the exchange, the search behind it) is bounded by `seconds` (default 120; <= 0: wait for
  * ever).  When it expires the step names the link(s) it was waiting on in tnsx_slab_last_error, calls the transport's abort and returns
- * TNSX_ERR_TIMEOUT -- a mismatched exchange on 8 GPUs fails with a message instead of hanging the job. */
+ * TNSX_ERR_TIMEOUT.  What is bounded: the waits on the STREAM, and the host-side waits of the in-process transport (tnsx_slab_transport_local); an application's
+ * own transport bounds its own host-side waits (return 3 from exchange) -- a mismatched exchange on 8 GPUs fails with a message instead of hanging the job. */
 tnsx_status tnsx_slab_set_watchdog(tnsx_slab* slab, double seconds);
 /* searches between the slab's sets (indices as in tnsx_slab_step); default: set 0 in itself */
 tnsx_status tnsx_slab_set_active_search(tnsx_slab* slab, int set_i, int set_j, int active);

@@ -82,7 +82,7 @@ ABI_SYMBOLS = [
     "tnsx_slab_transport_local", "tnsx_slab_transport_release", "tnsx_slab_balanced_cuts", "tnsx_slab_create", "tnsx_slab_destroy",
     "tnsx_slab_last_error", "tnsx_slab_set_active_search", "tnsx_slab_step", "tnsx_slab_engine_set", "tnsx_slab_get_info",
     "tnsx_slab_debug_set_capacity", "tnsx_slab_set_watchdog", "tnsx_slab_redistribute_begin", "tnsx_slab_redistribute_finish",
-    "tnsx_slab_set_collect_times", "tnsx_slab_transport_check",
+    "tnsx_slab_set_collect_times", "tnsx_slab_transport_check", "tnsx_slab_set_redistribute_watchdog",
 ]
 
 
@@ -184,6 +184,7 @@ def load_library():
     L.tnsx_slab_debug_set_capacity.argtypes = [vp, ci, C.c_uint]
     L.tnsx_slab_set_watchdog.argtypes = [vp, C.c_double]
     L.tnsx_slab_set_collect_times.argtypes = [vp, ci]
+    L.tnsx_slab_set_redistribute_watchdog.argtypes = [C.c_double]
     L.tnsx_slab_transport_check.argtypes = [vp, tp, ci, ci, C.POINTER(ci)]
     L.tnsx_slab_redistribute_begin.argtypes = [vp, tp, ci, ci, C.POINTER(C.c_float), vp, vp, vp, ci, C.POINTER(vp), C.POINTER(ci)]
     L.tnsx_slab_redistribute_finish.argtypes = [vp, vp, vp, vp]

@@ -697,6 +697,9 @@ static tnsx_status copy_records(tnsx_context* c, const PairResult& pr, int* dst,
 // of their slabs, which is what the region has to hold (nullptr after a dry pass, whose slabs have another size: the regions then
 // get a quarter / a half more than the records need).  generous: the common region can take EVERYTHING (the redo of a pass that
 // overflowed must not overflow again).
+#ifndef TNSX_POOL_SLAB_DIV
+#define TNSX_POOL_SLAB_DIV 8   // slabs of 1 / DIV of a wave's share of the pool (the holes: half of every wave's last slab)
+#endif
 static tnsx_status size_pool(tnsx_context* c, PairResult& pr, const uint64_t* payload, const uint64_t* asked, bool generous, int query_waves)
 {
 	for (int r = 0; r < PairResult::NR; r++) { pr.region_base[r] = 0; pr.region_cap[r] = 0; pr.region_used[r] = 0; }
@@ -711,7 +714,7 @@ static tnsx_status size_pool(tnsx_context* c, PairResult& pr, const uint64_t* pa
 	// a wave's last slab stays half empty on average: slabs of 1/8 of a wave's share keep the holes at ~6 % of the pool
 	// (round 3: the unit of allocation is the block of a whole cell -- some hundred ints to a few thousand -- so a slab is at least 4096
 	//  ints: with the 256-int slabs a small set used to get, every cell would be an allocation of its own)
-	uint64_t slab = std::min<uint64_t>(16384, std::max<uint64_t>(4096, expect / ((uint64_t)query_waves * 8)));
+	uint64_t slab = std::min<uint64_t>(16384, std::max<uint64_t>(4096, expect / ((uint64_t)query_waves * TNSX_POOL_SLAB_DIV)));
 	// (the holes depend on the slab size: the previous size is kept while it is within an eighth of the ideal one)
 	if (asked && slab >= (uint64_t)pr.pool_slab - pr.pool_slab / 8 && slab <= (uint64_t)pr.pool_slab + pr.pool_slab / 8) slab = pr.pool_slab;
 	if (asked && slab != pr.pool_slab) asked = nullptr;
@@ -842,16 +845,78 @@ static tnsx_status layout_grid(tnsx_context* c, const float b8[8], int64_t n_tot
 	return TNSX_OK;
 }
 
-static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
-{
-	*redo = false;
-	StageTimer tm(c);
-	struct Span { int stage, a, b; };
-	std::vector<Span> spans;
-	auto span = [&](int stage, int a, int b) { if (a >= 0 && b >= 0) spans.push_back({ stage, a, b }); };
+// ==================================================================================================
+// One attempt of run(), in stages (round 5: this was ONE function of 557 lines; the reference's run() is ten lines that call stages,
+// TreeNSearch.cpp:138-149).  RunAttempt holds what the stages share -- nothing in it outlives the attempt:
+//   plan_run         everything decided on the host before the first launch: inputs, bounds (unless the grid is reused), the grid, the result slots, the
+//                    pool of every pair sized from the previous run's numbers
+//   launch_build     k_run_begin + the build of every set that does not keep its structures
+//   launch_queries   the pass of every active pair + k_run_end
+//   judge_attempt    the ONE synchronisation; were the assumptions of the attempt right?
+//   finish_run       per pair: the counters of its pass, a repair if a pool region overflowed (collect_pair); sorted lists, host mirror, statistics
+// ==================================================================================================
+namespace {
+struct RunJob { int i, j; bool pool; bool begun; };
+struct RunSpan { int stage, a, b; };
+constexpr size_t RUN_WB = (size_t)tnsx::CHK_SLOTS * tnsx::CHK_STRIDE;                 // 64-bit words per block of the attempt's device words
+constexpr size_t RUN_HC = (size_t)PairResult::NR * tnsx::POOL_CTRL_WORDS;             // per job: cursor / neighbours / unused ints of every pool region (exact layout: word 0 = total)
+struct RunAttempt {
+	tnsx_context* c;
+	bool speculate;
+	StageTimer tm;
+	std::vector<RunSpan> spans;
+	int n_sets = 0;
+	hipStream_t st = nullptr;
+	int64_t n_total = 0;
+	bool variable = false, sparse = false;
+	tnsx::GridParams g{};
+	uint64_t n_cells = 1;
+	int key_bits = 1;
+	unsigned long long* d_words = nullptr;   // block 0 = the guard flag, block 1 + si = the partial checksums of set si
+	std::vector<char> skipped;               // sets that keep their build in this attempt
+	std::vector<RunJob> jobs;                // the active pairs
+	uint64_t* h_ctrl = nullptr; uint64_t* h_words = nullptr;
+	uint32_t* h_nocc = nullptr; uint32_t* h_filt = nullptr; uint32_t* h_left = nullptr; uint32_t* h_heavy = nullptr;
+	tnsx::RunEndArgs run_end{};
+	bool defer_readback = true;
+	int query_waves = 0;
+	tnsx::QueryConfig qc{};
+	int e_begin = -1, t_build0 = -1;
+	RunAttempt(tnsx_context* ctx, bool spec) : c(ctx), speculate(spec), tm(ctx) {}
+	void span(int stage, int a, int b) { if (a >= 0 && b >= 0) spans.push_back({ stage, a, b }); }
+	uint32_t* ctrl_slot(size_t k, int slot) const { return c->pool_ctrl.as<uint32_t>() + (k * tnsx::CTRL_SLOTS + (size_t)slot) * tnsx::CTRL_STRIDE_U32; }
+	PairResult& pair(const RunJob& jb) const { return c->pairs[(size_t)jb.i * n_sets + jb.j]; }
+	bool keeps_its_build(const PointSet& s) const
+	{
+		const bool same_input = s.chk_valid && s.chk_xyz == s.user_xyz && s.chk_radii == s.user_radii && s.chk_n == s.n && s.chk_double == s.is_double;
+		const bool cacheable = !s.user_ids && s.n > 0;
+		return speculate && cacheable && s.predicted_static && same_input && s.built_gen == c->grid_gen && (sparse || s.table_state == 1);
+	}
+};
+// (the stages keep the names the one function had for what they share)
+#define TNSX_RUN_ALIASES                                                                                                      \
+	tnsx_context* const c = run.c; const bool speculate = run.speculate; StageTimer& tm = run.tm; const int n_sets = run.n_sets;      \
+	hipStream_t st = run.st; tnsx_stats& S = c->stats; const int64_t n_total = run.n_total; const bool variable = run.variable;     \
+	const bool sparse = run.sparse; const tnsx::GridParams g = run.g; const uint64_t n_cells = run.n_cells; const int key_bits = run.key_bits; \
+	constexpr size_t WB = RUN_WB, HC = RUN_HC; unsigned long long* const d_words = run.d_words; std::vector<char>& skipped = run.skipped; \
+	std::vector<RunJob>& jobs = run.jobs; uint64_t* const h_ctrl = run.h_ctrl; uint64_t* const h_words = run.h_words; uint32_t* const h_nocc = run.h_nocc; \
+	uint32_t* const h_filt = run.h_filt; uint32_t* const h_left = run.h_left; uint32_t* const h_heavy = run.h_heavy; tnsx::RunEndArgs& run_end = run.run_end; \
+	bool& defer_readback = run.defer_readback; const int query_waves = run.query_waves; tnsx::QueryConfig& qc = run.qc;          \
+	auto span = [&run](int stage_, int a_, int b_) { run.span(stage_, a_, b_); };                                                 \
+	auto ctrl_slot = [&run](size_t k_, int slot_) { return run.ctrl_slot(k_, slot_); };                                           \
+	auto keeps_its_build = [&run](const PointSet& s_) { return run.keeps_its_build(s_); };                                        \
+	(void)speculate; (void)tm; (void)n_sets; (void)st; (void)S; (void)n_total; (void)variable; (void)sparse; (void)g; (void)n_cells; (void)key_bits; (void)WB; (void)HC; \
+	(void)d_words; (void)skipped; (void)jobs; (void)h_ctrl; (void)h_words; (void)h_nocc; (void)h_filt; (void)h_left; (void)h_heavy; (void)run_end; (void)defer_readback; \
+	(void)query_waves; (void)qc; (void)span; (void)ctrl_slot; (void)keeps_its_build
+}  // namespace
 
-	const int n_sets = (int)c->sets.size();
-	hipStream_t st = c->stream;
+static tnsx_status plan_run(RunAttempt& run)
+{
+	tnsx_context* const c = run.c; const bool speculate = run.speculate; StageTimer& tm = run.tm;
+	auto span = [&run](int stage_, int a_, int b_) { run.span(stage_, a_, b_); };
+	constexpr size_t WB = RUN_WB, HC = RUN_HC;
+	const int n_sets = run.n_sets = (int)c->sets.size();
+	run.st = c->stream;
 	tnsx_stats& S = c->stats;
 	const int retries_so_far = S.speculation_redos;
 	std::memset(&S, 0, sizeof(S));
@@ -859,7 +924,7 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	S.n_sets = n_sets;
 	c->ran = false;
 
-	const int e_begin = tm.mark();
+	const int e_begin = run.e_begin = tm.mark();
 	// ---- inputs -> device floats
 	{ const tnsx_status r = stage_inputs(c); if (r != TNSX_OK) return r; }
 	const int e_up = tm.mark();
@@ -867,8 +932,9 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 
 	int64_t n_total = 0;
 	for (const PointSet& s : c->sets) n_total += s.n;
+	run.n_total = n_total;
 	S.n_points = (uint64_t)n_total;
-	const bool variable = !c->radius_set;
+	const bool variable = run.variable = !c->radius_set;
 
 	// ---- bounds (tight AABB, radius range) -> host, unless the previous run's grid is reused
 	float b8[8] = { FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX, FLT_MAX, -FLT_MAX };
@@ -891,9 +957,9 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	tnsx::GridParams g{};
 	uint64_t n_cells = 1;
 	if (!speculate) { const tnsx_status r = layout_grid(c, b8, n_total, variable); if (r != TNSX_OK) return r; }
-	g = c->grid;
-	n_cells = (uint64_t)g.nx * g.ny * g.nz;
-	const bool sparse = c->grid_sparse;
+	g = run.g = c->grid;
+	n_cells = run.n_cells = (uint64_t)g.nx * g.ny * g.nz;
+	const bool sparse = run.sparse = c->grid_sparse;
 	S.grid_cell_size = c->grid_h;
 	for (int d = 0; d < 3; d++) { S.world_bottom[d] = c->world[d]; S.world_top[d] = c->world[3 + d]; }
 	S.world_cells_pow2 = c->world_cells_pow2;
@@ -902,16 +968,15 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	S.n_grid_cells = n_cells;
 	S.grid_trimmed = c->grid_trimmed ? 1 : 0;
 	S.grid_sparse = sparse ? 1 : 0;
-	const int key_bits = std::max(1, ceil_log2_u64(n_cells + 1));   // + 1: the key behind the last cell, where NaN points ("no point") go
+	const int key_bits = run.key_bits = std::max(1, ceil_log2_u64(n_cells + 1));   // + 1: the key behind the last cell, where NaN points ("no point") go
 	S.key_bits = key_bits;
 	if (sparse) { c->sparse_shift = std::max(0, key_bits - 22); c->sparse_blocks = (uint32_t)(((n_cells - 1) >> c->sparse_shift) + 1); }
 	S.radix_passes = tnsx::cell_sort_plan(key_bits).passes;
 	S.speculated = speculate ? 1 : 0;
 
 	// ---- device words of this attempt (64-bit each): block 0 = the guard flag, block 1 + si = the partial checksums of set si
-	constexpr size_t WB = (size_t)tnsx::CHK_SLOTS * tnsx::CHK_STRIDE;   // words per block
 	HIPCHK(c, c->run_words.reserve(sizeof(uint64_t) * WB * (size_t)(n_sets + 1)));
-	unsigned long long* const d_words = c->run_words.as<unsigned long long>();
+	run.d_words = c->run_words.as<unsigned long long>();
 
 	// ---- per set: cell sort -> cell table (or nothing: a set that did not change keeps what it has)
 	{
@@ -919,40 +984,31 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		HIPCHK(c, c->n_occ.reserve(sizeof(uint32_t) * (size_t)std::max(n_sets, 1)));
 		if (c->n_occ.p != old) for (PointSet& s : c->sets) s.built_gen = 0;   // the occupied-cell counts of cached sets lived in the old buffer
 	}
-	std::vector<char> skipped((size_t)n_sets, 0);
-	auto keeps_its_build = [&](const PointSet& s) {
-		const bool same_input = s.chk_valid && s.chk_xyz == s.user_xyz && s.chk_radii == s.user_radii && s.chk_n == s.n && s.chk_double == s.is_double;
-		const bool cacheable = !s.user_ids && s.n > 0;
-		return speculate && cacheable && s.predicted_static && same_input && s.built_gen == c->grid_gen && (sparse || s.table_state == 1);
-	};
-
+	run.skipped.assign((size_t)n_sets, 0);
 	// ---- per active pair: what its pass needs on the host side (sizes from the previous run; nothing here waits for the device).
 	//      pool mode (default): ONE pass, records bump-allocated from the regions of the pair's pool (first run of a pair: a dry pass first);
 	//      exact mode (opt.exact_layout): count -> scan -> fill, gap-free CSR in sorted order.
-	struct Job { int i, j; bool pool; bool begun; };
-	std::vector<Job> jobs;
+	std::vector<RunJob>& jobs = run.jobs;
 	for (int i = 0; i < n_sets; i++) for (int j = 0; j < n_sets; j++) if (c->active[i][j]) jobs.push_back({ i, j, false, false });
-	constexpr size_t HC = (size_t)PairResult::NR * tnsx::POOL_CTRL_WORDS;   // per job: cursor / neighbours / unused ints of every pool region (exact layout: word 0 = total)
 	HIPCHK(c, c->h_small.reserve(sizeof(uint64_t) * (HC * jobs.size() + 2 + WB * ((size_t)n_sets + 1)) + sizeof(uint32_t) * (size_t)(n_sets + 1 + 3 * (jobs.size() + 1)) + 64));
-	uint64_t* h_ctrl = c->h_small.as<uint64_t>();
-	uint64_t* h_words = h_ctrl + HC * jobs.size() + 2;                  // guard flag, partial checksums
-	uint32_t* h_nocc = reinterpret_cast<uint32_t*>(h_words + WB * ((size_t)n_sets + 1));
-	uint32_t* h_filt = h_nocc + n_sets + 1;                             // per job: cells that passed the candidate-presence filter
+	uint64_t* h_ctrl = run.h_ctrl = c->h_small.as<uint64_t>();
+	uint64_t* h_words = run.h_words = h_ctrl + HC * jobs.size() + 2;                  // guard flag, partial checksums
+	uint32_t* h_nocc = run.h_nocc = reinterpret_cast<uint32_t*>(h_words + WB * ((size_t)n_sets + 1));
+	uint32_t* h_filt = run.h_filt = h_nocc + n_sets + 1;                             // per job: cells that passed the candidate-presence filter
 	for (size_t k = 0; k < jobs.size(); k++) h_filt[k] = 0;
-	uint32_t* h_left = h_filt + jobs.size() + 1;                        // per job: cells the group kernel passed on to the cell tiers
+	uint32_t* h_left = run.h_left = h_filt + jobs.size() + 1;                        // per job: cells the group kernel passed on to the cell tiers
 	for (size_t k = 0; k < jobs.size(); k++) h_left[k] = 0;
-	uint32_t* h_heavy = h_left + jobs.size() + 1;                       // per job: cells the first tier passed on to the heavy tiers
+	uint32_t* h_heavy = run.h_heavy = h_left + jobs.size() + 1;                       // per job: cells the first tier passed on to the heavy tiers
 	for (size_t k = 0; k < jobs.size(); k++) h_heavy[k] = 0;
 	// the words of the pool passes go to the host with the ONE kernel at the end of the attempt (launch_run_end); the repeat of a pass that
 	// overflowed, and attempts with more pool passes than that kernel takes, copy them pass by pass
-	tnsx::RunEndArgs run_end{};
-	bool defer_readback = true;
+	run.run_end = tnsx::RunEndArgs{};
+	run.defer_readback = true;
 	HIPCHK(c, c->pool_ctrl.reserve(tnsx::CTRL_BYTES * (jobs.size() + 1)));   // per job: cursor, hit_total, 2 x (8 tickets, n_heavy), spread out
-	auto ctrl_slot = [&](size_t k, int slot) { return c->pool_ctrl.as<uint32_t>() + (k * tnsx::CTRL_SLOTS + (size_t)slot) * tnsx::CTRL_STRIDE_U32; };
-	const int query_waves = c->n_cus * 8 * 4;
+	const int query_waves = run.query_waves = c->n_cus * 8 * 4;
 	for (size_t k = 0; k < jobs.size(); k++) {
-		Job& jb = jobs[k];
-		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
+		RunJob& jb = jobs[k];
+		PairResult& pr = run.pair(jb);
 		const int n_i = c->sets[jb.i].n;
 		pr.n_i = n_i;
 		pr.n_query = c->sets[jb.i].n_query < 0 ? n_i : std::min(n_i, c->sets[jb.i].n_query);
@@ -978,10 +1034,16 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		}
 	}
 
+	return TNSX_OK;
+}
+
+static tnsx_status enqueue_run_begin(RunAttempt& run)
+{
+	TNSX_RUN_ALIASES;
 	// ---- ONE launch in front of everything (round 4: four kernels of a steady-state step, ~5 us of dispatch each): the words of this attempt and
 	//      the occupied-cell counts of the sets that are built start at zero, the table entries the previous run set are cleared, every pool
 	//      pass gets the hot words of its control block and its region table
-	const int t_build0 = tm.mark();
+	run.t_build0 = tm.mark();
 	{
 		tnsx::RunBeginArgs rb{};
 		rb.words = d_words; rb.n_words = WB * (size_t)(n_sets + 1); rb.n_occ = c->n_occ.as<uint32_t>();
@@ -1028,9 +1090,9 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 			else s.bk_gen = 0;
 		}
 		for (size_t k = 0; k < jobs.size() && rb.n_pool < tnsx::RUN_BEGIN_MAX_POOLS; k++) {
-			Job& jb = jobs[k];
+			RunJob& jb = jobs[k];
 			if (!jb.pool) continue;
-			const PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
+			const PairResult& pr = run.pair(jb);
 			tnsx::RunBeginPool& bp = rb.pool[rb.n_pool++];
 			const bool count_only = c->debug_nostore || pr.dry;
 			for (int r = 0; r < PairResult::NR; r++) { bp.regions[2 * r] = pr.region_base[r]; bp.regions[2 * r + 1] = count_only ? 0ull : pr.region_cap[r]; }
@@ -1039,6 +1101,13 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		}
 		tnsx::launch_run_begin(rb, st);
 	}
+	return TNSX_OK;
+}
+
+static tnsx_status launch_build(RunAttempt& run)
+{
+	TNSX_RUN_ALIASES;
+	{ const tnsx_status r = enqueue_run_begin(run); if (r != TNSX_OK) return r; }
 	for (int si = 0; si < n_sets; si++) {
 		PointSet& s = c->sets[si];
 		const bool cacheable = !s.user_ids && s.n > 0;
@@ -1088,139 +1157,147 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		S.radix_passes = passes;
 		if (s.bk_used) S.one_read_builds++;
 	}
-	// (stage times: the build is everything from the first launch of the attempt to here -- table clear and control blocks included; no event
-	//  between its kernels, every event record between two kernels is a bubble of 6-9 us)
-	int t_build1 = -1;
+	return TNSX_OK;
+}
 
-	// ---- per active pair: the query
-	auto make_args = [&](const Job& jb, PairResult& pr, size_t k) {
+// what the query kernels of pair (jb.i -> jb.j) get
+static tnsx::QueryArgs make_query_args(RunAttempt& run, const RunJob& jb, PairResult& pr, size_t k)
+{
+	TNSX_RUN_ALIASES;
+	const PointSet& A = c->sets[jb.i];
+	const PointSet& B = c->sets[jb.j];
+	tnsx::QueryArgs a{};
+	a.occ_i = A.occ.as<uint2>(); a.n_occ_i = c->n_occ.as<uint32_t>() + jb.i;
+	a.table_i = A.table.as<uint2>();
+	a.xyzi_i = A.xyzi[A.sorted_buf].as<float4>(); a.r2_i = A.r2[A.sorted_buf].as<float>();
+	a.orig_i = A.user_ids ? A.orig_sorted.as<uint32_t>() : nullptr;
+	a.table_j = B.table.as<uint2>(); a.xyzi_j = B.xyzi[B.sorted_buf].as<float4>(); a.r2_j = B.r2[B.sorted_buf].as<float>();
+	a.r2_fixed = c->radius_sq;
+	a.query_limit = A.n_query < 0 ? 0xffffffffu : (uint32_t)A.n_query;
+	a.n_points_i = (uint32_t)A.n;
+	a.g = g;
+	a.counts = pr.counts.as<uint32_t>();
+	a.offs_sorted = pr.offs_sorted.as<uint64_t>();
+	a.records = pr.records.as<int>();
+	a.offs_by_orig = pr.offs_orig.as<uint64_t>();
+	a.pool_cursor = reinterpret_cast<unsigned long long*>(ctrl_slot(k, tnsx::CTRL_CURSOR));
+	a.pool_regions = reinterpret_cast<const unsigned long long*>(ctrl_slot(k, tnsx::CTRL_REGIONS));
+	a.tickets = ctrl_slot(k, tnsx::CTRL_TICKETS);
+	a.n_heavy = ctrl_slot(k, tnsx::CTRL_NHEAVY);
+	a.tickets2 = ctrl_slot(k, tnsx::CTRL_TICKETS2);
+	a.n_heavy2 = ctrl_slot(k, tnsx::CTRL_NHEAVY2);
+	a.heavy = pr.heavy.as<uint2>();
+	a.heavy2 = pr.heavy2.as<uint2>();
+	// (the worklist of the group formulation shares buffer and counter with the candidate-presence filter: that one is for pairs of two
+	//  different sets, the group formulation for a set searched in itself)
+	a.heavy0 = pr.filtered.as<uint2>();
+	a.n_heavy0 = ctrl_slot(k, tnsx::CTRL_NFILTERED);
+	if (sparse) { a.socc_i = A.occ.as<uint2>(); a.blk_i = A.blk.as<uint32_t>(); a.socc_j = B.occ.as<uint2>(); a.blk_j = B.blk.as<uint32_t>(); a.sparse_shift = c->sparse_shift; }
+	a.abort_flag = speculate ? reinterpret_cast<const uint32_t*>(d_words) : nullptr;
+	a.pool_slab = pr.pool_slab;
+	a.pool_slab_heavy = std::max<uint32_t>(pr.pool_slab, 8192u);
+	a.shared_empty = jb.pool && jb.i != jb.j ? 1u : 0u;
+	if (a.shared_empty && pr.n_query > 0 && !sparse) {
+		// the query walks the cells that have candidates at all (launch_mark_cells + launch_filter_marked, enqueued by launch_pool)
+		a.occ_i = pr.filtered.as<uint2>();
+		a.n_occ_i = ctrl_slot(k, tnsx::CTRL_NFILTERED);
+	}
+	return a;
+}
+
+// tiers: bit 0 = begin (if the pass was not begun by launch_run_begin) + candidate-presence filter + first tier, bit 1 = the heavy tiers
+static tnsx_status launch_pool_pass(RunAttempt& run, size_t k, int tiers, bool fresh)
+{
+	TNSX_RUN_ALIASES;
+	const RunJob& jb = jobs[k];
+	PairResult& pr = run.pair(jb);
+	if ((tiers & 1) && (fresh || !jb.begun)) {
+		// the region table of this pass (all capacities 0: nothing is written, everything is counted).
+		// A pair of two different sets: most query cells may have no candidate at all (a fluid searched in its boundary).  Int 0 of
+		// the pool is THE empty record and every offset starts out pointing at it: cells without candidates then cost no
+		// allocation, no record and no scattered 8-byte offset store.
+		unsigned long long regions[2 * PairResult::NR];
+		const bool count_only = c->debug_nostore || pr.dry;
+		for (int r = 0; r < PairResult::NR; r++) { regions[2 * r] = pr.region_base[r]; regions[2 * r + 1] = count_only ? 0ull : pr.region_cap[r]; }
+		tnsx::launch_pool_begin(regions, ctrl_slot(k, 0), pr.offs_orig.as<uint64_t>(),
+		                        pr.shared_empty ? (size_t)pr.n_query : 0, pr.records.as<int>(), st);
+	}
+	const int t0 = tm.mark();   // (behind the last kernel of the build / of the previous pass: the bracket holds the pass's query kernels only)
+	if (pr.shared_empty && (tiers & 1) && !sparse) {   // (the presence filter's byte map is a dense structure: a sparse grid walks all occupied cells)
 		const PointSet& A = c->sets[jb.i];
-		const PointSet& B = c->sets[jb.j];
-		tnsx::QueryArgs a{};
-		a.occ_i = A.occ.as<uint2>(); a.n_occ_i = c->n_occ.as<uint32_t>() + jb.i;
-		a.table_i = A.table.as<uint2>();
-		a.xyzi_i = A.xyzi[A.sorted_buf].as<float4>(); a.r2_i = A.r2[A.sorted_buf].as<float>();
-		a.orig_i = A.user_ids ? A.orig_sorted.as<uint32_t>() : nullptr;
-		a.table_j = B.table.as<uint2>(); a.xyzi_j = B.xyzi[B.sorted_buf].as<float4>(); a.r2_j = B.r2[B.sorted_buf].as<float>();
-		a.r2_fixed = c->radius_sq;
-		a.query_limit = A.n_query < 0 ? 0xffffffffu : (uint32_t)A.n_query;
-		a.n_points_i = (uint32_t)A.n;
-		a.g = g;
-		a.counts = pr.counts.as<uint32_t>();
-		a.offs_sorted = pr.offs_sorted.as<uint64_t>();
-		a.records = pr.records.as<int>();
-		a.offs_by_orig = pr.offs_orig.as<uint64_t>();
-		a.pool_cursor = reinterpret_cast<unsigned long long*>(ctrl_slot(k, tnsx::CTRL_CURSOR));
-		a.pool_regions = reinterpret_cast<const unsigned long long*>(ctrl_slot(k, tnsx::CTRL_REGIONS));
-		a.tickets = ctrl_slot(k, tnsx::CTRL_TICKETS);
-		a.n_heavy = ctrl_slot(k, tnsx::CTRL_NHEAVY);
-		a.tickets2 = ctrl_slot(k, tnsx::CTRL_TICKETS2);
-		a.n_heavy2 = ctrl_slot(k, tnsx::CTRL_NHEAVY2);
-		a.heavy = pr.heavy.as<uint2>();
-		a.heavy2 = pr.heavy2.as<uint2>();
-		// (the worklist of the group formulation shares buffer and counter with the candidate-presence filter: that one is for pairs of two
-		//  different sets, the group formulation for a set searched in itself)
-		a.heavy0 = pr.filtered.as<uint2>();
-		a.n_heavy0 = ctrl_slot(k, tnsx::CTRL_NFILTERED);
-		if (sparse) { a.socc_i = A.occ.as<uint2>(); a.blk_i = A.blk.as<uint32_t>(); a.socc_j = B.occ.as<uint2>(); a.blk_j = B.blk.as<uint32_t>(); a.sparse_shift = c->sparse_shift; }
-		a.abort_flag = speculate ? reinterpret_cast<const uint32_t*>(d_words) : nullptr;
-		a.pool_slab = pr.pool_slab;
-		a.pool_slab_heavy = std::max<uint32_t>(pr.pool_slab, 8192u);
-		a.shared_empty = jb.pool && jb.i != jb.j ? 1u : 0u;
-		if (a.shared_empty && pr.n_query > 0 && !sparse) {
-			// the query walks the cells that have candidates at all (launch_mark_cells + launch_filter_marked, enqueued by launch_pool)
-			a.occ_i = pr.filtered.as<uint2>();
-			a.n_occ_i = ctrl_slot(k, tnsx::CTRL_NFILTERED);
+		const size_t max_cells = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pr.n_i, n_cells));
+		HIPCHK(c, pr.filtered.reserve(max_cells * sizeof(uint2)));
+		{
+			const PointSet& B = c->sets[jb.j];
+			const void* old_map = c->cell_map.p;
+			HIPCHK(c, c->cell_map.reserve(n_cells));
+			if (c->cell_map.p != old_map) HIPCHK(c, hipMemsetAsync(c->cell_map.p, 0, c->cell_map.cap, st));   // (all zero between uses)
+			const size_t max_cells_j = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(B.n, 1), n_cells));
+			unsigned char* map = c->cell_map.as<unsigned char>();
+			tnsx::launch_mark_cells(B.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.j, g, map, 1, max_cells_j, st);
+			tnsx::launch_filter_marked(A.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.i, map, pr.filtered.as<uint2>(), ctrl_slot(k, tnsx::CTRL_NFILTERED), max_cells, st);
+			tnsx::launch_mark_cells(B.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.j, g, map, 0, max_cells_j, st);
 		}
-		return a;
-	};
-	tnsx::QueryConfig qc{};
+	}
+	if (pr.n_i > 0) {
+		qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_POOL;
+		// opt-in (tnsx_options.query_formulation = 1), fixed radius, a set searched in itself: the group formulation (tnsx_query_group.hip)
+		// in front of the cell kernels, unless it was switched off for this pair
+		pr.groups_now = !sparse && !variable && jb.i == jb.j && c->opt.query_formulation == 1 && tnsx_query_formulation_available(1) != 0 && !pr.groups_off &&
+		                c->grid_h * c->grid_h > 1e-30f;
+		qc.groups = pr.groups_now;
+		if (pr.groups_now) { HIPCHK(c, pr.filtered.reserve((size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pr.n_i, n_cells)) * sizeof(uint2))); tiers = 3; }
+		qc.tiers = tiers;
+		tnsx::launch_query(make_query_args(run, jb, pr, k), qc, c->n_cus, st);
+		qc.groups = false; qc.tiers = 3;
+	}
+	pr.heavy_skipped = !(tiers & 2);
+	const int t1 = tm.mark();
+	span(ST_FILL, t0, t1);
+	uint32_t* const h_count = (pr.shared_empty && !sparse) ? h_filt + k : (pr.groups_now && pr.n_i > 0 ? h_left + k : nullptr);   // (the two worklists share a counter, see make_args)
+	if (defer_readback && run_end.n_jobs < tnsx::RUN_END_MAX_JOBS) {
+		tnsx::RunEndJob& rj = run_end.job[run_end.n_jobs++];
+		rj.ctrl_cursor = ctrl_slot(k, tnsx::CTRL_CURSOR); rj.h_ctrl = reinterpret_cast<unsigned long long*>(h_ctrl + HC * k);
+		rj.d_count = ctrl_slot(k, tnsx::CTRL_NFILTERED); rj.h_count = h_count;
+		rj.d_heavy = ctrl_slot(k, tnsx::CTRL_NHEAVY); rj.h_heavy = h_heavy + k;
+		return TNSX_OK;
+	}
+	HIPCHK(c, hipMemcpy2DAsync(h_ctrl + HC * k, tnsx::POOL_CTRL_WORDS * sizeof(uint64_t), ctrl_slot(k, tnsx::CTRL_CURSOR), tnsx::CTRL_STRIDE_U32 * sizeof(uint32_t),
+	                           tnsx::POOL_CTRL_WORDS * sizeof(uint64_t), PairResult::NR, hipMemcpyDeviceToHost, st));
+	if (h_count) HIPCHK(c, hipMemcpyAsync(h_count, ctrl_slot(k, tnsx::CTRL_NFILTERED), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	HIPCHK(c, hipMemcpyAsync(h_heavy + k, ctrl_slot(k, tnsx::CTRL_NHEAVY), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	return TNSX_OK;
+}
+
+static tnsx_status launch_queries(RunAttempt& run)
+{
+	TNSX_RUN_ALIASES;
+	qc = tnsx::QueryConfig{};
 	qc.arith = c->opt.arith;
 	qc.variable = variable;
 	qc.symmetric = variable && c->symmetric;   // TreeNSearch.cpp:2431
 	qc.blocks_per_cu = c->opt.query_blocks_per_cu;
 	qc.fast_blocks_per_cu = c->opt.fast_blocks_per_cu;
-
-	// tiers: bit 0 = begin (if the pass was not begun by launch_run_begin) + candidate-presence filter + first tier, bit 1 = the heavy tiers
-	auto launch_pool = [&](size_t k, int tiers, bool fresh) -> tnsx_status {
-		const Job& jb = jobs[k];
-		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
-		if ((tiers & 1) && (fresh || !jb.begun)) {
-			// the region table of this pass (all capacities 0: nothing is written, everything is counted).
-			// A pair of two different sets: most query cells may have no candidate at all (a fluid searched in its boundary).  Int 0 of
-			// the pool is THE empty record and every offset starts out pointing at it: cells without candidates then cost no
-			// allocation, no record and no scattered 8-byte offset store.
-			unsigned long long regions[2 * PairResult::NR];
-			const bool count_only = c->debug_nostore || pr.dry;
-			for (int r = 0; r < PairResult::NR; r++) { regions[2 * r] = pr.region_base[r]; regions[2 * r + 1] = count_only ? 0ull : pr.region_cap[r]; }
-			tnsx::launch_pool_begin(regions, ctrl_slot(k, 0), pr.offs_orig.as<uint64_t>(),
-			                        pr.shared_empty ? (size_t)pr.n_query : 0, pr.records.as<int>(), st);
-		}
-		const int t0 = tm.mark();   // (behind the last kernel of the build / of the previous pass: the bracket holds the pass's query kernels only)
-		if (pr.shared_empty && (tiers & 1) && !sparse) {   // (the presence filter's byte map is a dense structure: a sparse grid walks all occupied cells)
-			const PointSet& A = c->sets[jb.i];
-			const size_t max_cells = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pr.n_i, n_cells));
-			HIPCHK(c, pr.filtered.reserve(max_cells * sizeof(uint2)));
-			{
-				const PointSet& B = c->sets[jb.j];
-				const void* old_map = c->cell_map.p;
-				HIPCHK(c, c->cell_map.reserve(n_cells));
-				if (c->cell_map.p != old_map) HIPCHK(c, hipMemsetAsync(c->cell_map.p, 0, c->cell_map.cap, st));   // (all zero between uses)
-				const size_t max_cells_j = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(B.n, 1), n_cells));
-				unsigned char* map = c->cell_map.as<unsigned char>();
-				tnsx::launch_mark_cells(B.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.j, g, map, 1, max_cells_j, st);
-				tnsx::launch_filter_marked(A.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.i, map, pr.filtered.as<uint2>(), ctrl_slot(k, tnsx::CTRL_NFILTERED), max_cells, st);
-				tnsx::launch_mark_cells(B.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.j, g, map, 0, max_cells_j, st);
-			}
-		}
-		if (pr.n_i > 0) {
-			qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_POOL;
-			// opt-in (tnsx_options.query_formulation = 1), fixed radius, a set searched in itself: the group formulation (tnsx_query_group.hip)
-			// in front of the cell kernels, unless it was switched off for this pair
-			pr.groups_now = !sparse && !variable && jb.i == jb.j && c->opt.query_formulation == 1 && tnsx_query_formulation_available(1) != 0 && !pr.groups_off &&
-			                c->grid_h * c->grid_h > 1e-30f;
-			qc.groups = pr.groups_now;
-			if (pr.groups_now) { HIPCHK(c, pr.filtered.reserve((size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pr.n_i, n_cells)) * sizeof(uint2))); tiers = 3; }
-			qc.tiers = tiers;
-			tnsx::launch_query(make_args(jb, pr, k), qc, c->n_cus, st);
-			qc.groups = false; qc.tiers = 3;
-		}
-		pr.heavy_skipped = !(tiers & 2);
-		const int t1 = tm.mark();
-		span(ST_FILL, t0, t1);
-		uint32_t* const h_count = (pr.shared_empty && !sparse) ? h_filt + k : (pr.groups_now && pr.n_i > 0 ? h_left + k : nullptr);   // (the two worklists share a counter, see make_args)
-		if (defer_readback && run_end.n_jobs < tnsx::RUN_END_MAX_JOBS) {
-			tnsx::RunEndJob& rj = run_end.job[run_end.n_jobs++];
-			rj.ctrl_cursor = ctrl_slot(k, tnsx::CTRL_CURSOR); rj.h_ctrl = reinterpret_cast<unsigned long long*>(h_ctrl + HC * k);
-			rj.d_count = ctrl_slot(k, tnsx::CTRL_NFILTERED); rj.h_count = h_count;
-			rj.d_heavy = ctrl_slot(k, tnsx::CTRL_NHEAVY); rj.h_heavy = h_heavy + k;
-			return TNSX_OK;
-		}
-		HIPCHK(c, hipMemcpy2DAsync(h_ctrl + HC * k, tnsx::POOL_CTRL_WORDS * sizeof(uint64_t), ctrl_slot(k, tnsx::CTRL_CURSOR), tnsx::CTRL_STRIDE_U32 * sizeof(uint32_t),
-		                           tnsx::POOL_CTRL_WORDS * sizeof(uint64_t), PairResult::NR, hipMemcpyDeviceToHost, st));
-		if (h_count) HIPCHK(c, hipMemcpyAsync(h_count, ctrl_slot(k, tnsx::CTRL_NFILTERED), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-		HIPCHK(c, hipMemcpyAsync(h_heavy + k, ctrl_slot(k, tnsx::CTRL_NHEAVY), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-		return TNSX_OK;
-	};
-
-	t_build1 = tm.mark();
-	span(ST_SORT, t_build0, t_build1);
+	// (stage times: the build is everything from the first launch of the attempt to here -- table clear and control blocks included; no event
+	//  between its kernels, every event record between two kernels is a bubble of 6-9 us)
+	const int t_build1 = tm.mark();
+	span(ST_SORT, run.t_build0, t_build1);
 	for (size_t k = 0; k < jobs.size(); k++) {
-		Job& jb = jobs[k];
-		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
+		RunJob& jb = jobs[k];
+		PairResult& pr = run.pair(jb);
 		const int n_i = pr.n_i;
 		if (jb.pool) {
 			// the heavy tiers (cells with more than 512 candidates or more than 64 query points) are not launched when the previous run of the
 			// pair had nothing for them: what the first tier passes on is counted, and they run after the synchronisation if it did
 			const bool light = speculate && !pr.dry && pr.heavy_known && pr.heavy_cells == 0;
-			const tnsx_status r = launch_pool(k, light ? 1 : 3, false);
+			const tnsx_status r = launch_pool_pass(run, k, light ? 1 : 3, false);
 			if (r != TNSX_OK) return r;
 		}
 		else {
 			const int t0 = tm.mark();
 			if (n_i > 0) {
 				qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_COUNT;
-				tnsx::launch_query(make_args(jb, pr, k), qc, c->n_cus, st);
+				tnsx::launch_query(make_query_args(run, jb, pr, k), qc, c->n_cus, st);
 			}
 			const int t1 = tm.mark();
 			tnsx::exclusive_scan_u32_to_u64(pr.counts.as<uint32_t>(), pr.offs_sorted.as<uint64_t>(), (size_t)n_i, c->scan_temp.p, st);
@@ -1233,6 +1310,12 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	run_end.words = d_words; run_end.h_words = reinterpret_cast<unsigned long long*>(h_words); run_end.n_words = WB * (size_t)(n_sets + 1);
 	tnsx::launch_run_end(run_end, st);
 	defer_readback = false;
+	return TNSX_OK;
+}
+
+static tnsx_status judge_attempt(RunAttempt& run, bool* redo)
+{
+	TNSX_RUN_ALIASES;
 	{ const tnsx_status r = sync_stream(c); if (r != TNSX_OK) return r; }   // record totals / pool cursors / what was speculated on are needed on the host
 
 	// ---- were the assumptions of this attempt right?
@@ -1261,102 +1344,114 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 		if (!skipped[(size_t)si] && s.bk_now) { s.bk_gen = c->grid_gen; s.bk_n = s.n; }   // (this build wrote the windows of the next one)
 	}
 	if (wrong) { *redo = true; S.speculation_redos++; return TNSX_OK; }
+	return TNSX_OK;
+}
 
-	for (size_t k = 0; k < jobs.size(); k++) {
-		const Job& jb = jobs[k];
-		PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
-		uint64_t n_neighbors = 0;
-		if (jb.pool) {
-			// what every XCD produced: ints it asked for - ints it left unused.  The pass failed if a wave found both its own region and the
-			// overflow region full (or if it was a dry pass): size the pool by what was counted and redo this pair's pass.
-			const uint64_t* hc = h_ctrl + HC * k;
-			if (pr.heavy_skipped && h_heavy[k] != 0u) {
-				// the first tier did pass cells on after all: the two heavy tiers now, on the same control block
-				const tnsx_status r = launch_pool(k, 2, false);
-				if (r != TNSX_OK) return r;
-				HIPCHK(c, hipStreamSynchronize(st));
-				S.heavy_catchups++;
-			}
-			pr.heavy_cells = h_heavy[k]; pr.heavy_known = true;
-			uint64_t payload[PairResult::NR], asked_now[PairResult::NR];
-			auto read_counters = [&]() {
-				n_neighbors = 0;
-				for (int r = 0; r < PairResult::NR; r++) {
-					const uint64_t asked = hc[(size_t)r * tnsx::POOL_CTRL_WORDS];
-					asked_now[r] = asked;
-					// (the common region: what the heavy tiers asked for + what fast-tier waves were diverted to it, the latter counted in their
-					//  own region as well -- a harmless overestimate in the rare run where a region was full)
-					payload[r] = asked - std::min(asked, hc[(size_t)r * tnsx::POOL_CTRL_WORDS + tnsx::POOL_WASTE_WORD]);
-					n_neighbors += hc[(size_t)r * tnsx::POOL_CTRL_WORDS + tnsx::POOL_HITS_WORD];
-				}
-			};
-			read_counters();
-			for (int attempt = 0; !c->debug_nostore && (pr.dry || hc[(size_t)tnsx::POOL_OVERFLOW * tnsx::POOL_CTRL_WORDS] > pr.region_cap[tnsx::POOL_OVERFLOW]); attempt++) {
-				if (attempt >= 5) TNSX_FAIL(c, TNSX_ERR_HIP, "neighbour pool kept overflowing (%llu neighbours)", (unsigned long long)n_neighbors);
-				const bool was_dry = pr.dry;
-				if (pr.dry) { pr.dry = false; S.cold_passes++; }   // the dry pass counted everything: the real pass is sized exactly
-				else {
-#ifdef TNSX_BUILD_DEBUG_POOL
-					fprintf(stderr, "[tnsx] pool overflow pair %zu: overflow region asked %llu of %llu, slab %u n_i %d\n", k,
-					                                            (unsigned long long)hc[(size_t)tnsx::POOL_OVERFLOW * tnsx::POOL_CTRL_WORDS], (unsigned long long)pr.region_cap[tnsx::POOL_OVERFLOW], pr.pool_slab, pr.n_i);
-#endif
-					S.pool_retries++;
-				}
-				{ const tnsx_status r = size_pool(c, pr, payload, was_dry ? nullptr : asked_now, !was_dry, query_waves); if (r != TNSX_OK) return r; }
-				const tnsx_status r = launch_pool(k, 3, true);
-				if (r != TNSX_OK) return r;
-				HIPCHK(c, hipStreamSynchronize(st));
-				pr.heavy_cells = h_heavy[k];
-				read_counters();
-			}
-			pr.n_records = pr.shared_empty ? 1 : 0;
-			uint64_t sum = 0;
+// the outcome of the pass of pair k: its counters, the heavy tiers if they were left out and turn out to be needed, the repeat of a pass whose pool overflowed (or
+// that was a dry pass), the exact layout's fill pass
+static tnsx_status collect_pair(RunAttempt& run, size_t k)
+{
+	TNSX_RUN_ALIASES;
+	const RunJob& jb = jobs[k];
+	PairResult& pr = run.pair(jb);
+	uint64_t n_neighbors = 0;
+	if (jb.pool) {
+		// what every XCD produced: ints it asked for - ints it left unused.  The pass failed if a wave found both its own region and the
+		// overflow region full (or if it was a dry pass): size the pool by what was counted and redo this pair's pass.
+		const uint64_t* hc = h_ctrl + HC * k;
+		if (pr.heavy_skipped && h_heavy[k] != 0u) {
+			// the first tier did pass cells on after all: the two heavy tiers now, on the same control block
+			const tnsx_status r = launch_pool_pass(run, k, 2, false);
+			if (r != TNSX_OK) return r;
+			HIPCHK(c, hipStreamSynchronize(st));
+			S.heavy_catchups++;
+		}
+		pr.heavy_cells = h_heavy[k]; pr.heavy_known = true;
+		uint64_t payload[PairResult::NR], asked_now[PairResult::NR];
+		auto read_counters = [&]() {
+			n_neighbors = 0;
 			for (int r = 0; r < PairResult::NR; r++) {
-				pr.region_payload[r] = payload[r];
-				pr.region_asked[r] = asked_now[r];
-				sum += payload[r];
-				pr.region_used[r] = c->debug_nostore ? 0 : std::min<uint64_t>(hc[(size_t)r * tnsx::POOL_CTRL_WORDS], pr.region_cap[r]);
-				if (pr.region_used[r]) pr.n_records = std::max(pr.n_records, pr.region_base[r] + pr.region_used[r]);
+				const uint64_t asked = hc[(size_t)r * tnsx::POOL_CTRL_WORDS];
+				asked_now[r] = asked;
+				// (the common region: what the heavy tiers asked for + what fast-tier waves were diverted to it, the latter counted in their
+				//  own region as well -- a harmless overestimate in the rare run where a region was full)
+				payload[r] = asked - std::min(asked, hc[(size_t)r * tnsx::POOL_CTRL_WORDS + tnsx::POOL_WASTE_WORD]);
+				n_neighbors += hc[(size_t)r * tnsx::POOL_CTRL_WORDS + tnsx::POOL_HITS_WORD];
 			}
-			pr.need_hint = sum + 1;
-		}
-		else {
-			pr.n_records = h_ctrl[HC * k];
-			n_neighbors = pr.n_records - (uint64_t)pr.n_query;
-			pr.shared_empty = false;
-			for (int r = 0; r < PairResult::NR; r++) { pr.region_base[r] = 0; pr.region_used[r] = 0; }
-			pr.region_used[0] = pr.n_records;
-			HIPCHK(c, pr.records.reserve(std::max<uint64_t>(pr.n_records, 1) * sizeof(int)));
-			const int t0 = tm.mark();
-			if (pr.n_i > 0) {
-				qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_FILL;
-				tnsx::launch_query(make_args(jb, pr, k), qc, c->n_cus, st);
+		};
+		read_counters();
+		for (int attempt = 0; !c->debug_nostore && (pr.dry || hc[(size_t)tnsx::POOL_OVERFLOW * tnsx::POOL_CTRL_WORDS] > pr.region_cap[tnsx::POOL_OVERFLOW]); attempt++) {
+			if (attempt >= 5) TNSX_FAIL(c, TNSX_ERR_HIP, "neighbour pool kept overflowing (%llu neighbours)", (unsigned long long)n_neighbors);
+			const bool was_dry = pr.dry;
+			if (pr.dry) { pr.dry = false; S.cold_passes++; }   // the dry pass counted everything: the real pass is sized exactly
+			else {
+#ifdef TNSX_BUILD_DEBUG_POOL
+				fprintf(stderr, "[tnsx] pool overflow pair %zu: overflow region asked %llu of %llu, slab %u n_i %d\n", k,
+				                                            (unsigned long long)hc[(size_t)tnsx::POOL_OVERFLOW * tnsx::POOL_CTRL_WORDS], (unsigned long long)pr.region_cap[tnsx::POOL_OVERFLOW], pr.pool_slab, pr.n_i);
+#endif
+				S.pool_retries++;
 			}
-			const int t1 = tm.mark();
-			span(ST_FILL, t0, t1);
+			{ const tnsx_status r = size_pool(c, pr, payload, was_dry ? nullptr : asked_now, !was_dry, query_waves); if (r != TNSX_OK) return r; }
+			const tnsx_status r = launch_pool_pass(run, k, 3, true);
+			if (r != TNSX_OK) return r;
+			HIPCHK(c, hipStreamSynchronize(st));
+			pr.heavy_cells = h_heavy[k];
+			read_counters();
 		}
-		pr.n_neighbors = n_neighbors;
-		pr.valid = true;
-		S.n_queries += (uint64_t)pr.n_query;
-		S.n_neighbors += n_neighbors;
-		if (jb.pool) S.n_pool_pairs++;
-		S.n_filtered_cells += h_filt[k];
-		pr.n_cells_i = h_nocc[jb.i];
-		if (jb.pool && pr.groups_now) {
-			S.n_group_pairs++;
-			S.n_group_passed_cells += h_left[k];
-			// more than a quarter of the occupied cells passed on (dense cells, lists longer than the lanes' capacity): the cell kernels
-			// alone are the better tool for this pair
-			if ((uint64_t)h_left[k] * 4u > (uint64_t)h_nocc[jb.i] + 64u) pr.groups_off = true;
+		pr.n_records = pr.shared_empty ? 1 : 0;
+		uint64_t sum = 0;
+		for (int r = 0; r < PairResult::NR; r++) {
+			pr.region_payload[r] = payload[r];
+			pr.region_asked[r] = asked_now[r];
+			sum += payload[r];
+			pr.region_used[r] = c->debug_nostore ? 0 : std::min<uint64_t>(hc[(size_t)r * tnsx::POOL_CTRL_WORDS], pr.region_cap[r]);
+			if (pr.region_used[r]) pr.n_records = std::max(pr.n_records, pr.region_base[r] + pr.region_used[r]);
 		}
+		pr.need_hint = sum + 1;
 	}
+	else {
+		pr.n_records = h_ctrl[HC * k];
+		n_neighbors = pr.n_records - (uint64_t)pr.n_query;
+		pr.shared_empty = false;
+		for (int r = 0; r < PairResult::NR; r++) { pr.region_base[r] = 0; pr.region_used[r] = 0; }
+		pr.region_used[0] = pr.n_records;
+		HIPCHK(c, pr.records.reserve(std::max<uint64_t>(pr.n_records, 1) * sizeof(int)));
+		const int t0 = tm.mark();
+		if (pr.n_i > 0) {
+			qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_FILL;
+			tnsx::launch_query(make_query_args(run, jb, pr, k), qc, c->n_cus, st);
+		}
+		const int t1 = tm.mark();
+		span(ST_FILL, t0, t1);
+	}
+	pr.n_neighbors = n_neighbors;
+	pr.valid = true;
+	S.n_queries += (uint64_t)pr.n_query;
+	S.n_neighbors += n_neighbors;
+	if (jb.pool) S.n_pool_pairs++;
+	S.n_filtered_cells += h_filt[k];
+	pr.n_cells_i = h_nocc[jb.i];
+	if (jb.pool && pr.groups_now) {
+		S.n_group_pairs++;
+		S.n_group_passed_cells += h_left[k];
+		// more than a quarter of the occupied cells passed on (dense cells, lists longer than the lanes' capacity): the cell kernels
+		// alone are the better tool for this pair
+		if ((uint64_t)h_left[k] * 4u > (uint64_t)h_nocc[jb.i] + 64u) pr.groups_off = true;
+	}
+	return TNSX_OK;
+}
+
+static tnsx_status finish_run(RunAttempt& run)
+{
+	TNSX_RUN_ALIASES;
+	for (size_t k = 0; k < jobs.size(); k++) { const tnsx_status r = collect_pair(run, k); if (r != TNSX_OK) return r; }
 	for (int si = 0; si < n_sets; si++) S.n_occupied_cells += h_nocc[si];
 
 	// ---- optional: ascending order inside every record
 	if (c->opt.sorted_lists) {
 		const int t0 = tm.mark();
-		for (const Job& jb : jobs) {
-			PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
+		for (const RunJob& jb : jobs) {
+			PairResult& pr = run.pair(jb);
 			tnsx::launch_sort_records(pr.records.as<int>(), pr.offs_orig.as<uint64_t>(), pr.n_query, c->n_cus, st);
 		}
 		const int t1 = tm.mark();
@@ -1366,8 +1461,8 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	// ---- optional pinned host mirror (what get_neighborlist needs on the CPU side)
 	const int e_m0 = tm.mark();
 	if (c->opt.mirror_to_host) {
-		for (const Job& jb : jobs) {
-			PairResult& pr = c->pairs[(size_t)jb.i * n_sets + jb.j];
+		for (const RunJob& jb : jobs) {
+			PairResult& pr = run.pair(jb);
 			HIPCHK(c, pr.h_offs.reserve((size_t)std::max(pr.n_i, 1) * sizeof(uint64_t)));
 			HIPCHK(c, pr.h_records.reserve(std::max<uint64_t>(pr.n_records, 1) * sizeof(int)));
 			if (pr.n_query > 0) {
@@ -1391,16 +1486,30 @@ static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
 	}
 	if (c->opt.collect_stage_times) {
 		float acc[ST_N] = { 0 };
-		for (const Span& sp : spans) acc[sp.stage] += tm.ms(sp.a, sp.b);
+		for (const RunSpan& sp : run.spans) acc[sp.stage] += tm.ms(sp.a, sp.b);
 		S.ms_upload = acc[ST_UPLOAD]; S.ms_bounds = acc[ST_BOUNDS]; S.ms_table_clear = acc[ST_KEYS]; S.ms_sort = acc[ST_SORT];
 		S.ms_cells = acc[ST_CELLS]; S.ms_count = acc[ST_COUNT]; S.ms_scan = acc[ST_SCAN];
 		S.ms_fill = acc[ST_FILL]; S.ms_mirror = acc[ST_MIRROR]; S.ms_sort_lists = acc[ST_SORT_LISTS];
-		S.ms_total = tm.ms(e_begin, e_end);
+		S.ms_total = tm.ms(run.e_begin, e_end);
 	}
 	c->ran = true;
 	c->cells_valid = true;
 	return TNSX_OK;
 }
+
+// one attempt: speculate = the previous run's grid and the sets that did not change are taken over unseen and verified on the device while the attempt
+// proceeds; *redo = an assumption was wrong (the caller repeats the run without speculation)
+static tnsx_status run_once(tnsx_context* c, bool speculate, bool* redo)
+{
+	*redo = false;
+	RunAttempt run(c, speculate);
+	{ const tnsx_status r = plan_run(run); if (r != TNSX_OK) return r; }
+	{ const tnsx_status r = launch_build(run); if (r != TNSX_OK) return r; }
+	{ const tnsx_status r = launch_queries(run); if (r != TNSX_OK) return r; }
+	{ const tnsx_status r = judge_attempt(run, redo); if (r != TNSX_OK || *redo) return r; }
+	return finish_run(run);
+}
+
 
 tnsx_status tnsx_run_scalar(tnsx_context* c)
 {

@@ -135,6 +135,7 @@ struct LocalGroup {
 	uint64_t ar_gen = 0;
 	std::vector<uint32_t> ar_acc;
 	int refs = 0;
+	double host_wait_s = 120.0;                // bound of every host-side wait for a peer (tnsx_slab_set_watchdog of any slab on this group sets it)
 };
 struct LocalTransport { LocalGroup* g; int rank; };
 
@@ -156,6 +157,16 @@ int local_exchange(void* user, int rank, int world, const tnsx_slab_op* ops, int
 		g->box[(size_t)rank * world + ops[k].peer].push_back({ ops[k].send, ops[k].send_bytes, e.ready, &e.done, &e.consumed });
 		g->cv.notify_all();
 	}
+	// (a wait that timed out: the messages this rank posted and nobody took are withdrawn -- they point into this frame)
+	auto give_up = [&]() {
+		std::lock_guard<std::mutex> lk(g->mu);
+		for (int k = 0; k < n_ops; k++) {
+			if (!ops[k].send_bytes) continue;
+			auto& q = g->box[(size_t)rank * world + ops[k].peer];
+			for (auto it = q.begin(); it != q.end();) { if (it->consumed == &sent[(size_t)k].consumed) it = q.erase(it); else ++it; }
+		}
+		return 3;   // timed out
+	};
 	// 2. take every message addressed to this rank, in the order of the ops
 	int rc = 0;
 	for (int k = 0; k < n_ops; k++) {
@@ -164,7 +175,8 @@ int local_exchange(void* user, int rank, int world, const tnsx_slab_op* ops, int
 		{
 			std::unique_lock<std::mutex> lk(g->mu);
 			auto& q = g->box[(size_t)ops[k].peer * world + rank];
-			g->cv.wait(lk, [&] { return !q.empty(); });
+			// (bounded: a peer that never posts its message must not hang this thread for ever -- the slab layer's claim that every wait of a step is bounded)
+			if (!g->cv.wait_for(lk, std::chrono::duration<double>(g->host_wait_s), [&] { return !q.empty(); })) { lk.unlock(); return give_up(); }
 			m = q.front();
 			q.pop_front();
 		}
@@ -184,7 +196,7 @@ int local_exchange(void* user, int rank, int world, const tnsx_slab_op* ops, int
 		if (!ops[k].send_bytes) continue;
 		{
 			std::unique_lock<std::mutex> lk(g->mu);
-			g->cv.wait(lk, [&] { return e.consumed; });
+			if (!g->cv.wait_for(lk, std::chrono::duration<double>(g->host_wait_s), [&] { return e.consumed; })) { lk.unlock(); return give_up(); }
 		}
 		if (e.done) { if (hipStreamWaitEvent(s, e.done, 0) != hipSuccess) rc = rc ? rc : 1; }
 		// (events are destroyed by their users: `ready` by the sender once consumed, `done` by the sender after the wait was enqueued)
@@ -203,7 +215,8 @@ int local_allreduce(void* user, int, int world, void* buf, int count, int op, vo
 	std::vector<uint32_t> result;
 	{
 		std::unique_lock<std::mutex> lk(g->mu);
-		g->cv.wait(lk, [&] { return g->ar_left == 0; });             // the previous reduction has been read by everybody
+		const auto bound = std::chrono::duration<double>(g->host_wait_s);
+		if (!g->cv.wait_for(lk, bound, [&] { return g->ar_left == 0; })) return 3;   // the previous reduction has been read by everybody (3: timed out)
 		if (g->ar_arrived == 0) g->ar_acc = mine;
 		else for (int i = 0; i < count; i++) {
 			uint32_t& a = g->ar_acc[(size_t)i];
@@ -216,7 +229,7 @@ int local_allreduce(void* user, int, int world, void* buf, int count, int op, vo
 		}
 		const uint64_t gen = g->ar_gen;
 		if (++g->ar_arrived == world) { g->ar_arrived = 0; g->ar_left = world; g->ar_gen++; g->cv.notify_all(); }
-		else g->cv.wait(lk, [&] { return g->ar_gen != gen; });
+		else if (!g->cv.wait_for(lk, bound, [&] { return g->ar_gen != gen; })) { g->ar_arrived--; return 3; }   // (a rank that never came: this one withdraws)
 		result = g->ar_acc;
 		if (--g->ar_left == 0) g->cv.notify_all();
 	}
@@ -249,6 +262,9 @@ struct DBuf {
 		return true;
 	}
 	template <typename T> T* as() const { return static_cast<T*>(p); }
+	// after a watchdog timeout on a transport that cannot abort: the stream may still read or write this memory whenever it drains (and hipFree would block on
+	// it): the buffer is deliberately leaked instead of freed under the stream's feet
+	void abandon() { p = nullptr; cap = 0; }
 };
 struct SetState {
 	int set_id = -1;
@@ -687,7 +703,7 @@ tnsx_status tnsx_slab_step(tnsx_slab* s, int n_sets, const float* const* xyz, co
 				ops.push_back({ peer_of(s, side), st.send[side].p, ((size_t)st.cap_s[side] + 1) * W * 4, st.recv[side].p, ((size_t)st.cap_r[side] + 1) * W * 4 });
 			}
 		}
-		if (do_exchange(s, ops)) return sfail(s, TNSX_ERR_HIP, "halo exchange failed (transport)");
+		if (const int xrc = do_exchange(s, ops)) return sfail(s, xrc == 3 ? TNSX_ERR_TIMEOUT : TNSX_ERR_HIP, "halo exchange failed (transport)");
 		for (int k = 0; k < n_sets; k++) {
 			SetState& st = s->sets[(size_t)k];
 			const uint32_t rows[2] = { side_on[0] ? st.cap_r[0] : 0u, side_on[1] ? st.cap_r[1] : 0u };
@@ -729,7 +745,7 @@ tnsx_status tnsx_slab_step(tnsx_slab* s, int n_sets, const float* const* xyz, co
 						                in_over ? (void*)(st.recv[side].as<float>() + W) : nullptr, in_over ? (size_t)st.n_in[side] * W * 4 : 0 });
 				}
 			}
-			if (do_exchange(s, fix)) return sfail(s, TNSX_ERR_HIP, "halo exchange failed (transport, repair round)");
+			if (const int xrc = do_exchange(s, fix)) return sfail(s, xrc == 3 ? TNSX_ERR_TIMEOUT : TNSX_ERR_HIP, "halo exchange failed (transport, repair round)");
 			SHIP(s, hipMemsetAsync(s->d_small.p, 0, (size_t)n_sets * 8 * 4, s->stream));
 			for (int k = 0; k < n_sets; k++) {
 				SetState& st = s->sets[(size_t)k];
@@ -760,7 +776,7 @@ tnsx_status tnsx_slab_step(tnsx_slab* s, int n_sets, const float* const* xyz, co
 				ops.push_back({ peer_of(s, side), st.send[side].p, 4, st.recv[side].p, 4 });
 			}
 		}
-		if (do_exchange(s, ops)) return sfail(s, TNSX_ERR_HIP, "halo exchange failed (transport, counts)");
+		if (const int xrc = do_exchange(s, ops)) return sfail(s, xrc == 3 ? TNSX_ERR_TIMEOUT : TNSX_ERR_HIP, "halo exchange failed (transport, counts)");
 		for (int k = 0; k < n_sets; k++) for (int side = 0; side < 2; side++) if (side_on[side])
 			SHIP(s, hipMemcpyAsync(small_dev(s, (size_t)k) + 2 + side, s->sets[(size_t)k].recv[side].p, 4, hipMemcpyDeviceToDevice, s->stream));
 		SHIP(s, hipMemcpyAsync(s->h_small, s->d_small.p, (size_t)n_sets * 8 * 4, hipMemcpyDeviceToHost, s->stream));
@@ -777,7 +793,7 @@ tnsx_status tnsx_slab_step(tnsx_slab* s, int n_sets, const float* const* xyz, co
 					                st.n_in[side] ? (void*)(st.recv[side].as<float>() + W) : nullptr, (size_t)st.n_in[side] * W * 4 });
 			}
 		}
-		if (do_exchange(s, ops)) return sfail(s, TNSX_ERR_HIP, "halo exchange failed (transport, rows)");
+		if (const int xrc = do_exchange(s, ops)) return sfail(s, xrc == 3 ? TNSX_ERR_TIMEOUT : TNSX_ERR_HIP, "halo exchange failed (transport, rows)");
 		for (int k = 0; k < n_sets; k++) {
 			SetState& st = s->sets[(size_t)k];
 			const uint32_t rows[2] = { side_on[0] ? st.n_in[0] : 0u, side_on[1] ? st.n_in[1] : 0u };
@@ -840,6 +856,8 @@ tnsx_status tnsx_slab_set_watchdog(tnsx_slab* s, double seconds)
 {
 	if (!s) return TNSX_ERR_INVALID;
 	s->watchdog_s = seconds;
+	// (the in-process transport waits for its peers on the host: the same bound)
+	if (s->tr.exchange == local_exchange && s->tr.user) static_cast<LocalTransport*>(s->tr.user)->g->host_wait_s = seconds > 0.0 ? seconds : 1.0e9;
 	return TNSX_OK;
 }
 
@@ -852,7 +870,14 @@ struct tnsx_slab_redist {
 	hipStream_t stream = nullptr;
 	int device = 0;
 };
+static double g_redistribute_watchdog_s = 120.0;
 extern "C" {
+
+tnsx_status tnsx_slab_set_redistribute_watchdog(double seconds)
+{
+	g_redistribute_watchdog_s = seconds;   // (<= 0: wait for ever)
+	return TNSX_OK;
+}
 
 tnsx_status tnsx_slab_redistribute_begin(tnsx_context* engine, const tnsx_slab_transport* tr, int rank, int world, const float* cuts, const float* xyz,
                                          const long long* gids, const float* radii, int n_points, tnsx_slab_redist** out, int* n_owned)
@@ -867,7 +892,7 @@ tnsx_status tnsx_slab_redistribute_begin(tnsx_context* engine, const tnsx_slab_t
 	if (!stream) return fail(TNSX_ERR_STATE, "multi-device contexts shard host data themselves");
 	if (hipSetDevice(device) != hipSuccess) return fail(TNSX_ERR_HIP, "hipSetDevice failed");
 	const int W = radii ? 6 : 5;
-	const double watchdog = 120.0;
+	const double watchdog = g_redistribute_watchdog_s;   // (tnsx_slab_set_redistribute_watchdog; default 120 s)
 	// ---- how many of my points go where
 	DBuf d_small;   // [0, world) send counts = scatter cursors, [world, 2 world) first row of every destination, [2 world, 3 world) receive counts
 	if (!d_small.reserve((size_t)3 * world * 4)) return fail(TNSX_ERR_HIP, "out of device memory");
@@ -883,7 +908,12 @@ tnsx_status tnsx_slab_redistribute_begin(tnsx_context* engine, const tnsx_slab_t
 	    hipMemcpyAsync(h_rcnt.data(), d_rcnt, (size_t)world * 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return fail(TNSX_ERR_HIP, "copy of the counts failed");
 	{
 		const int w = wait_stream(stream, watchdog);
-		if (w == 2) { if (tr && tr->abort) tr->abort(tr->user); return fail(TNSX_ERR_TIMEOUT, "the exchange of the counts did not complete within 120 s (a rank that never called, or a transport that does not reach every pair of ranks)"); }
+		if (w == 2) {
+			// (with an abort hook the pending operations return and the stream drains; without one -- in-process, host-staged, an application's own transport -- the
+			//  stream may still be stuck, or complete later: the buffers it may touch are leaked, not freed)
+			if (tr && tr->abort) tr->abort(tr->user); else d_small.abandon();
+			return fail(TNSX_ERR_TIMEOUT, "the exchange of the counts did not complete within the watchdog's time (a rank that never called, or a transport that does not reach every pair of ranks)");
+		}
 		if (w == 1) return fail(TNSX_ERR_HIP, "HIP error while exchanging the counts");
 	}
 	h_rcnt[(size_t)rank] = h_cnt[(size_t)rank];   // my own share stays
@@ -912,7 +942,11 @@ tnsx_status tnsx_slab_redistribute_begin(tnsx_context* engine, const tnsx_slab_t
 	if (!ops.empty() && tr->exchange(tr->user, rank, world, ops.data(), (int)ops.size(), stream)) { delete r; return fail(TNSX_ERR_HIP, "exchange of the rows failed (transport)"); }
 	{
 		const int w = wait_stream(stream, watchdog);   // (the send buffer is released below)
-		if (w == 2) { if (tr && tr->abort) tr->abort(tr->user); delete r; return fail(TNSX_ERR_TIMEOUT, "the exchange of the rows did not complete within 120 s"); }
+		if (w == 2) {
+			if (tr && tr->abort) { tr->abort(tr->user); delete r; }
+			else { d_small.abandon(); send.abandon(); r->rows.abandon(); delete r; }   // (see above: leaked on purpose)
+			return fail(TNSX_ERR_TIMEOUT, "the exchange of the rows did not complete within the watchdog's time");
+		}
 		if (w == 1) { delete r; return fail(TNSX_ERR_HIP, "HIP error while exchanging the rows"); }
 	}
 	*out = r;
