@@ -755,9 +755,12 @@ static void launch_zsort_pairs(const float* xyz, int n, GridParams g, int key_bi
 	}
 }
 
+#ifndef TNSX_ZS_PAIRS_FROM
+#define TNSX_ZS_PAIRS_FROM 25   // keys of this many bits and more take the pair sort; 16 .. 24 bits: one ranked pass + k_morton_place (measured against each other: profiles/r5_zsort.txt)
+#endif
 int launch_morton_sort(const float* xyz, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, int* order_out, hipStream_t s)
 {
-	if (n >= (1 << 16) && key_bits >= 16 && key_bits <= 24) {
+	if (n >= (1 << 16) && key_bits >= 16 && key_bits <= 24 && key_bits < TNSX_ZS_PAIRS_FROM) {
 		int lo_bits = key_bits - CS_MAX_BITS;
 		lo_bits = lo_bits < 8 ? 8 : lo_bits;
 		const int hi_bits = key_bits - lo_bits;   // 8 .. 11
@@ -774,7 +777,7 @@ int launch_morton_sort(const float* xyz, int n, GridParams g, int key_bits, cons
 		hipLaunchKernelGGL(k_morton_place, dim3(1 << hi_bits), dim3(BP_THREADS), lds, s, b.xyzi[1], order_out, g, lo_bits, totals);
 		return 1;
 	}
-	if (n >= (1 << 16) && key_bits > 24 && key_bits <= 30) {   // round 5: {key, index} pairs through single-pass digit sorts (above)
+	if (n >= (1 << 16) && key_bits >= TNSX_ZS_PAIRS_FROM && key_bits <= 30) {   // round 5: {key, index} pairs through single-pass digit sorts (above)
 		launch_zsort_pairs(xyz, n, g, key_bits, b, temp, order_out, s);
 		return 1;
 	}
