@@ -591,17 +591,22 @@ __global__ void __launch_bounds__(ZS_KEY_THREADS) k_zs_keys(const float* __restr
 	for (int k = threadIdx.x; k < plan.passes * R; k += ZS_KEY_THREADS) part[(size_t)blockIdx.x * (ZS_MAX_PASSES * R) + k] = h[k];
 }
 // digit totals of every pass: column sums of the partial histograms (the exclusive scan over the digit values is done by every tile of k_zs_pass itself: 512
-// values).  A workgroup owns 64 digit values of one pass, four threads share a column.
-__global__ void __launch_bounds__(256) k_zs_totals(const uint32_t* __restrict__ part, int n_part, uint32_t* __restrict__ totals)
+// values).  A workgroup owns 64 digit values of one pass, sixteen threads share a column.
+__global__ void __launch_bounds__(1024) k_zs_totals(const uint32_t* __restrict__ part, int n_part, uint32_t* __restrict__ totals)
 {
 	constexpr int R = 1 << ZS_MAX_BITS;
-	__shared__ uint32_t red[4][64];
+	__shared__ uint32_t red[16][64];
 	const int p = blockIdx.y, d = blockIdx.x * 64 + (threadIdx.x & 63), kg = threadIdx.x >> 6;
 	uint32_t c = 0;
-	for (int k = kg; k < n_part; k += 4) c += part[(size_t)k * (ZS_MAX_PASSES * R) + p * R + d];
+	for (int k = kg; k < n_part; k += 16) c += part[(size_t)k * (ZS_MAX_PASSES * R) + p * R + d];
 	red[kg][threadIdx.x & 63] = c;
 	__syncthreads();
-	if (kg == 0) totals[p * R + d] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+	if (kg == 0) {
+		uint32_t t = 0;
+		#pragma unroll
+		for (int q = 0; q < 16; q++) t += red[q][threadIdx.x];
+		totals[p * R + d] = t;
+	}
 }
 template <int BITS, bool LAST>
 __global__ void __launch_bounds__(ZS_THREADS) k_zs_pass(const uint2* __restrict__ in, uint2* __restrict__ out, int* __restrict__ order_out, int n, int shift,
@@ -741,7 +746,7 @@ static void launch_zsort_pairs(const float* xyz, int n, GridParams g, int key_bi
 	(void)hipMemsetAsync(ticket, 0, (64 + (size_t)plan.passes * (size_t)tiles * R) * sizeof(uint32_t), s);
 	uint2* buf[2] = { reinterpret_cast<uint2*>(b.xyzi[0]), reinterpret_cast<uint2*>(b.xyzi[1]) };   // (the ping-pong arrays of the search structure: 16 bytes per point each)
 	hipLaunchKernelGGL(k_zs_keys, dim3(kgrid), dim3(ZS_KEY_THREADS), 0, s, xyz, n, g, pd, buf[0], part);
-	hipLaunchKernelGGL(k_zs_totals, dim3((unsigned)(R / 64), (unsigned)plan.passes), dim3(256), 0, s, part, kgrid, base);
+	hipLaunchKernelGGL(k_zs_totals, dim3((unsigned)(R / 64), (unsigned)plan.passes), dim3(1024), 0, s, part, kgrid, base);
 	int cur = 0;
 	for (int p = 0; p < plan.passes; p++) {
 		const bool last = p == plan.passes - 1;
