@@ -237,7 +237,8 @@ def dropin_mode(n, seed, arith_const):
         v = ns.pair_view(0, 0)
         out = {"ms_per_run": round(ms, 2), "value": round(n / ms / 1e3, 1), "unit": "Mpoints/s", "upload_ms": round(st["ms_upload"], 2),
                "device_ms": round(st["ms_total"] - st["ms_upload"] - st["ms_mirror"], 2), "mirror_ms": round(st["ms_mirror"], 2),
-               "mirror_gb": round(v.n_records * 4 / 1e9, 2), "mirror_gbs": round(v.n_records * 4 / 1e6 / max(st["ms_mirror"], 1e-9), 1),
+               "mirror_gb": round(((v.n_neighbors + v.n_points) * 4 + v.n_points * 8) / 1e9, 2), "pool_on_device_gb": round(v.n_records * 4 / 1e9, 2),
+               "mirror_gbs": round(((v.n_neighbors + v.n_points) * 4 + v.n_points * 8) / 1e6 / max(st["ms_mirror"], 1e-9), 1),
                "note": "host pointers in, lists in pinned host memory out (the reference's calling convention through include/TreeNSearch): bound by "
                        "ONE PCIe link moving the records; never `value`"}
         del ns

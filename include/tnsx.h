@@ -119,7 +119,9 @@ typedef struct tnsx_csr_view {
 	uint64_t n_neighbors;            /* total neighbour indices */
 	const uint64_t* offsets_device;  /* [n_points] by ORIGINAL point index, HBM */
 	const int* records_device;       /* [n_records], HBM */
-	const uint64_t* offsets_host;    /* pinned host mirrors, NULL unless mirrored */
+	const uint64_t* offsets_host;    /* pinned host mirror, NULL unless mirrored.  Round 5: the mirror is a GAP-FREE copy in point order -- n_neighbors + n_points ints,
+	                                    records_host[offsets_host[p]] = count of point p followed by its indices, the record of point p + 1 right behind it -- so these
+	                                    offsets are NOT the device offsets (the device records keep the pool's layout, holes included) */
 	const int* records_host;
 } tnsx_csr_view;
 

@@ -30,4 +30,4 @@ if devices and len(devices) > 1:
           f"into one pinned buffer, slowest engine {st['ms_total']:.2f} ms of device work + upload")
 else:
     print(f"drop-in mode ({os.path.basename(A.LIB_PATH)}): {ms:.2f} ms per run() = {n / ms / 1e3:.1f} Mpoints/s; upload {st['ms_upload']:.2f} ms, device work {st['ms_total'] - st['ms_upload'] - st['ms_mirror']:.2f} ms, "
-          f"mirror of {v.n_records * 4 / 1e9:.2f} GB {st['ms_mirror']:.2f} ms")
+          f"mirror of {((v.n_neighbors + v.n_points) * 4 + v.n_points * 8) / 1e9:.2f} GB (gap-free records + offsets; the pool on the device: {v.n_records * 4 / 1e9:.2f} GB) {st['ms_mirror']:.2f} ms")

@@ -218,7 +218,9 @@ __global__ void __launch_bounds__(SB_THREADS) k_cs_strip_scan(uint32_t* __restri
 // picked up by original index -- carrying it through every pass costs a scattered 4-byte store per point and pass, the expensive
 // kind (measured at 20 M points, two passes: sort 0.77 ms carried, 0.68 ms gathered).
 template <int BITS, bool FIRST, bool VARIABLE, bool MORTON>
-__global__ void __launch_bounds__(CS_THREADS) __attribute__((amdgpu_waves_per_eu(BITS <= 10 ? 4 : 3, 4)))
+// (three waves per SIMD allowed: at four, the sixteen register-resident points of a thread + their ranks leave the compiler 16 - 52 bytes of scratch per lane in some
+//  instantiations; the kernel waits for its scattered stores, not for issue slots -- round 5: scratch 0 for every instantiation)
+__global__ void __launch_bounds__(CS_THREADS) __attribute__((amdgpu_waves_per_eu(3, 4)))
 k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, const float4* __restrict__ xyzi_in, const float* __restrict__ r2_in,
              float4* __restrict__ xyzi_out, float* __restrict__ r2_out, int n, GridParams g, int shift, const uint32_t* __restrict__ hist_scanned,
              const uint32_t* __restrict__ totals, int ntiles, const int* __restrict__ ids, uint32_t* __restrict__ orig_out, BuildGuard gd)
@@ -234,7 +236,6 @@ k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, con
 	if (tile >= ntiles) return;
 
 	float px[CS_ITEMS], py[CS_ITEMS], pz[CS_ITEMS], pw[CS_ITEMS];   // (scalar arrays: a float4 array ends up in scratch)
-	float rr[CS_ITEMS];
 	bool bad_r = false;
 	// this wave's CS_ITEMS*64 consecutive elements: wave-uniform 64-bit base + 32-bit lane offsets (scalar-base addressing)
 	const size_t wbase = (size_t)tile * CS_TILE + (size_t)w * (CS_ITEMS * WAVE);
@@ -249,20 +250,12 @@ k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, con
 		if (FIRST) {
 			const F3 q = (reinterpret_cast<const F3*>(xyz) + lbase)[lc];
 			px[i] = q.x; py[i] = q.y; pz[i] = q.z; pw[i] = __uint_as_float((uint32_t)wbase + li);
-			if (VARIABLE) { const float r = (radii + lbase)[lc]; rr[i] = __fmul_rn(r, r); bad_r |= (r > gd.r_max) & (q.x == q.x); }   // single pass: index = position; the radius of a NaN x (no point) counts for nothing
 		}
 		else {
 			const float4 q = (xyzi_in + lbase)[lc];
 			px[i] = q.x; py[i] = q.y; pz[i] = q.z; pw[i] = q.w;
 		}
 	}
-	if (VARIABLE && !FIRST) {
-		// gather by original index (the radii array of a 50 M-point set is 200 MB: it stays in the 256 MB Infinity Cache)
-		#pragma unroll
-		for (int i = 0; i < CS_ITEMS; i++) { const float r = radii[__float_as_uint(pw[i])]; rr[i] = __fmul_rn(r, r); bad_r |= (r > gd.r_max) & (px[i] == px[i]); }
-	}
-	// (speculated grid: a radius above the one the cell edge was chosen for -> the host repeats the run with fresh bounds)
-	if (VARIABLE && gd.flag && __builtin_amdgcn_ballot_w64(bad_r) != 0ull && lane == 0) atomicOr(gd.flag, 1u);
 
 	// global base of every digit value for this tile = (exclusive scan of the totals) + (scanned tile count).  Thread t owns the
 	// PER consecutive values [t*PER, t*PER + PER).
@@ -321,22 +314,43 @@ k_cs_scatter(const float* __restrict__ xyz, const float* __restrict__ radii, con
 		for (int ww = 0; ww < CS_WAVES; ww++) { const uint32_t t = wcount[ww][b]; wcount[ww][b] = s; s += t; }
 	}
 	__syncthreads();
+	// The radii are picked up HERE, eight at a time, by original index (the radii array of a 50 M-point set is 200 MB: it stays in the 256 MB Infinity Cache; a single
+	// pass: index = position, a coalesced load) -- not with the points at the top of the kernel: sixteen more registers alive through the ranking were what made
+	// every VARIABLE instantiation spill 150 - 200 bytes per lane at four waves per SIMD (round 5: scratch 0).
+	constexpr int RB = 8;
 	#pragma unroll
-	for (int i = 0; i < CS_ITEMS; i++) {
-		if ((uint32_t)(i * WAVE + lane) < rem) {
-			const uint32_t pos = wcount[w][dig_rank[i] & 0xffffu] + (dig_rank[i] >> 16);
-			float wv = pw[i];
-			if (ids) {
-				// last pass of a set with user ids (tnsx_set_point_ids): the point carries its ID from here on -- that is what the
-				// query emits -- and its original index goes to a side array (the query needs it for the queries only)
-				const uint32_t o = __float_as_uint(wv);
-				wv = __int_as_float(ids[o]);
-				orig_out[pos] = o;
+	for (int i0 = 0; i0 < CS_ITEMS; i0 += RB) {
+		float rr[RB];
+		if (VARIABLE) {
+			#pragma unroll
+			for (int u = 0; u < RB; u++) {
+				const int i = i0 + u;
+				const uint32_t li = (uint32_t)(i * WAVE + lane);
+				const float r = FIRST ? (radii + lbase)[li < lclamp ? li : lclamp] : radii[__float_as_uint(pw[i])];
+				rr[u] = __fmul_rn(r, r);
+				bad_r |= (r > gd.r_max) & (px[i] == px[i]);   // (the radius of a NaN x -- no point -- counts for nothing)
 			}
-			xyzi_out[pos] = make_float4(px[i], py[i], pz[i], wv);
-			if (VARIABLE) r2_out[pos] = rr[i];
+		}
+		#pragma unroll
+		for (int u = 0; u < RB; u++) {
+			const int i = i0 + u;
+			if ((uint32_t)(i * WAVE + lane) < rem) {
+				const uint32_t pos = wcount[w][dig_rank[i] & 0xffffu] + (dig_rank[i] >> 16);
+				float wv = pw[i];
+				if (ids) {
+					// last pass of a set with user ids (tnsx_set_point_ids): the point carries its ID from here on -- that is what the
+					// query emits -- and its original index goes to a side array (the query needs it for the queries only)
+					const uint32_t o = __float_as_uint(wv);
+					wv = __int_as_float(ids[o]);
+					orig_out[pos] = o;
+				}
+				xyzi_out[pos] = make_float4(px[i], py[i], pz[i], wv);
+				if (VARIABLE) r2_out[pos] = rr[u];
+			}
 		}
 	}
+	// (speculated grid: a radius above the one the cell edge was chosen for -> the host repeats the run with fresh bounds)
+	if (VARIABLE && gd.flag && __builtin_amdgcn_ballot_w64(bad_r) != 0ull && lane == 0) atomicOr(gd.flag, 1u);
 }
 
 template <int BITS, bool MORTON>

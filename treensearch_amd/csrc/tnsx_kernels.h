@@ -216,6 +216,10 @@ void launch_run_end(const RunEndArgs& a, hipStream_t s);
 // ---- ascending order inside every record of the first n_query points (tnsx_options.sorted_lists), in place
 void launch_sort_records(int* records, const uint64_t* offs_by_orig, int n_query, int n_cus, hipStream_t s);
 
+// ---- gap-free copy of a pair's records in point order (the host mirror): len[p] = count + 1; out[new_offs[p] ...] = the record of point p (new_offs: n + 1 entries)
+void launch_record_lengths(const int* records, const uint64_t* offs_by_orig, int n, uint32_t* len, hipStream_t s);
+void launch_compact_records(const int* records, const uint64_t* offs_by_orig, const uint64_t* new_offs, int n, int* out, hipStream_t s);
+
 // ---- permutation of byte records: out[new] = in[perm[new]] ------------------------------------------
 void launch_permute_bytes(const void* in, void* out, const int* new_to_old, int n, size_t rec_bytes, hipStream_t s);
 

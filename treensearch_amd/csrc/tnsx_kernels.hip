@@ -226,6 +226,60 @@ static void scan_impl(const uint32_t* in, TOut* out, size_t n, void* temp, hipSt
 void exclusive_scan_u32_to_u64(const uint32_t* in, uint64_t* out, size_t n, void* temp, hipStream_t s) { scan_impl<uint64_t>(in, out, n, temp, s, 1); }
 
 // =====================================================================================================
+// Gap-free copy of a pair's records in POINT order (round 5: the host mirror).  The record pool has holes (the unused ends of the waves' slabs: 10 % at C2) and
+// its records lie in the order the cells were served; the link to the host is what bounds the drop-in mode, so what crosses it is compacted first:
+// len[p] = count + 1 -> exclusive scan = the mirror's offsets -> every record copied to its place.  A wave owns 64 consecutive points; it walks their records
+// four at a time (the loads of four records in flight), 64 ints per lane round.
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_record_lengths(const int* __restrict__ records, const uint64_t* __restrict__ offs, int n, uint32_t* __restrict__ len)
+{
+	const int p = blockIdx.x * 256 + threadIdx.x;
+	if (p < n) len[p] = (uint32_t)records[offs[p]] + 1u;
+}
+__global__ void __launch_bounds__(256) k_compact_records(const int* __restrict__ records, const uint64_t* __restrict__ offs, const uint64_t* __restrict__ new_offs, int n,
+                                                         int* __restrict__ out)
+{
+	const int lane = lane_id();
+	const size_t wave = (size_t)blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
+	const size_t p0 = wave * WAVE;
+	if (p0 >= (size_t)n) return;
+	const size_t p = p0 + (size_t)lane < (size_t)n ? p0 + (size_t)lane : (size_t)n - 1;
+	const uint64_t src = offs[p], dst = new_offs[p];
+	const uint32_t len = (uint32_t)(new_offs[p + 1] - dst);
+	const int cnt = (int)((size_t)n - p0 < (size_t)WAVE ? (size_t)n - p0 : (size_t)WAVE);
+	for (int t0 = 0; t0 < cnt; t0 += 4) {
+		int v[4];
+		uint64_t d[4];
+		uint32_t l[4];
+		#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const int t = t0 + u < cnt ? t0 + u : cnt - 1;
+			const uint64_t s_t = ((uint64_t)readlane_u32((uint32_t)(src >> 32), t) << 32) | readlane_u32((uint32_t)src, t);
+			d[u] = ((uint64_t)readlane_u32((uint32_t)(dst >> 32), t) << 32) | readlane_u32((uint32_t)dst, t);
+			l[u] = t0 + u < cnt ? readlane_u32(len, t) : 0u;
+			v[u] = (uint32_t)lane < l[u] ? records[s_t + (uint32_t)lane] : 0;
+		}
+		#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			if ((uint32_t)lane < l[u]) out[d[u] + (uint32_t)lane] = v[u];
+			if (l[u] > (uint32_t)WAVE) {   // (a record longer than 64 ints: the rest, 64 at a time)
+				const int t = t0 + u;
+				const uint64_t s_t = ((uint64_t)readlane_u32((uint32_t)(src >> 32), t) << 32) | readlane_u32((uint32_t)src, t);
+				for (uint32_t k = (uint32_t)WAVE + (uint32_t)lane; k < l[u]; k += (uint32_t)WAVE) out[d[u] + k] = records[s_t + k];
+			}
+		}
+	}
+}
+void launch_record_lengths(const int* records, const uint64_t* offs, int n, uint32_t* len, hipStream_t s)
+{
+	if (n > 0) hipLaunchKernelGGL(k_record_lengths, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, records, offs, n, len);
+}
+void launch_compact_records(const int* records, const uint64_t* offs, const uint64_t* new_offs, int n, int* out, hipStream_t s)
+{
+	if (n > 0) hipLaunchKernelGGL(k_compact_records, dim3((unsigned)(((size_t)n + 255) / 256)), dim3(256), 0, s, records, offs, new_offs, n, out);
+}
+
+// =====================================================================================================
 // permutation of fixed-size byte records (device-side apply_zsort, TreeNSearch.h:465-480)
 // =====================================================================================================
 template <typename T>
