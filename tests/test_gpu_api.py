@@ -176,6 +176,14 @@ def test_get_neighborlist_and_for_each_neighbor(oracle):
         got = []
         ns.for_each_neighbor(0, 0, p, got.append)
         assert sorted(got) == idx[offs[p]:offs[p + 1]].tolist()
+    # round 5: the host mirror is a gap-free copy in POINT order (compacted on the device before it crosses the link): the record of point p + 1 starts right
+    # behind the record of point p, whatever the layout of the pool on the device
+    import ctypes as C
+    n = len(offs) - 1
+    ho = np.ctypeslib.as_array(C.cast(v.offsets_host, C.POINTER(C.c_uint64)), shape=(n,)).copy()
+    hr = np.ctypeslib.as_array(C.cast(v.records_host, C.POINTER(C.c_int32)), shape=(int(offs[-1]) + n,)).copy()
+    assert ho[0] == 0 and np.array_equal(np.diff(ho), np.diff(offs)[:-1] + 1), "host records must follow each other in point order without gaps"
+    assert np.array_equal(hr[ho], np.diff(offs)), "count words of the mirrored records"
     # memory in use by the lists (TreeNSearch.cpp:254-261 sums its chunk storage): the gap-free layout is exactly one count
     # word + the indices per point, the default record pool may add unused slab tails
     assert ns.get_neighborlist_n_bytes() >= 4 * (int(offs[-1]) + len(offs) - 1)
