@@ -1091,7 +1091,12 @@ static tnsx_status enqueue_run_begin(RunAttempt& run)
 			else {
 				const void* old_table = s.table.p;
 				HIPCHK(c, s.table.reserve(n_cells * sizeof(uint2)));
-				if (s.table.p != old_table || s.table_state == 2) HIPCHK(c, hipMemsetAsync(s.table.p, 0, s.table.cap, st));   // new or unknown: all of it
+				// (the list-based clear reads the PREVIOUS occupied-cell list inside k_run_begin; launch_build re-reserves that list for this run's build.  A list that
+				//  has to grow would be freed while the enqueued kernel may still read it -- correct today only because hipFree synchronises -- so a
+				//  set that outgrew its list clears the whole table instead and k_run_begin never sees the old list)
+				const bool occ_grows = ((size_t)std::max(s.n, 1) + 2) * sizeof(uint2) > s.occ.cap;
+				if (s.table.p != old_table || s.table_state == 2 || (occ_grows && s.table_state == 1 && s.table_dirty > 0))
+					HIPCHK(c, hipMemsetAsync(s.table.p, 0, s.table.cap, st));   // new or unknown: all of it
 				else if (s.table_state == 1 && s.table_dirty > 0) {
 					if (rb.n_clear < tnsx::RUN_BEGIN_MAX_SETS) rb.clear[rb.n_clear++] = { s.occ.as<uint2>(), s.table.as<uint2>(), s.table_dirty };
 					else tnsx::launch_table_clear(s.occ.as<uint2>(), s.table_dirty, s.table.as<uint2>(), st);
