@@ -306,18 +306,20 @@ def one_gpu_reference(n_total):
     """What the N-GPU figure of c5 is to be divided by: the SAME workload (all of its points, one slab, through tnsx_slab_step) on ONE GPU.  `bench.py --gpus 1`
     runs c2 (the N = 1 rule of the bench contract), so the number is quoted from the committed single-GPU run of c5 and labelled as such; `bench.py
     --workload c5 [--points N]` on one GPU reproduces it."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "bench_r4_c5_200m_1gpu.json")
+    here = os.path.dirname(os.path.abspath(__file__))
+    name = next((n for n in ("bench_r5_c5_200m_1gpu.json", "bench_r4_c5_200m_1gpu.json") if os.path.exists(os.path.join(here, "profiles", n))), "bench_r4_c5_200m_1gpu.json")
+    path = os.path.join(here, "profiles", name)
     try:
         with open(path) as f:
             ref = json.loads(f.read().strip().splitlines()[-1])
         if int(ref["config"]["points_total"]) != int(n_total):
-            return {"quoted": False, "note": f"no committed single-GPU run of c5 at {n_total} points (profiles/bench_r4_c5_200m_1gpu.json is at {ref['config']['points_total']}); "
+            return {"quoted": False, "note": f"no committed single-GPU run of c5 at {n_total} points (profiles/{name} is at {ref['config']['points_total']}); "
                                              "run `python bench.py --workload c5 --points N` on one GPU"}
-        return {"quoted": True, "source": "profiles/bench_r4_c5_200m_1gpu.json (builder-run on a 1-GPU box in round 4: another box, not this run)",
+        return {"quoted": True, "source": f"profiles/{name} (builder-run on a 1-GPU box: another box, not this run)",
                 "ms_per_step": ref["ms_per_step"], "value": ref["value"], "unit": ref["unit"],
                 "note": "speed-up at N GPUs = this line's value / this value (both: all points of the workload per step)"}
     except Exception as e:   # (the file is part of the repository; a checkout without profiles/ still gets its line)
-        return {"quoted": False, "note": f"profiles/bench_r4_c5_200m_1gpu.json not readable ({e})"}
+        return {"quoted": False, "note": f"profiles/{name} not readable ({e})"}
 
 
 def measured_copy_peak(torch):
