@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TNSX_VERSION 501
+#define TNSX_VERSION 600
 
 typedef struct tnsx_context tnsx_context;
 
@@ -103,8 +103,9 @@ typedef struct tnsx_options {
 	                             search radius as a SPARSE grid -- occupied-cell lists + block index, up to 2^32 cells -- instead of coarser cells; < 0: never
 	                             (coarsen the cells until a dense table fits, the behaviour of rounds 1-3) */
 	int query_formulation;    /* 0 = default: the cell kernels (candidates in the lanes).  1 = experiment of round 3, measured
-	                             SLOWER and since round 5 NOT in the default build of the library (tnsx_query_formulation_available;
-	                             build with TNSX_WITH_GROUP_FORMULATION=1): a fixed-radius search of a set in itself first runs the group formulation --
+	                             SLOWER (profiles/r3_group_formulation.txt) and NOT part of libtnsx.so (tnsx_query_formulation_available answers 0; its
+	                             source is tools/ubench/tnsx_query_group.hip, tools/build_group_variant.sh builds a variant of the library that carries
+	                             it): a fixed-radius search of a set in itself first runs the group formulation --
 	                             16 query points of a cell per batch in the lanes, the tests as 16x16x4 fp32 MFMAs with an exact re-test
 	                             inside the rounding band -- and the cell kernels take the cells it passes on; a pair that passes on more
 	                             than a quarter of its cells goes back to the cell kernels alone.  Results are identical either way */
@@ -121,7 +122,9 @@ typedef struct tnsx_csr_view {
 	const int* records_device;       /* [n_records], HBM */
 	const uint64_t* offsets_host;    /* pinned host mirror, NULL unless mirrored.  Round 5: the mirror is a GAP-FREE copy in point order -- n_neighbors + n_points ints,
 	                                    records_host[offsets_host[p]] = count of point p followed by its indices, the record of point p + 1 right behind it -- so these
-	                                    offsets are NOT the device offsets (the device records keep the pool's layout, holes included) */
+	                                    offsets are NOT the device offsets (the device records keep the pool's layout, holes included) .  A multi-device context
+	                                    (tnsx_options.n_devices > 1) keeps one region of records per slab in its host view: there n_records ints are valid and
+	                                    the offsets address them; read every list through its offset, never by walking the records front to back */
 	const int* records_host;
 } tnsx_csr_view;
 
@@ -168,6 +171,8 @@ typedef struct tnsx_stats {
 	int one_read_builds;          /* point sets whose bucket build read the input once in the last run (windows from the previous run) */
 	int heavy_catchups;           /* pool passes whose heavy tiers (cells with > 512 candidates or > 64 query points) were not launched with the first
 	                                 tier -- the previous run of the pair had no such cell -- and had to run after the run's synchronisation */
+	int nan_fixups;               /* pool passes of the last run after which query points that entered no cell (NaN x: "no point") had their offsets pointed
+	                                 at the pool's empty record (a pass whose records do not add up to neighbours + queries; never in a run without such points) */
 } tnsx_stats;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */
@@ -176,8 +181,9 @@ tnsx_status tnsx_create(const tnsx_options* opt /* may be NULL */, tnsx_context*
 void        tnsx_destroy(tnsx_context* ctx);                                               /* TreeNSearch.h:37 */
 const char* tnsx_last_error(const tnsx_context* ctx /* NULL: creation errors */);
 int         tnsx_version(void);
+int         tnsx_get_device(const tnsx_context* ctx);   /* HIP device ordinal the context's memory and stream live on (multi-device: the first slab's) */
 /* 1 when this build of the library carries the query formulation `f` of tnsx_options.query_formulation (0: always; 1: only when the library was
- * built with TNSX_WITH_GROUP_FORMULATION, see treensearch_amd/build.py), else 0.  Asking a context for a formulation its library does not carry is
+ * built with -DTNSX_WITH_GROUP_FORMULATION by tools/build_group_variant.sh -- never the product library), else 0.  Asking a context for a formulation its library does not carry is
  * not an error: the run uses formulation 0 (the results are identical by contract). */
 int         tnsx_query_formulation_available(int f);
 
@@ -223,6 +229,12 @@ tnsx_status tnsx_mirror_pair_to_host(tnsx_context* ctx, int set_i, int set_j);
 /* copies one pair's offsets / records into caller memory (host or device pointers, either may be NULL) */
 tnsx_status tnsx_copy_pair(tnsx_context* ctx, int set_i, int set_j, uint64_t* offsets_dst, int* records_dst,
                            int dst_on_device);
+/* The pair as a standard, gap-free CSR in point order, built on the device into caller-provided DEVICE memory ("CSR tensors
+ * out" -- what get_neighborlist, TreeNSearch.cpp:241-249, hands out one point at a time, for consumers that live on the GPU): offsets_out[p] ..
+ * offsets_out[p + 1] delimit the neighbours of point p in indices_out; n_points + 1 offsets, n_neighbors indices (tnsx_get_pair_view gives both
+ * numbers), no count words; the order inside a list is the records' order.  indices_out may be NULL (offsets = running neighbour counts only).
+ * Returns when the arrays are complete.  Single-device contexts only. */
+tnsx_status tnsx_pair_csr_device(tnsx_context* ctx, int set_i, int set_j, int64_t* offsets_out, int* indices_out);
 
 /* ---- z-sort (TreeNSearch.cpp:2571-2716, TreeNSearch.h:443-481) ---------------------------------- */
 tnsx_status tnsx_prepare_zsort(tnsx_context* ctx);

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(built_library):
 def test_version(built_library):
     from treensearch_amd import api
     L = api.load_library()
-    assert L.tnsx_version() == 501   # TNSX_VERSION of include/tnsx.h (round 5: tnsx_query_formulation_available; the group formulation behind a build flag)
+    assert L.tnsx_version() == 600   # TNSX_VERSION of include/tnsx.h (round 6: tnsx_pair_csr_device, tnsx_get_device, tnsx_stats.nan_fixups)
 
 
 def test_no_cpu_fallback(built_library):

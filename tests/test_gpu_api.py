@@ -577,3 +577,81 @@ def test_cloud_far_from_the_origin_hits_the_cell_limit_like_the_reference():
     assert e.value.status == 5 and "32768" in e.value.message
     ns.run_scalar()
     assert ns.get_stats()["world_cells_pow2"] <= 64
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# "data_ptr() in, CSR tensors out" -- device-side consumers of the lists
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["uniform_fixed_100000", "dam_break_sym_1000000", "two_set_asym_80000_20000", "edge_empty_and_tiny"])
+@pytest.mark.parametrize("exact_layout", [False, True])
+def test_torch_csr_out_equals_host_csr_and_golden(name, exact_layout, oracle):
+    """neighbor_csr_torch (gap-free CSR built on the device, tnsx_pair_csr_device) and neighbor_records_torch (zero-copy views of the engine's offsets /
+    records) against neighbor_csr (host) and the reference's fixture -- C1 and the 1 M-point dam break of configs[3], plus two sets and empty sets."""
+    import torch
+    case = CS.by_name(name)
+    ns = P.make_engine(case, 0, device_inputs=True, exact_layout=exact_layout)
+    ns.run()
+    res = {}
+    for pr in case.active:
+        h_offs, h_idx = ns.neighbor_csr(*pr)                       # host path, lists ascending
+        d_offs, d_idx = ns.neighbor_csr_torch(*pr, sort_each=True)
+        assert d_offs.is_cuda and d_idx.is_cuda and d_offs.dtype == torch.int64 and d_idx.dtype == torch.int32
+        assert np.array_equal(d_offs.cpu().numpy(), h_offs) and np.array_equal(d_idx.cpu().numpy(), h_idx), f"{name} {pr}: device CSR != host CSR"
+        res[pr] = (d_offs.cpu().numpy(), d_idx.cpu().numpy())
+        # the zero-copy record views: records[offsets[p]] = count, then the indices -- the same lists again, read on the device
+        offs, recs = ns.neighbor_records_torch(*pr)
+        v = ns.pair_view(*pr)
+        assert offs.numel() == v.n_points and recs.numel() == v.n_records
+        if v.n_points:
+            assert offs.data_ptr() == v.offsets_device and recs.data_ptr() == v.records_device, "views, not copies"
+            counts = recs[offs].to(torch.int64)
+            assert torch.equal(counts, d_offs[1:] - d_offs[:-1])
+            src = torch.repeat_interleave(offs + 1 - d_offs[:-1], counts) + torch.arange(int(d_offs[-1].item()), device="cuda", dtype=torch.int64)
+            unsorted_offs, unsorted_idx = ns.neighbor_csr_torch(*pr)
+            assert torch.equal(recs[src], unsorted_idx) and torch.equal(unsorted_offs, d_offs), "tnsx_pair_csr_device copies the records' own order"
+    P.assert_matches_golden(res, load_golden(case.name), 0, oracle, f"{name} torch CSR")
+    assert ns.get_stats()["nan_fixups"] == 0
+
+
+@pytest.mark.parametrize("mirror", [False, True])
+def test_nan_points_inside_the_query_range_have_empty_lists(mirror, oracle):
+    """A NaN x is "no point" (include/tnsx.h): it enters no cell, finds nothing and is found by nobody.  Scattered THROUGH the query range of a set searched in
+    itself (round-5 advice: no query kernel ever wrote such a point's offset, and the compaction of the host mirror followed it), every such point must
+    read as an EMPTY list -- through the device views, the device CSR and the gap-free host mirror -- and the others as if the NaN points did not exist."""
+    import torch
+    import treensearch_amd as T
+    from treensearch_amd import datagen as D
+    n = 60000
+    pts = D.uniform_cloud(n, 99)
+    r = D.radius_for_neighbors(n, 30.0)
+    rng = np.random.default_rng(11)
+    absent = np.sort(rng.choice(n, 300, replace=False))
+    real = np.setdiff1d(np.arange(n), absent)
+    bad = pts.copy()
+    bad[absent, 0] = np.nan
+    bad[absent[::2], 1] = np.float32(1.0e6)          # (whatever else such a row holds counts for nothing)
+    ro, ri = oracle.pair_search(np.ascontiguousarray(pts[real]), np.ascontiguousarray(pts[real]), radius=r, same_set=True)
+    want_counts = np.zeros(n, np.int64)
+    want_counts[real] = np.diff(ro)
+    want_offs = np.zeros(n + 1, np.int64)
+    want_offs[1:] = np.cumsum(want_counts)
+    want_idx = real[ri].astype(np.int32)              # (ascending inside every list: real is increasing)
+    ns = T.TreeNSearch(mirror_to_host=mirror)
+    ns.set_search_radius(r)
+    src = bad if mirror else torch.from_numpy(bad).cuda()
+    ns.add_point_set(src)
+    ns.set_active_search(0, 0, True)
+    for step in range(3):                             # the dry pass + sized pass, then two steady-state runs on the reused grid
+        ns.run()
+        assert ns.get_stats()["nan_fixups"] == 1, "the records of the pass do not add up to neighbours + queries: the stray offsets are pointed at the empty record"
+        offs, idx = ns.neighbor_csr(0, 0)
+        assert np.array_equal(offs, want_offs) and np.array_equal(idx, want_idx), f"run {step}"
+        d_offs, d_idx = ns.neighbor_csr_torch(0, 0, sort_each=True)
+        assert np.array_equal(d_offs.cpu().numpy(), want_offs) and np.array_equal(d_idx.cpu().numpy(), want_idx)
+        if mirror:
+            import ctypes as C
+            v = ns.pair_view(0, 0)
+            ho = np.ctypeslib.as_array(C.cast(v.offsets_host, C.POINTER(C.c_uint64)), shape=(n,))
+            hr = np.ctypeslib.as_array(C.cast(v.records_host, C.POINTER(C.c_int32)), shape=(int(want_offs[-1]) + n,))
+            assert np.array_equal(hr[ho], want_counts) and int(ho[-1]) + 1 + int(want_counts[-1]) == int(want_offs[-1]) + n
+            assert all(ns.get_neighborlist(0, 0, int(p)).size() == 0 for p in absent[:20])

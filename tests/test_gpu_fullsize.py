@@ -21,21 +21,12 @@ pytestmark = pytest.mark.gpu
 
 def _device_csr(ns, i, j):
     """(counts int64[n], owner int64[E], idx int64[E]) of pair (i, j) on the device; owner / idx are set-local indices"""
-    import ctypes as C
     import torch
-    v = ns.pair_view(i, j)
-    offs = torch.empty(max(v.n_points, 1), dtype=torch.int64, device="cuda")
-    recs = torch.empty(max(v.n_records, 1), dtype=torch.int32, device="cuda")
-    ns._check(ns._L.tnsx_copy_pair(ns._h, int(i), int(j), C.c_void_p(offs.data_ptr()), C.c_void_p(recs.data_ptr()), 1))
-    offs = offs[:v.n_points]
-    counts = recs[offs].to(torch.int64)
-    total = int(counts.sum().item())
-    assert total == v.n_neighbors
-    start = torch.cumsum(counts, 0) - counts
-    src = torch.repeat_interleave(offs + 1 - start, counts) + torch.arange(total, device="cuda", dtype=torch.int64)
-    idx = recs[src].to(torch.int64)
-    owner = torch.repeat_interleave(torch.arange(v.n_points, device="cuda", dtype=torch.int64), counts)
-    return counts, owner, idx
+    offs, idx = ns.neighbor_csr_torch(i, j)          # the device-side CSR of the public API (tnsx_pair_csr_device): nothing crosses the link
+    counts = offs[1:] - offs[:-1]
+    assert int(offs[-1].item()) == ns.pair_view(i, j).n_neighbors == idx.numel()
+    owner = torch.repeat_interleave(torch.arange(counts.numel(), device="cuda", dtype=torch.int64), counts)
+    return counts, owner, idx.to(torch.int64)
 
 
 def _weights(n, seed):
@@ -177,12 +168,9 @@ def test_c4_step_loop_matches_oracle(oracle):
 def _chunked_properties(ns, i, j, n_j, same_set, w_a, w_b, chunk=4_000_000, owner_ids=None):
     """-> (total, sum w_a[i] w_b[j], sum w_b[i] w_a[j], sum w_a[i] count_i) over all directed pairs, all mod 2^64; asserts
     well-formedness of every list on the way.  owner_ids: identity of query point p (default p); list entries are identities."""
-    import ctypes as C
     import torch
     v = ns.pair_view(i, j)
-    offs = torch.empty(max(v.n_points, 1), dtype=torch.int64, device="cuda")
-    recs = torch.empty(max(v.n_records, 1), dtype=torch.int32, device="cuda")
-    ns._check(ns._L.tnsx_copy_pair(ns._h, int(i), int(j), C.c_void_p(offs.data_ptr()), C.c_void_p(recs.data_ptr()), 1))
+    offs, recs = ns.neighbor_records_torch(i, j)     # zero-copy views of the engine's own offsets / records (at 200 M points the records are 48 GB)
     total, m_ab, m_ba, deg = 0, 0, 0, 0
     M = (1 << 64) - 1
     for lo in range(0, v.n_points, chunk):
@@ -215,12 +203,8 @@ def _chunked_properties(ns, i, j, n_j, same_set, w_a, w_b, chunk=4_000_000, owne
 def _sampled_lists(ns, i, j, sample):
     """Sorted neighbour lists of the query points `sample` (int64 numpy, set-local indices of set i) of pair (i, j), fetched from the device copy of the
     pair: (offsets int64[k + 1], indices int32[E]) like oracle.pair_search returns them."""
-    import ctypes as C
     import torch
-    v = ns.pair_view(i, j)
-    offs = torch.empty(max(v.n_points, 1), dtype=torch.int64, device="cuda")
-    recs = torch.empty(max(v.n_records, 1), dtype=torch.int32, device="cuda")
-    ns._check(ns._L.tnsx_copy_pair(ns._h, int(i), int(j), C.c_void_p(offs.data_ptr()), C.c_void_p(recs.data_ptr()), 1))
+    offs, recs = ns.neighbor_records_torch(i, j)
     o = offs[torch.from_numpy(sample).cuda()]
     counts = recs[o].to(torch.int64)
     e = int(counts.sum().item())

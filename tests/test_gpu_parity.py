@@ -356,74 +356,6 @@ def test_full_size_properties_symmetry_idempotence_self_exclusion(n):
     assert np.array_equal(offs, offs2) and np.array_equal(idx, idx2), "second run differs"
 
 
-# ---- round 3: the group formulation (tnsx_options.query_formulation = 1; treensearch_amd/csrc/tnsx_query_group.hip): tests on the matrix pipe with an
-#      exact re-test inside the rounding band, the cell kernels behind it for what it passes on.  Opt-in (measured slower), identical lists.
-FIXED = [c for c in SMALL if c.radii is None]
-
-
-def _need_group_formulation():
-    """Round 5: tnsx_query_group.hip is part of libtnsx.so only in builds made with TNSX_WITH_GROUP_FORMULATION=1 (treensearch_amd/build.py); the default
-    library answers 0 here and runs the cell kernels whatever query_formulation says."""
-    import treensearch_amd as T
-    if not T.load_library().tnsx_query_formulation_available(1):
-        pytest.skip("libtnsx.so was built without the group formulation (TNSX_WITH_GROUP_FORMULATION=1 python -m treensearch_amd.build)")
-
-
-@pytest.mark.parametrize("case", FIXED, ids=[c.name for c in FIXED])
-@pytest.mark.parametrize("mode", [0, 1], ids=["strict", "contracted"])
-def test_group_formulation_matches_golden(case, mode, oracle):
-    _need_group_formulation()
-    ns = P.make_engine(case, mode, query_formulation=1)
-    self_pairs = sum(1 for (i, j) in case.active if i == j and len(case.points[i]) > 0)
-    for step in range(2):         # step 0: dry pass + sized pass, step 1: one pass
-        ns.run()
-        st = ns.get_stats()
-        # (a pair that passed on most of its cells is back on the cell kernels in step 1; a sparse grid -- the far outlier of the edge case -- is served by the
-        #  general kernel alone)
-        assert st["n_group_pairs"] == self_pairs or step == 1 or st["grid_sparse"] == 1
-        res = {pr: ns.neighbor_csr(*pr) for pr in case.active}
-        P.assert_matches_golden(res, load_golden(case.name), mode, oracle, case.name + " (group formulation, step %d)" % step)
-
-
-@pytest.mark.parametrize("mode", [0, 1], ids=["strict", "contracted"])
-def test_group_formulation_c2_10m_matches_reference_digest(mode, oracle):
-    _need_group_formulation()
-    case = CS.by_name("uniform_fixed_10000000")
-    golden = load_golden(case.name)
-    ns = P.make_engine(case, mode, device_inputs=True, query_formulation=1)
-    ns.run(); ns.run()
-    st = ns.get_stats()
-    assert st["n_group_pairs"] == 1 and st["n_group_passed_cells"] < st["n_occupied_cells"] // 100
-    assert st["n_neighbors"] == golden["pairs"]["0->0"]["strict" if mode == 0 else "contracted"]["total"]
-    P.assert_matches_golden({(0, 0): ns.neighbor_csr(0, 0, sort_each=False)}, golden, mode, oracle, case.name + " (group formulation)", lists_sorted=False)
-
-
-def test_group_formulation_points_on_the_radius(oracle):
-    """A lattice whose spacing IS the search radius: six neighbours of every point sit exactly on d == r, i.e. inside the rounding band
-    of the matrix-pipe test, and the lattice is moved off the origin so that the local coordinates round.  The band must hand every
-    one of them to the reference's own arithmetic."""
-    import treensearch_amd as T
-    _need_group_formulation()
-    r = np.float32(0.03125)
-    g = np.arange(24, dtype=np.float32) * r
-    pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) + np.float32([0.7, 1.3, 2.9])
-    pts = np.ascontiguousarray(pts.astype(np.float32))
-    lists = {}
-    for form in (0, 1):
-        ns = T.TreeNSearch(query_formulation=form)
-        ns.set_search_radius(float(r)); ns.add_point_set(pts); ns.set_active_search(0, 0, True)
-        ns.run(); ns.run()
-        lists[form] = ns.neighbor_csr(0, 0)
-        if form == 1:
-            assert ns.get_stats()["n_group_pairs"] == 1
-    P.assert_same_csr(lists[1], lists[0], "group formulation vs cell kernels, points on the radius")
-    off, idx = lists[1]
-    assert int(off[-1]) > 0
-    ora = oracle.pair_search(pts, pts, radius=float(r), same_set=True, mode=0)
-    P.assert_same_csr(lists[1], ora, "group formulation vs oracle, points on the radius")
-    assert int(ora[0][-1]) >= 6 * 22 ** 3          # (the inner points see at least their six axis neighbours at d == r)
-
-
 def _filament(n, turns, seed, jitter):
     """n points along a helix that winds through the unit cube, jittered: sparse EVERYWHERE -- a bounding box of ~10^9 cells of one radius, < 0.1 % occupied"""
     rng = np.random.default_rng(seed)
@@ -485,11 +417,10 @@ def test_sparse_grid_keeps_cells_of_one_radius(oracle):
 
 
 def test_an_unavailable_formulation_falls_back_to_the_cell_kernels(oracle):
-    """A library built without the group formulation (the default since round 5) accepts query_formulation = 1 and runs the cell kernels: same lists, no
+    """The product library (built without the group formulation: a refutation that lives in tools/ since round 6) accepts query_formulation = 1 and runs the cell kernels: same lists, no
     group pair in the statistics."""
     import treensearch_amd as T
-    if T.load_library().tnsx_query_formulation_available(1):
-        pytest.skip("this library carries the group formulation")
+    assert T.load_library().tnsx_query_formulation_available(1) == 0, "the product library does not carry the refuted formulation (tools/build_group_variant.sh builds a variant that does)"
     case = CS.by_name("uniform_fixed_100000")
     ns = P.make_engine(case, 0, query_formulation=1)
     ns.run(); ns.run()

@@ -5,6 +5,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import treensearch_amd as T
+import treensearch_amd.api as A
+# the group formulation is not part of the product library: load the variant that carries it (tools/build_group_variant.sh)
+VARIANT = os.path.join(ROOT, "ab_libs", "libtnsx_group.so")
+if os.path.exists(VARIANT):
+    A._lib, A.LIB_PATH = None, VARIANT
 from treensearch_amd import datagen as D
 form = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000

@@ -56,7 +56,7 @@ class Stats(C.Structure):
                 ("n_pool_pairs", C.c_int), ("pool_retries", C.c_int), ("cold_passes", C.c_int), ("speculated", C.c_int),
                 ("speculation_redos", C.c_int), ("n_cached_sets", C.c_int), ("n_filtered_cells", C.c_uint32), ("n_devices_used", C.c_int),
                 ("world_bottom", C.c_float * 3), ("world_top", C.c_float * 3), ("world_cells_pow2", C.c_int), ("zsort_cell_size_inv", C.c_float),
-                ("grid_trimmed", C.c_int), ("n_group_pairs", C.c_uint32), ("n_group_passed_cells", C.c_uint32), ("grid_sparse", C.c_int), ("one_read_builds", C.c_int), ("heavy_catchups", C.c_int)]
+                ("grid_trimmed", C.c_int), ("n_group_pairs", C.c_uint32), ("n_group_passed_cells", C.c_uint32), ("grid_sparse", C.c_int), ("one_read_builds", C.c_int), ("heavy_catchups", C.c_int), ("nan_fixups", C.c_int)]
 
     def as_dict(self):
         d = {}
@@ -68,13 +68,13 @@ class Stats(C.Structure):
 
 # every symbol include/tnsx.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_SYMBOLS = [
-    "tnsx_default_options", "tnsx_create", "tnsx_destroy", "tnsx_last_error", "tnsx_version", "tnsx_query_formulation_available",
+    "tnsx_default_options", "tnsx_create", "tnsx_destroy", "tnsx_last_error", "tnsx_version", "tnsx_get_device", "tnsx_query_formulation_available",
     "tnsx_add_point_set", "tnsx_resize_point_set",
     "tnsx_set_search_radius", "tnsx_set_cell_size", "tnsx_set_symmetric_search", "tnsx_set_active_search",
     "tnsx_set_active_search_all", "tnsx_set_all_searches", "tnsx_set_arithmetic", "tnsx_set_collect_stage_times",
     "tnsx_get_n_sets", "tnsx_get_n_points_in_set", "tnsx_get_total_n_points", "tnsx_is_search_active",
     "tnsx_does_set_exist", "tnsx_get_neighborlist_n_bytes",
-    "tnsx_run", "tnsx_run_scalar", "tnsx_get_pair_view", "tnsx_mirror_pair_to_host", "tnsx_copy_pair",
+    "tnsx_run", "tnsx_run_scalar", "tnsx_get_pair_view", "tnsx_mirror_pair_to_host", "tnsx_copy_pair", "tnsx_pair_csr_device",
     "tnsx_prepare_zsort", "tnsx_get_zsort_order", "tnsx_apply_zsort", "tnsx_get_stats",
     "tnsx_halo_pack", "tnsx_x_histogram", "tnsx_set_query_count", "tnsx_translate_neighbors", "tnsx_set_point_ids", "tnsx_synchronize",
     # slab layer (tnsx_slab.cpp)
@@ -156,6 +156,8 @@ def load_library():
     L.tnsx_get_pair_view.argtypes = [vp, ci, ci, C.POINTER(_CsrView)]
     L.tnsx_mirror_pair_to_host.argtypes = [vp, ci, ci]
     L.tnsx_copy_pair.argtypes = [vp, ci, ci, vp, vp, ci]
+    L.tnsx_pair_csr_device.argtypes = [vp, ci, ci, vp, vp]
+    L.tnsx_get_device.argtypes = [vp]
     L.tnsx_prepare_zsort.argtypes = [vp]
     L.tnsx_get_zsort_order.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(ci)]
     L.tnsx_apply_zsort.argtypes = [vp, ci, vp, C.c_size_t, ci, ci]
@@ -213,6 +215,26 @@ def _describe(arr, want_cols: Optional[int]):
         raise ValueError("array must be C-contiguous (xyzxyz... layout)")
     flags = (TNSX_F64 if a.dtype == np.float64 else TNSX_F32) | TNSX_HOST
     return a.ctypes.data if a.size else None, a.size, flags, a
+
+
+class _DeviceArray:
+    """A raw device pointer dressed as a CUDA array (the __cuda_array_interface__ protocol, version 2) so that torch.as_tensor wraps it without a
+    copy; keeps the owner of the memory alive."""
+
+    def __init__(self, ptr: int, n: int, typestr: str, owner):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), True), "version": 2, "strides": None}
+        self._owner = owner
+
+
+def _device_view(ptr, n: int, typestr: str, itemsize: int, device, owner):
+    import torch
+    dtype = {"<i8": torch.int64, "<i4": torch.int32}[typestr]
+    if n == 0 or not ptr:
+        return torch.empty(0, dtype=dtype, device=device)
+    p = ptr if isinstance(ptr, int) else C.cast(ptr, C.c_void_p).value
+    t = torch.as_tensor(_DeviceArray(p, n, typestr, owner), device=device)
+    assert t.data_ptr() == p and t.dtype == dtype, "torch copied the array instead of wrapping it"
+    return t
 
 
 class NeighborList:
@@ -524,6 +546,43 @@ class TreeNSearch:
             order = np.lexsort((idx, lid))
             idx = idx[order]
         return out_offs, np.ascontiguousarray(idx, np.int32)
+
+    # ---- device-side consumers ("data_ptr() in, CSR tensors out") -- the lists never leave HBM
+    def neighbor_records_torch(self, i: int, j: int):
+        """The record storage of pair (i, j) as CUDA tensors WITHOUT a copy: (offsets int64[n_i] by original point index, records int32[n_records]) with
+        records[offsets[p]] = count of point p followed by its neighbour indices -- what get_neighborlist (TreeNSearch.cpp:241-249) reads, for kernels on
+        the GPU.  The tensors are views of the engine's own memory (tnsx_csr_view.*_device): valid until the next run() of this object, read-only by
+        contract; the records keep the pool's layout (holes between the blocks of records: address every list through its offset)."""
+        import torch
+        v = self.pair_view(i, j)
+        if not v.offsets_device or not v.records_device:
+            raise TnsxError(4, "neighbor_records_torch: the pair has no device view (multi-device contexts hold host views only)")
+        dev = torch.device("cuda", self._device_index())
+        offs = _device_view(v.offsets_device, max(int(v.n_points), 0), "<i8", 8, dev, self)
+        recs = _device_view(v.records_device, max(int(v.n_records), 0), "<i4", 4, dev, self)
+        return offs, recs
+
+    def neighbor_csr_torch(self, i: int, j: int, sort_each: bool = False):
+        """Standard gap-free CSR of pair (i, j) in original point order, built on the device (tnsx_pair_csr_device: lengths -> scan -> copy) into
+        tensors this call allocates: (offsets int64[n_i + 1], indices int32[E]) on the engine's GPU -- the device-side twin of neighbor_csr().
+        sort_each: ascending order inside every list (a device sort of (list, index) keys; off by default: the contract is the set)."""
+        import torch
+        v = self.pair_view(i, j)
+        dev = torch.device("cuda", self._device_index())
+        n, e = max(int(v.n_points), 0), int(v.n_neighbors)
+        offs = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        idx = torch.empty(e, dtype=torch.int32, device=dev)
+        torch.cuda.current_stream(dev).synchronize() if self._own_stream else None     # (the allocations' previous users, should the caching allocator recycle them)
+        self._check(self._L.tnsx_pair_csr_device(self._h, int(i), int(j), C.c_void_p(offs.data_ptr()), C.c_void_p(idx.data_ptr()) if e else None))
+        if sort_each and e:
+            lid = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), offs[1:] - offs[:-1])
+            idx = idx[torch.argsort(lid * (1 << 31) + idx.to(torch.int64))]
+        return offs, idx
+
+    def _device_index(self) -> int:
+        if not hasattr(self, "_dev_index"):
+            self._dev_index = int(self._L.tnsx_get_device(self._h))
+        return self._dev_index
 
     def get_neighborlist(self, set_i: int, set_j: int, point_i: int) -> NeighborList:
         """TreeNSearch.h:182."""

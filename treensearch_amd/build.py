@@ -16,10 +16,6 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libtnsx.so")
 SOURCES = ["tnsx_kernels.hip", "tnsx_build.hip", "tnsx_query.hip", "tnsx_engine.cpp", "tnsx_multi.cpp", "tnsx_slab.cpp"]
-# The group formulation of round 3 (MFMA tiles, measured 2.6 x slower than the cell kernels: DESIGN.md section 6) is kept as a reproducible
-# refutation, not as part of the product: TNSX_WITH_GROUP_FORMULATION=1 in the environment of the BUILD adds its translation unit and the
-# -DTNSX_WITH_GROUP_FORMULATION that makes tnsx_options.query_formulation = 1 reach it (tnsx_query_formulation_available(1) tells).
-OPTIONAL_GROUP = "tnsx_query_group.hip"
 HEADERS = ["tnsx_kernels.h", "tnsx_device.h", "tnsx_pool.h", "tnsx_multi.h", os.path.join(ROOT, "include", "tnsx.h")]
 
 # -ffp-contract=off: the neighbour predicate must not be re-associated or fused behind our back
@@ -34,24 +30,17 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def _with_group() -> bool:
-    return os.environ.get("TNSX_WITH_GROUP_FORMULATION", "0") not in ("", "0")
-
-
 def _sources():
-    return SOURCES + ([OPTIONAL_GROUP] if _with_group() else [])
+    return SOURCES
 
 
 def _commands():
     """[(source, object, command line)]: everything that decides what an object file contains."""
     extra = os.environ.get("TNSX_EXTRA_FLAGS", "").split()     # experiments, e.g. -DTNSX_FAST_WAVES_PER_EU=5
-    if _with_group():
-        extra = ["-DTNSX_WITH_GROUP_FORMULATION"] + extra
     out = []
     for src in _sources():
         obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
-        per_file = ["-mllvm", "-amdgpu-mfma-vgpr-form"] if src == OPTIONAL_GROUP else []   # MFMA results straight into VGPRs (no v_accvgpr_read)
-        out.append((src, obj, [hipcc()] + FLAGS + per_file + extra + ["-I" + os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, src), "-o", obj]))
+        out.append((src, obj, [hipcc()] + FLAGS + extra + ["-I" + os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, src), "-o", obj]))
     return out
 
 
@@ -70,7 +59,7 @@ def _stale() -> bool:
     deps.append(os.path.abspath(__file__))
     if any(os.path.getmtime(d) > t for d in deps):
         return True
-    # the library on disk was linked from objects compiled with other flags (an experiment's TNSX_EXTRA_FLAGS, the group formulation on / off)
+    # the library on disk was linked from objects compiled with other flags (an experiment's TNSX_EXTRA_FLAGS)
     return _recorded(LIB) != "\n".join(" ".join(cmd) for _, _, cmd in _commands())
 
 

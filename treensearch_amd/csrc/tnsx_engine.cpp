@@ -127,7 +127,8 @@ struct PairResult {
 	uint64_t region_payload[NR] = { 0 };   // ints of records the waves of XCD r produced in the previous run
 	uint64_t region_asked[NR] = { 0 };     // ints they asked their region for (records + the unused ends of their slabs); 0: not known for the current slab size
 	uint64_t region_base[NR] = { 0 }, region_cap[NR] = { 0 }, region_used[NR] = { 0 };
-	bool shared_empty = false;   // int 0 of `records` is the empty record every list without a candidate points at
+	bool pooled = false;         // pool layout: int 0 of `records` is THE empty record (count 0), the regions start behind it
+	bool shared_empty = false;   // ... and every offset is pre-set to it, so that cells without a candidate write nothing (pairs of two different sets)
 	bool dry = false;            // this pass only counts (first run of a pair: nothing is known about its size yet)
 	uint32_t n_cells_i = 0;      // occupied cells of set i in the previous run
 	bool groups_off = false;     // the group formulation sent too much of this pair to its leftover kernel: cell kernels from now on
@@ -136,7 +137,6 @@ struct PairResult {
 	uint32_t heavy_cells = 0;    // cells its first tier passed on to the heavy tiers
 	bool heavy_skipped = false;  // this attempt did not launch the heavy tiers (the previous run had nothing for them; checked after the run)
 	DevBuf counts, offs_sorted, offs_orig, records, heavy, heavy2, filtered;
-	DevBuf m_len, m_offs, m_records;   // the host mirror's gap-free copy in point order, made on the device (mirror_pair)
 	PinnedBuf h_offs, h_records;
 	bool mirrored = false;
 };
@@ -187,6 +187,7 @@ struct tnsx_context {
 
 	// scratch
 	DevBuf bounds_partials, bounds_out, sort_temp, scan_temp, n_occ, permute_tmp, pool_ctrl, run_words, cell_map, trim_hist;
+	DevBuf m_len, m_offs, m_records;   // staging of the host mirror's gap-free copy in point order (mirror_pair; shared by all pairs, used in stream order)
 	PinnedBuf h_small, h_trim;
 	tnsx_stats stats{};
 	std::vector<hipEvent_t> events;
@@ -685,7 +686,7 @@ enum Stage { ST_UPLOAD, ST_BOUNDS, ST_KEYS, ST_SORT, ST_GATHER, ST_CELLS, ST_COU
 static tnsx_status copy_records(tnsx_context* c, const PairResult& pr, int* dst, hipMemcpyKind kind, hipStream_t st)
 {
 	const int* src = pr.records.as<int>();
-	if (pr.shared_empty) HIPCHK(c, hipMemcpyAsync(dst, src, sizeof(int), kind, st));
+	if (pr.pooled) HIPCHK(c, hipMemcpyAsync(dst, src, sizeof(int), kind, st));
 	for (int r = 0; r < PairResult::NR; r++) {
 		if (pr.region_used[r] == 0) continue;
 		HIPCHK(c, hipMemcpyAsync(dst + pr.region_base[r], src + pr.region_base[r], pr.region_used[r] * sizeof(int), kind, st));
@@ -704,15 +705,17 @@ static tnsx_status mirror_pair(tnsx_context* c, PairResult& pr, hipStream_t st)
 	HIPCHK(c, pr.h_offs.reserve((std::max<size_t>(nq, 1) + 1) * sizeof(uint64_t)));
 	HIPCHK(c, pr.h_records.reserve(std::max<uint64_t>(total, 1) * sizeof(int)));
 	if (nq > 0) {
-		HIPCHK(c, pr.m_len.reserve(nq * sizeof(uint32_t)));
-		HIPCHK(c, pr.m_offs.reserve((nq + 1) * sizeof(uint64_t)));
-		HIPCHK(c, pr.m_records.reserve(std::max<uint64_t>(total, 1) * sizeof(int)));
+		// ONE staging area per context, not per pair (round-5 advice: a second persistent copy of every pair's records doubled the list memory of the drop-in
+		// mode): everything here is enqueued on the context's stream, so the copy of one pair to the host is over before the next pair's compaction overwrites it
+		HIPCHK(c, c->m_len.reserve(nq * sizeof(uint32_t)));
+		HIPCHK(c, c->m_offs.reserve((nq + 1) * sizeof(uint64_t)));
+		HIPCHK(c, c->m_records.reserve(std::max<uint64_t>(total, 1) * sizeof(int)));
 		HIPCHK(c, c->scan_temp.reserve(tnsx::scan_temp_bytes(nq)));
-		tnsx::launch_record_lengths(pr.records.as<int>(), pr.offs_orig.as<uint64_t>(), (int)nq, pr.m_len.as<uint32_t>(), st);
-		tnsx::exclusive_scan_u32_to_u64(pr.m_len.as<uint32_t>(), pr.m_offs.as<uint64_t>(), nq, c->scan_temp.p, st);
-		tnsx::launch_compact_records(pr.records.as<int>(), pr.offs_orig.as<uint64_t>(), pr.m_offs.as<uint64_t>(), (int)nq, pr.m_records.as<int>(), st);
-		HIPCHK(c, hipMemcpyAsync(pr.h_offs.p, pr.m_offs.p, nq * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-		if (total > 0) HIPCHK(c, hipMemcpyAsync(pr.h_records.p, pr.m_records.p, total * sizeof(int), hipMemcpyDeviceToHost, st));
+		tnsx::launch_record_lengths(pr.records.as<int>(), pr.offs_orig.as<uint64_t>(), (int)nq, c->m_len.as<uint32_t>(), false, st);
+		tnsx::exclusive_scan_u32_to_u64(c->m_len.as<uint32_t>(), c->m_offs.as<uint64_t>(), nq, c->scan_temp.p, st);
+		tnsx::launch_compact_records(pr.records.as<int>(), pr.offs_orig.as<uint64_t>(), c->m_offs.as<uint64_t>(), (int)nq, c->m_records.as<int>(), false, st);
+		HIPCHK(c, hipMemcpyAsync(pr.h_offs.p, c->m_offs.p, nq * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+		if (total > 0) HIPCHK(c, hipMemcpyAsync(pr.h_records.p, c->m_records.p, total * sizeof(int), hipMemcpyDeviceToHost, st));
 	}
 	pr.mirrored = true;
 	return TNSX_OK;
@@ -751,7 +754,7 @@ static tnsx_status size_pool(tnsx_context* c, PairResult& pr, const uint64_t* pa
 	const uint64_t waves_x = std::min<uint64_t>((uint64_t)query_waves / tnsx::POOL_REGIONS, (uint64_t)pr.n_i / tnsx::POOL_REGIONS + 2);
 	// (a wave of the heavy tiers that gets a cell writes at least a handful of records; should this ever be too little, the pass is repeated)
 	const uint64_t waves_heavy = std::min<uint64_t>(std::min<uint64_t>((uint64_t)query_waves, (uint64_t)pr.n_i / 4 + 8), payload[tnsx::POOL_OVERFLOW] / 16 + 8);
-	uint64_t first = pr.shared_empty ? 64 : 0;
+	uint64_t first = 64;   // (int 0: the empty record of the pool)
 	for (int r = 0; r < PairResult::NR; r++) {
 		const bool common = r == tnsx::POOL_OVERFLOW;
 		uint64_t cap;
@@ -1047,6 +1050,7 @@ static tnsx_status plan_run(RunAttempt& run)
 			// handling below turns into a real pass of the right size.
 			pr.dry = pr.need_hint == 0;
 			pr.shared_empty = jb.i != jb.j && pr.n_query > 0;
+			pr.pooled = true;
 			{ const tnsx_status r = size_pool(c, pr, pr.dry ? nullptr : pr.region_payload, pr.region_asked[0] || pr.region_asked[tnsx::POOL_OVERFLOW] ? pr.region_asked : nullptr, false, query_waves); if (r != TNSX_OK) return r; }
 			// worklists of the cells the fast / fat kernels pass on (at most one entry per occupied cell)
 			const size_t max_cells = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_i, n_cells));
@@ -1272,7 +1276,7 @@ static tnsx_status launch_pool_pass(RunAttempt& run, size_t k, int tiers, bool f
 	}
 	if (pr.n_i > 0) {
 		qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_POOL;
-		// opt-in (tnsx_options.query_formulation = 1), fixed radius, a set searched in itself: the group formulation (tnsx_query_group.hip)
+		// opt-in (tnsx_options.query_formulation = 1), fixed radius, a set searched in itself: the group formulation (tools/ubench/tnsx_query_group.hip, variant builds only)
 		// in front of the cell kernels, unless it was switched off for this pair
 		pr.groups_now = !sparse && !variable && jb.i == jb.j && c->opt.query_formulation == 1 && tnsx_query_formulation_available(1) != 0 && !pr.groups_off &&
 		                c->grid_h * c->grid_h > 1e-30f;
@@ -1429,7 +1433,7 @@ static tnsx_status collect_pair(RunAttempt& run, size_t k)
 			pr.heavy_cells = h_heavy[k];
 			read_counters();
 		}
-		pr.n_records = pr.shared_empty ? 1 : 0;
+		pr.n_records = 1;
 		uint64_t sum = 0;
 		for (int r = 0; r < PairResult::NR; r++) {
 			pr.region_payload[r] = payload[r];
@@ -1439,11 +1443,20 @@ static tnsx_status collect_pair(RunAttempt& run, size_t k)
 			if (pr.region_used[r]) pr.n_records = std::max(pr.n_records, pr.region_base[r] + pr.region_used[r]);
 		}
 		pr.need_hint = sum + 1;
+		// A query point that entered no cell (a NaN x is "no point") was never visited, so nobody wrote its offset.  The records that were written say
+		// whether there is one: ints of records = neighbours + one count word per visited query.  Rare; its offsets then go to the empty record, so that
+		// every consumer -- the device views, the compaction of the host mirror -- finds a list of length 0 there (round-5 advice).
+		if (!pr.shared_empty && !c->debug_nostore && pr.n_query > 0 && sum != n_neighbors + (uint64_t)pr.n_query) {
+			const PointSet& A = c->sets[jb.i];
+			tnsx::launch_point_nan_offsets(A.d_xyz, pr.n_query, pr.offs_orig.as<uint64_t>(), st);
+			S.nan_fixups++;
+		}
 	}
 	else {
 		pr.n_records = h_ctrl[HC * k];
 		n_neighbors = pr.n_records - (uint64_t)pr.n_query;
 		pr.shared_empty = false;
+		pr.pooled = false;
 		for (int r = 0; r < PairResult::NR; r++) { pr.region_base[r] = 0; pr.region_used[r] = 0; }
 		pr.region_used[0] = pr.n_records;
 		HIPCHK(c, pr.records.reserve(std::max<uint64_t>(pr.n_records, 1) * sizeof(int)));
@@ -1631,6 +1644,33 @@ tnsx_status tnsx_copy_pair(tnsx_context* c, int i, int j, uint64_t* offsets_dst,
 	const hipMemcpyKind kind = dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
 	if (offsets_dst && pr->n_query > 0) HIPCHK(c, hipMemcpyAsync(offsets_dst, pr->offs_orig.p, (size_t)pr->n_query * sizeof(uint64_t), kind, c->stream));
 	if (records_dst && pr->n_records > 0) { const tnsx_status r = copy_records(c, *pr, records_dst, kind, c->stream); if (r != TNSX_OK) return r; }
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return TNSX_OK;
+}
+
+// SURVEY.md section 8(f)4 "CSR tensors out": the pair as a standard gap-free CSR in point order, built ON THE DEVICE into caller memory (device pointers):
+// offsets_out[p] .. offsets_out[p + 1] delimit the neighbours of point p in indices_out (n_points + 1 offsets, n_neighbors indices, no count words).
+// What get_neighborlist hands out one point at a time (TreeNSearch.cpp:241-249), for consumers that live on the GPU.
+tnsx_status tnsx_pair_csr_device(tnsx_context* c, int i, int j, int64_t* offsets_out, int* indices_out)
+{
+	if (!c) return TNSX_ERR_INVALID;
+	TNSX_NOT_MULTI("tnsx_pair_csr_device");
+	PairResult* pr = nullptr;
+	{ const tnsx_status r = find_pair(c, i, j, &pr); if (r != TNSX_OK) return r; }
+	if (!offsets_out) TNSX_FAIL(c, TNSX_ERR_INVALID, "tnsx_pair_csr_device: null offsets");
+	if (hipSetDevice(c->device) != hipSuccess) TNSX_FAIL(c, TNSX_ERR_HIP, "hipSetDevice failed");
+	const size_t nq = (size_t)std::max(pr->n_query, 0);
+	std::lock_guard<std::mutex> lock(c->mirror_mutex);   // (m_len is the mirror's scratch)
+	if (nq == 0) { HIPCHK(c, hipMemsetAsync(offsets_out, 0, sizeof(int64_t), c->stream)); }
+	else {
+		HIPCHK(c, c->m_len.reserve(nq * sizeof(uint32_t)));
+		HIPCHK(c, c->scan_temp.reserve(tnsx::scan_temp_bytes(nq)));
+		tnsx::launch_record_lengths(pr->records.as<int>(), pr->offs_orig.as<uint64_t>(), (int)nq, c->m_len.as<uint32_t>(), true, c->stream);
+		tnsx::exclusive_scan_u32_to_u64(c->m_len.as<uint32_t>(), reinterpret_cast<uint64_t*>(offsets_out), nq, c->scan_temp.p, c->stream);
+		if (indices_out && pr->n_neighbors > 0)
+			tnsx::launch_compact_records(pr->records.as<int>(), pr->offs_orig.as<uint64_t>(), reinterpret_cast<const uint64_t*>(offsets_out), (int)nq, indices_out, true, c->stream);
+	}
+	HIPCHK(c, hipGetLastError());
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	return TNSX_OK;
 }
@@ -1847,6 +1887,7 @@ tnsx_status tnsx_set_query_count(tnsx_context* c, int set_i, int n_query)
 // (tnsx_slab.cpp) the stream / device a single-device context works on
 void* tnsx_internal_stream(tnsx_context* c) { return c && !c->multi ? (void*)c->stream : nullptr; }
 int tnsx_internal_device(tnsx_context* c) { return c ? c->device : 0; }
+extern "C" int tnsx_get_device(const tnsx_context* c) { return c ? c->device : -1; }
 void tnsx_internal_set_sync_timeout(tnsx_context* c, double seconds) { if (c) c->sync_timeout_s = seconds; }
 
 tnsx_status tnsx_get_stats(const tnsx_context* c, tnsx_stats* out)

@@ -120,7 +120,7 @@ struct QueryArgs {
 	const uint2* socc_i; const uint32_t* blk_i; const uint2* socc_j; const uint32_t* blk_j; int sparse_shift;
 	const uint32_t* abort_flag;   // the run's guard word (or nullptr): non-zero = the build already knows that this attempt will be thrown away (a point outside the
 	                              // reused grid, an overflowed window of the one-read bucket pass -- the sorted arrays then have HOLES): the query kernels do nothing
-	uint2* heavy0; uint32_t* n_heavy0;   // group formulation (tnsx_query_group.hip): worklist of the cells it passes on to the three cell tiers (zeroed before)
+	uint2* heavy0; uint32_t* n_heavy0;   // group formulation (tools/ubench/tnsx_query_group.hip, variant builds only): worklist of the cells it passes on to the three cell tiers (zeroed before)
 };
 // Control block of one pool pass.  Every hot counter sits CTRL_STRIDE_U32 words (4352 B) from the next: the L2 serialises
 // atomics that hit the same cache line (measured: ~88 atomics/us per line, whatever the word), and the stride also spreads
@@ -146,14 +146,14 @@ struct QueryConfig {
 	bool symmetric;  // d2 <= r_i^2 || d2 <= r_j^2 (only meaningful with variable)
 	bool self;       // set_i == set_j: exclude the point itself
 	int mode;        // QUERY_COUNT / QUERY_FILL (exact two-pass layout) / QUERY_POOL (single pass)
-	bool groups = false;   // QUERY_POOL with a fixed radius: the group formulation (tnsx_query_group.hip) instead of the three cell tiers
+	bool groups = false;   // QUERY_POOL with a fixed radius: the group formulation (tools/ubench/tnsx_query_group.hip, variant builds only) instead of the three cell tiers
 	int group_waves_per_cu = 0;   // its launch width (waves per CU); 0 = default
 	int blocks_per_cu = 0, fast_blocks_per_cu = 0;   // launch widths (workgroups per CU) of the general / the fast kernels; 0 = default
 	int tiers = 3;   // QUERY_POOL: bit 0 = the first tier, bit 1 = the two heavy tiers over the first tier's reject list (launched later, or not at all, when
 	                 // the previous run of the pair rejected nothing: two empty launches are ~10 us of a step)
 };
 void launch_query(const QueryArgs& a, const QueryConfig& c, int n_compute_units, hipStream_t s);
-// group formulation of a pool pass with a fixed radius (tnsx_query_group.hip): k_query_groups over the occupied cells, then the three cell tiers
+// group formulation of a pool pass with a fixed radius (tools/ubench/tnsx_query_group.hip, variant builds only): k_query_groups over the occupied cells, then the three cell tiers
 // over what it passed on (a.heavy0 / a.n_heavy0: at most one entry per occupied cell)
 void launch_query_groups(const QueryArgs& a, const QueryConfig& c, int n_compute_units, hipStream_t s);
 // pool pass over two different sets, candidate-presence filter: launch_mark_cells writes `value` into the byte of every grid cell
@@ -189,6 +189,8 @@ void launch_slab_rows_to_points(const float* rows, size_t n_rows, int W, float* 
 //      n_shared_empty > 0 (a pair of two different sets): offs[0..n) = 0 and records[0] = 0, the shared empty record at int 0 of the pool.
 //      (On its own only for the repeat of a pass and for runs with more pool passes than launch_run_begin takes.)
 void launch_pool_begin(const unsigned long long* regions, uint32_t* ctrl, uint64_t* offs, size_t n_shared_empty, int* records, hipStream_t s);
+// offs[p] = 0 (the pool's empty record) for every p < n whose x is NaN ("no point": it entered no cell and no query wrote its offset); xyz: 3 floats per point
+void launch_point_nan_offsets(const float* xyz, int n, uint64_t* offs, hipStream_t s);
 // ---- start of a run, ONE launch (round 4; every kernel of a step costs ~5 us of dispatch whatever it does):
 //      words[0..n_words) = 0 (guard flag, partial checksums), n_occ[si] = 0 for every set si whose bit is set in `sets` (si < 64),
 //      zero[k][0..n_zero[k]) = 0 (the cursors of the one-read bucket pass),
@@ -217,8 +219,9 @@ void launch_run_end(const RunEndArgs& a, hipStream_t s);
 void launch_sort_records(int* records, const uint64_t* offs_by_orig, int n_query, int n_cus, hipStream_t s);
 
 // ---- gap-free copy of a pair's records in point order (the host mirror): len[p] = count + 1; out[new_offs[p] ...] = the record of point p (new_offs: n + 1 entries)
-void launch_record_lengths(const int* records, const uint64_t* offs_by_orig, int n, uint32_t* len, hipStream_t s);
-void launch_compact_records(const int* records, const uint64_t* offs_by_orig, const uint64_t* new_offs, int n, int* out, hipStream_t s);
+// indices_only: the count words are left out (len[p] = count, the copy starts behind the count word): a standard CSR
+void launch_record_lengths(const int* records, const uint64_t* offs_by_orig, int n, uint32_t* len, bool indices_only, hipStream_t s);
+void launch_compact_records(const int* records, const uint64_t* offs_by_orig, const uint64_t* new_offs, int n, int* out, bool indices_only, hipStream_t s);
 
 // ---- permutation of byte records: out[new] = in[perm[new]] ------------------------------------------
 void launch_permute_bytes(const void* in, void* out, const int* new_to_old, int n, size_t rec_bytes, hipStream_t s);

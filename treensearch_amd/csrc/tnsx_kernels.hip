@@ -231,20 +231,21 @@ void exclusive_scan_u32_to_u64(const uint32_t* in, uint64_t* out, size_t n, void
 // len[p] = count + 1 -> exclusive scan = the mirror's offsets -> every record copied to its place.  A wave owns 64 consecutive points; it walks their records
 // four at a time (the loads of four records in flight), 64 ints per lane round.
 // =====================================================================================================
-__global__ void __launch_bounds__(256) k_record_lengths(const int* __restrict__ records, const uint64_t* __restrict__ offs, int n, uint32_t* __restrict__ len)
+// skip = 0: whole records, `[count, j...]` (the host mirror);  skip = 1: the indices only (a standard CSR: tnsx_pair_csr_device)
+__global__ void __launch_bounds__(256) k_record_lengths(const int* __restrict__ records, const uint64_t* __restrict__ offs, int n, uint32_t* __restrict__ len, uint32_t skip)
 {
 	const int p = blockIdx.x * 256 + threadIdx.x;
-	if (p < n) len[p] = (uint32_t)records[offs[p]] + 1u;
+	if (p < n) len[p] = (uint32_t)records[offs[p]] + 1u - skip;
 }
 __global__ void __launch_bounds__(256) k_compact_records(const int* __restrict__ records, const uint64_t* __restrict__ offs, const uint64_t* __restrict__ new_offs, int n,
-                                                         int* __restrict__ out)
+                                                         int* __restrict__ out, uint32_t skip)
 {
 	const int lane = lane_id();
 	const size_t wave = (size_t)blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
 	const size_t p0 = wave * WAVE;
 	if (p0 >= (size_t)n) return;
 	const size_t p = p0 + (size_t)lane < (size_t)n ? p0 + (size_t)lane : (size_t)n - 1;
-	const uint64_t src = offs[p], dst = new_offs[p];
+	const uint64_t src = offs[p] + skip, dst = new_offs[p];
 	const uint32_t len = (uint32_t)(new_offs[p + 1] - dst);
 	const int cnt = (int)((size_t)n - p0 < (size_t)WAVE ? (size_t)n - p0 : (size_t)WAVE);
 	for (int t0 = 0; t0 < cnt; t0 += 4) {
@@ -270,13 +271,13 @@ __global__ void __launch_bounds__(256) k_compact_records(const int* __restrict__
 		}
 	}
 }
-void launch_record_lengths(const int* records, const uint64_t* offs, int n, uint32_t* len, hipStream_t s)
+void launch_record_lengths(const int* records, const uint64_t* offs, int n, uint32_t* len, bool indices_only, hipStream_t s)
 {
-	if (n > 0) hipLaunchKernelGGL(k_record_lengths, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, records, offs, n, len);
+	if (n > 0) hipLaunchKernelGGL(k_record_lengths, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, records, offs, n, len, indices_only ? 1u : 0u);
 }
-void launch_compact_records(const int* records, const uint64_t* offs, const uint64_t* new_offs, int n, int* out, hipStream_t s)
+void launch_compact_records(const int* records, const uint64_t* offs, const uint64_t* new_offs, int n, int* out, bool indices_only, hipStream_t s)
 {
-	if (n > 0) hipLaunchKernelGGL(k_compact_records, dim3((unsigned)(((size_t)n + 255) / 256)), dim3(256), 0, s, records, offs, new_offs, n, out);
+	if (n > 0) hipLaunchKernelGGL(k_compact_records, dim3((unsigned)(((size_t)n + 255) / 256)), dim3(256), 0, s, records, offs, new_offs, n, out, indices_only ? 1u : 0u);
 }
 
 // =====================================================================================================
@@ -634,12 +635,22 @@ __device__ __forceinline__ void pool_begin_block(const unsigned long long* __res
 __global__ void __launch_bounds__(256) k_pool_begin(PoolRegionTable t, uint32_t* __restrict__ ctrl, uint64_t* __restrict__ offs, size_t n, int* __restrict__ records)
 {
 	if (blockIdx.x == 0) pool_begin_block(t.v, ctrl);
+	if (blockIdx.x == 0 && threadIdx.x == 0) records[0] = 0;   // the empty record of the pool
 	if (n == 0) return;
-	if (blockIdx.x == 0 && threadIdx.x == 0) records[0] = 0;
 	ulonglong2* o2 = reinterpret_cast<ulonglong2*>(offs);
 	const size_t n2 = n / 2;
 	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) o2[i] = make_ulonglong2(0ull, 0ull);
 	if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) offs[n - 1] = 0ull;
+}
+// query points that entered no cell (x is NaN: no point) were never visited and have no offset: point them at the pool's empty record (int 0)
+__global__ void __launch_bounds__(256) k_point_nan_offsets(const float* __restrict__ xyz, int n, uint64_t* __restrict__ offs)
+{
+	const int p = blockIdx.x * 256 + threadIdx.x;
+	if (p < n) { const float x = xyz[3 * (size_t)p]; if (x != x) offs[p] = 0ull; }
+}
+void launch_point_nan_offsets(const float* xyz, int n, uint64_t* offs, hipStream_t s)
+{
+	if (n > 0) hipLaunchKernelGGL(k_point_nan_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xyz, n, offs);
 }
 void launch_pool_begin(const unsigned long long* regions, uint32_t* ctrl, uint64_t* offs, size_t n_shared_empty, int* records, hipStream_t s)
 {
@@ -691,8 +702,8 @@ __global__ void __launch_bounds__(256) k_run_begin(const RunBeginArgs a)
 	for (int k = 0; k < a.n_pool; k++) {
 		const RunBeginPool& p = a.pool[k];
 		if (blockIdx.x == (unsigned)k % gridDim.x) pool_begin_block(p.regions, p.ctrl);   // (uniform per block: the barrier inside is safe)
+		if (gtid == 0) p.records[0] = 0;   // the empty record of the pool
 		if (p.n_shared_empty == 0) continue;
-		if (gtid == 0) p.records[0] = 0;
 		ulonglong2* o2 = reinterpret_cast<ulonglong2*>(p.offs);
 		const size_t n2 = p.n_shared_empty / 2;
 		for (size_t i = gtid; i < n2; i += gsz) o2[i] = make_ulonglong2(0ull, 0ull);

@@ -1,4 +1,4 @@
-// Per-wave bump allocation from the record pool (pool passes of the query kernels); shared by tnsx_query.hip and tnsx_query_group.hip.
+// Per-wave bump allocation from the record pool (pool passes of the query kernels); shared by tnsx_query.hip and tools/ubench/tnsx_query_group.hip.
 #pragma once
 #include "tnsx_kernels.h"
 #include "tnsx_device.h"

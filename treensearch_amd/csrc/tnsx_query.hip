@@ -1289,7 +1289,7 @@ static void launch_query_1(const QueryArgs& a, const QueryConfig& c, int n_cus, 
 }
 void launch_query(const QueryArgs& a, const QueryConfig& c, int n_compute_units, hipStream_t s)
 {
-#ifdef TNSX_WITH_GROUP_FORMULATION   // (tnsx_query_group.hip is part of the library only in builds that ask for it: measured 2.6 x slower)
+#ifdef TNSX_WITH_GROUP_FORMULATION   // (tools/ubench/tnsx_query_group.hip: a refuted formulation, linked only into the variant library of tools/build_group_variant.sh)
 	if (c.mode == QUERY_POOL && c.groups && !c.variable) { launch_query_groups(a, c, n_compute_units, s); return; }
 #endif
 	if (c.arith == 0) launch_query_1<0>(a, c, n_compute_units, s); else launch_query_1<1>(a, c, n_compute_units, s);

@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -124,7 +125,14 @@ void rccl_abort(void* user)
 // All slabs of a decomposition inside ONE process (a thread per slab, any streams, one or several devices that can reach each
 // other's memory): what tests/test_gpu_slabs.py runs on a single GPU.  A message is handed over as {pointer, bytes, event}: the
 // receiver orders its stream behind the sender's event and copies device to device; the sender orders its stream behind the copy.
-struct LocalMsg { const void* ptr; size_t bytes; hipEvent_t ready; hipEvent_t* done; bool* consumed; };
+// The state of one posted message is owned jointly by the queue entry / the receiver that took it and by the sender (round-5 advice: a sender that gave up
+// after a timeout used to leave a receiver in mid-copy with pointers into its dead stack frame).  The events die with the last owner.
+struct LocalSent {
+	hipEvent_t ready = nullptr, done = nullptr;
+	bool consumed = false;
+	~LocalSent() { if (ready) (void)hipEventDestroy(ready); if (done) (void)hipEventDestroy(done); }
+};
+struct LocalMsg { const void* ptr; size_t bytes; std::shared_ptr<LocalSent> st; };
 struct LocalGroup {
 	int world = 0;
 	std::mutex mu;
@@ -134,8 +142,9 @@ struct LocalGroup {
 	int ar_arrived = 0, ar_left = 0;
 	uint64_t ar_gen = 0;
 	std::vector<uint32_t> ar_acc;
+	bool ar_failed = false;                    // a rank withdrew from a reduction after a timeout: its contribution is in ar_acc, the group's reductions are void from here on
 	int refs = 0;
-	double host_wait_s = 120.0;                // bound of every host-side wait for a peer (tnsx_slab_set_watchdog of any slab on this group sets it)
+	double host_wait_s = 120.0;                // bound of every host-side wait for a peer (tnsx_slab_set_watchdog of any slab on this group sets it; read and written under mu)
 };
 struct LocalTransport { LocalGroup* g; int rank; };
 
@@ -144,26 +153,24 @@ int local_exchange(void* user, int rank, int world, const tnsx_slab_op* ops, int
 	LocalTransport* t = static_cast<LocalTransport*>(user);
 	LocalGroup* g = t->g;
 	hipStream_t s = static_cast<hipStream_t>(stream);
-	struct Sent { hipEvent_t ready, done; bool consumed; };
-	std::vector<Sent> sent((size_t)n_ops);
+	std::vector<std::shared_ptr<LocalSent>> sent((size_t)n_ops);
 	// 1. post every send
 	for (int k = 0; k < n_ops; k++) {
-		sent[(size_t)k] = { nullptr, nullptr, true };
 		if (!ops[k].send_bytes) continue;
-		Sent& e = sent[(size_t)k];
-		e.consumed = false;
-		if (hipEventCreateWithFlags(&e.ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(e.ready, s) != hipSuccess) return 1;
+		auto e = std::make_shared<LocalSent>();
+		if (hipEventCreateWithFlags(&e->ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(e->ready, s) != hipSuccess) return 1;
+		sent[(size_t)k] = e;
 		std::lock_guard<std::mutex> lk(g->mu);
-		g->box[(size_t)rank * world + ops[k].peer].push_back({ ops[k].send, ops[k].send_bytes, e.ready, &e.done, &e.consumed });
+		g->box[(size_t)rank * world + ops[k].peer].push_back({ ops[k].send, ops[k].send_bytes, e });
 		g->cv.notify_all();
 	}
-	// (a wait that timed out: the messages this rank posted and nobody took are withdrawn -- they point into this frame)
+	// (a wait that timed out: the messages this rank posted and nobody took are withdrawn; one a peer has taken stays alive through the peer's reference)
 	auto give_up = [&]() {
 		std::lock_guard<std::mutex> lk(g->mu);
 		for (int k = 0; k < n_ops; k++) {
-			if (!ops[k].send_bytes) continue;
+			if (!sent[(size_t)k]) continue;
 			auto& q = g->box[(size_t)rank * world + ops[k].peer];
-			for (auto it = q.begin(); it != q.end();) { if (it->consumed == &sent[(size_t)k].consumed) it = q.erase(it); else ++it; }
+			for (auto it = q.begin(); it != q.end();) { if (it->st == sent[(size_t)k]) it = q.erase(it); else ++it; }
 		}
 		return 3;   // timed out
 	};
@@ -182,26 +189,24 @@ int local_exchange(void* user, int rank, int world, const tnsx_slab_op* ops, int
 		}
 		hipEvent_t done = nullptr;
 		if (m.bytes != ops[k].recv_bytes) rc = 2;   // the two ends disagree on a message size: a protocol error
-		if (rc == 0 && (hipStreamWaitEvent(s, m.ready, 0) != hipSuccess ||
+		if (rc == 0 && (hipStreamWaitEvent(s, m.st->ready, 0) != hipSuccess ||
 		                hipMemcpyAsync(ops[k].recv, m.ptr, m.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)) rc = 1;
 		if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess || hipEventRecord(done, s) != hipSuccess) rc = rc ? rc : 1;
 		std::lock_guard<std::mutex> lk(g->mu);
-		*m.done = done;
-		*m.consumed = true;
+		m.st->done = done;
+		m.st->consumed = true;
 		g->cv.notify_all();
 	}
 	// 3. the send buffers may be reused once the receivers' copies are ordered before this stream's later work
 	for (int k = 0; k < n_ops; k++) {
-		Sent& e = sent[(size_t)k];
-		if (!ops[k].send_bytes) continue;
+		if (!sent[(size_t)k]) continue;
+		LocalSent& e = *sent[(size_t)k];
 		{
 			std::unique_lock<std::mutex> lk(g->mu);
 			if (!g->cv.wait_for(lk, std::chrono::duration<double>(g->host_wait_s), [&] { return e.consumed; })) { lk.unlock(); return give_up(); }
 		}
 		if (e.done) { if (hipStreamWaitEvent(s, e.done, 0) != hipSuccess) rc = rc ? rc : 1; }
-		// (events are destroyed by their users: `ready` by the sender once consumed, `done` by the sender after the wait was enqueued)
-		(void)hipEventDestroy(e.ready);
-		if (e.done) (void)hipEventDestroy(e.done);
+		// (both events are destroyed with the message's state, i.e. after this wait was enqueued and after the receiver let go of it)
 	}
 	return rc;
 }
@@ -216,7 +221,8 @@ int local_allreduce(void* user, int, int world, void* buf, int count, int op, vo
 	{
 		std::unique_lock<std::mutex> lk(g->mu);
 		const auto bound = std::chrono::duration<double>(g->host_wait_s);
-		if (!g->cv.wait_for(lk, bound, [&] { return g->ar_left == 0; })) return 3;   // the previous reduction has been read by everybody (3: timed out)
+		if (g->ar_failed) return 3;                                                     // (a rank withdrew earlier: what ar_acc holds is not a reduction any more)
+		if (!g->cv.wait_for(lk, bound, [&] { return g->ar_left == 0 || g->ar_failed; }) || g->ar_failed) return 3;   // the previous reduction has been read by everybody (3: timed out)
 		if (g->ar_arrived == 0) g->ar_acc = mine;
 		else for (int i = 0; i < count; i++) {
 			uint32_t& a = g->ar_acc[(size_t)i];
@@ -229,7 +235,13 @@ int local_allreduce(void* user, int, int world, void* buf, int count, int op, vo
 		}
 		const uint64_t gen = g->ar_gen;
 		if (++g->ar_arrived == world) { g->ar_arrived = 0; g->ar_left = world; g->ar_gen++; g->cv.notify_all(); }
-		else if (!g->cv.wait_for(lk, bound, [&] { return g->ar_gen != gen; })) { g->ar_arrived--; return 3; }   // (a rank that never came: this one withdraws)
+		else if (!g->cv.wait_for(lk, bound, [&] { return g->ar_gen != gen || g->ar_failed; }) || g->ar_gen == gen) {
+			// a rank that never came: this one withdraws.  Its contribution stays in ar_acc, so the generation can never complete correctly: the group's
+			// reductions fail from here on (every waiter is woken and returns 3) instead of handing out a polluted sum to a late arrival.
+			g->ar_failed = true;
+			g->cv.notify_all();
+			return 3;
+		}
 		result = g->ar_acc;
 		if (--g->ar_left == 0) g->cv.notify_all();
 	}
@@ -845,7 +857,10 @@ tnsx_status tnsx_slab_transport_check(tnsx_context* engine, const tnsx_slab_tran
 	uint32_t sum = 0u;
 	tnsx_status rc = TNSX_OK;
 	if (hipMemcpyAsync(d, &one, sizeof one, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = TNSX_ERR_HIP;
-	if (rc == TNSX_OK && transport->allreduce(transport->user, rank, world, d, 1, TNSX_SLAB_SUM_U32, st) != 0) rc = TNSX_ERR_HIP;
+	if (rc == TNSX_OK) {
+		const int arc = transport->allreduce(transport->user, rank, world, d, 1, TNSX_SLAB_SUM_U32, st);
+		if (arc != 0) rc = arc == 3 ? TNSX_ERR_TIMEOUT : TNSX_ERR_HIP;      // (3: the transport's own bounded wait expired)
+	}
 	if (rc == TNSX_OK && (wait_stream(st, 60.0) != 0 || hipMemcpy(&sum, d, sizeof sum, hipMemcpyDeviceToHost) != hipSuccess)) rc = TNSX_ERR_TIMEOUT;
 	(void)hipFree(d);
 	if (rc == TNSX_OK) *ranks_seen = (int)sum;
@@ -857,7 +872,11 @@ tnsx_status tnsx_slab_set_watchdog(tnsx_slab* s, double seconds)
 	if (!s) return TNSX_ERR_INVALID;
 	s->watchdog_s = seconds;
 	// (the in-process transport waits for its peers on the host: the same bound)
-	if (s->tr.exchange == local_exchange && s->tr.user) static_cast<LocalTransport*>(s->tr.user)->g->host_wait_s = seconds > 0.0 ? seconds : 1.0e9;
+	if (s->tr.exchange == local_exchange && s->tr.user) {
+		LocalGroup* g = static_cast<LocalTransport*>(s->tr.user)->g;
+		std::lock_guard<std::mutex> lk(g->mu);      // (peers read it under the lock)
+		g->host_wait_s = seconds > 0.0 ? seconds : 1.0e9;
+	}
 	return TNSX_OK;
 }
 
