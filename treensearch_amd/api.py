@@ -222,7 +222,7 @@ class _DeviceArray:
     copy; keeps the owner of the memory alive."""
 
     def __init__(self, ptr: int, n: int, typestr: str, owner):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), True), "version": 2, "strides": None}
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
         self._owner = owner
 
 
