@@ -988,9 +988,6 @@ __device__ __forceinline__ void fast_cell_nc(const QueryArgs& a, const RunRef RR
 #ifndef TNSX_FAT_WAVES_PER_EU
 #define TNSX_FAT_WAVES_PER_EU 3
 #endif
-#ifndef TNSX_YZ_TICKETS
-#define TNSX_YZ_TICKETS 0
-#endif
 // Round 5: no first-tier instantiation spills any more (tools/kernel_resources.py: scratch 0; the fixed-radius / self kernel of C2 went from 96 to 84 VGPRs) -- the
 // lane-derived constants of the cell bodies are recomputed per cell (TNSX_LANE_OPAQUE), the neighbour offsets of the look-ups are one packed register, the cull loads
 // coordinates only.  One instantiation is still a register short at five waves: per-point radii + symmetric + two different sets + contracted arithmetic (both sets'
@@ -1014,26 +1011,11 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 	__shared__ uint16_t s_slots[TNSX_CULL ? Q_WAVES * SLOT_CAP : 2];
 	uint16_t* const my_slots = s_slots + (TNSX_CULL ? (threadIdx.x / WAVE) * SLOT_CAP : 0);
 	const int lane = lane_id();
-	const uint32_t xcd = blockIdx.x & 7u;
-#if TNSX_YZ_TICKETS
-	// EXPERIMENT (round 6, verdict item 1; tools/build_variant.sh -DTNSX_YZ_TICKETS=1; dense grids only): the first tier does not walk the occupied-cell list in
-	// key order (x, then y, then z: an XCD's eight fronts sweep whole z-layers, and a layer's points come back from the fabric once per neighbouring layer) but the
-	// GRID CELLS of its z-slab with y OUTERMOST: row sequence q = y * L + (z - z0) over the L layers of the slab, the rows dealt round-robin to the XCD's eight
-	// ticket counters, so that all fronts of an XCD advance through y together over a working set of (L + 2) x 3 rows.  Empty cells are visited and cost a look-up.
-	const bool yz = !FAT && a.blk_j == nullptr;
-	const uint32_t gnx = (uint32_t)a.g.nx, gny = (uint32_t)a.g.ny, gnz = (uint32_t)a.g.nz;
-	const uint32_t yz_z0 = (gnz * xcd) >> 3, yz_L = ((gnz * (xcd + 1u)) >> 3) - yz_z0, yz_rows = yz_L * gny;
-	const uint32_t n_occ = yz ? gnx * gny * gnz : (FAT ? *a.n_heavy : *a.n_occ_i);
-	// (yz: positions are (ticket, counter) codes; hi is only the "nothing left" mark)
-	const uint32_t lo = yz ? 0u : (uint32_t)(((uint64_t)n_occ * xcd) >> 3), hi = yz ? 0xffffffffu : (uint32_t)(((uint64_t)n_occ * (xcd + 1u)) >> 3);
-	const uint32_t n_slice = yz ? yz_rows * gnx : hi - lo;
-#else
 	const uint32_t n_occ = FAT ? *a.n_heavy : *a.n_occ_i;
+	const uint32_t xcd = blockIdx.x & 7u;
 	const uint32_t lo = (uint32_t)(((uint64_t)n_occ * xcd) >> 3), hi = (uint32_t)(((uint64_t)n_occ * (xcd + 1u)) >> 3);
-	const uint32_t n_slice = hi - lo;
-#endif
 	// more waves than cells (short worklists of the later tiers): the surplus leaves without touching the counter
-	if ((blockIdx.x >> 3) * Q_WAVES + threadIdx.x / WAVE >= n_slice) return;
+	if ((blockIdx.x >> 3) * Q_WAVES + threadIdx.x / WAVE >= hi - lo) return;
 	PoolState ps = { 0u, 0u, 0u, 0u, 0u };
 	uint32_t wave_hits = 0;
 
@@ -1045,30 +1027,14 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 	// pass over millions of cheap cells.  Every XCD's share of the cell list is therefore cut into CTRL_SUBRANGES contiguous
 	// pieces with a counter each; a wave starts on piece (its index % CTRL_SUBRANGES) and moves on to the next piece when one
 	// is used up, until all are.
-	const uint32_t span = n_slice;
+	const uint32_t span = hi - lo;
 	uint32_t sub = readfirstlane_u32(((blockIdx.x >> 3) * Q_WAVES + threadIdx.x / WAVE) % CTRL_SUBRANGES), used_up = 0;
 	auto sub_begin = [&](uint32_t k) { return lo + (uint32_t)(((uint64_t)span * k) / CTRL_SUBRANGES); };
 	uint32_t cur_lo = sub_begin(sub), cur_hi = sub_begin(sub + 1u);
 	auto take = [&]() { uint32_t t = 0; if (lane == 0) t = atomicAdd(tickets + (xcd * CTRL_SUBRANGES + sub) * CTRL_STRIDE_U32, 1u); return t; };
-#if TNSX_YZ_TICKETS
-	// counter k owns the rows q = k, k + 8, ... of the slab's row sequence: ((rows - k + 7) / 8) * nx cells
-	auto yz_cells = [&](uint32_t k) { return yz_rows > k ? ((yz_rows - k + CTRL_SUBRANGES - 1u) / CTRL_SUBRANGES) * gnx : 0u; };
-	const uint32_t yz_mx = 0xffffffffu / gnx + 1u, yz_ml = 0xffffffffu / (yz_L ? yz_L : 1u) + 1u;   // (exact quotients for the operand ranges here: n * d < 2^32)
-	uint32_t yz_left = yz_cells(sub);
-#endif
 	// a returned ticket -> position in the cell list (>= hi: nothing is left anywhere on this XCD)
 	auto resolve = [&](uint32_t pending) -> uint32_t {
 		uint32_t t = readfirstlane_u32(pending);
-#if TNSX_YZ_TICKETS
-		if (yz) {
-			while (t >= yz_left) {
-				if (++used_up >= CTRL_SUBRANGES) return hi;
-				sub = (sub + 1u) % CTRL_SUBRANGES; yz_left = yz_cells(sub);
-				t = readfirstlane_u32(take());
-			}
-			return t * CTRL_SUBRANGES + sub;     // (ticket, counter): decoded by entry()
-		}
-#endif
 		while (cur_lo + t >= cur_hi) {
 			if (++used_up >= CTRL_SUBRANGES) return hi;
 			sub = (sub + 1u) % CTRL_SUBRANGES; cur_lo = sub_begin(sub); cur_hi = sub_begin(sub + 1u);
@@ -1076,21 +1042,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 		}
 		return cur_lo + t;
 	};
-#if TNSX_YZ_TICKETS
-	auto entry = [&](uint32_t first) -> uint2 {
-		if (yz) {
-			if (first >= hi) return make_uint2(0u, 0u);
-			const uint32_t t = first / CTRL_SUBRANGES, k = first % CTRL_SUBRANGES;
-			const uint32_t rq = __umulhi(t, yz_mx), x = t - rq * gnx;        // t / nx, t % nx
-			const uint32_t q = rq * CTRL_SUBRANGES + k;
-			const uint32_t y = __umulhi(q, yz_ml), z = yz_z0 + (q - y * yz_L);
-			return make_uint2(0u, (z * gny + y) * gnx + x);
-		}
-		return cell_list[first < hi ? first : lo];
-	};
-#else
 	auto entry = [&](uint32_t first) { return cell_list[first < hi ? first : lo]; };   // uniform address; clamped, never out of range
-#endif
 	uint2 rej = make_uint2(0u, 0u);
 	uint32_t rej_n = 0;
 	auto flush_rejects = [&]() {
@@ -1151,8 +1103,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 		qrange = a.table_i[have_next ? key_next : key];
 
 		const uint32_t nq = cur_q.y - cur_q.x;
-		const bool empty_cell = TNSX_YZ_TICKETS && nq == 0u;   // (only the experiment's walk over ALL grid cells meets cells without a query point)
-		bool pass_on = !empty_cell && (RR.total > 2u * (uint32_t)Q_SLOTS || nq > (uint32_t)WAVE);
+		bool pass_on = RR.total > 2u * (uint32_t)Q_SLOTS || nq > (uint32_t)WAVE;
 		bool fat_culled = false;
 #if TNSX_LANE_OPAQUE
 		// The cell bodies use slot numbers k * 64 + lane for a dozen values of k (the validity of a last chunk, the survivors of the cull).  Left alone the
@@ -1164,8 +1115,7 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 #else
 		const int lane_c = lane;
 #endif
-		if (empty_cell) { /* nothing to do */ }
-		else if (!pass_on && !FAT && RR.total > (uint32_t)(VARIABLE ? TNSX_CULL_FROM_VARIABLE : TNSX_CULL_FROM)) {
+		if (!pass_on && !FAT && RR.total > (uint32_t)(VARIABLE ? TNSX_CULL_FROM_VARIABLE : TNSX_CULL_FROM)) {
 			// more candidates than the loop holds: cull them against the bounding box of the query points; the cell is done
 			// here if at most 512 survive
 			pass_on = !(TNSX_CULL && fast_cell_culled<ARITH, VARIABLE, SYM, SELF, false>(a, RR, lane_c, cur_q, ps, wave_hits, my_slots));
@@ -1176,14 +1126,9 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 		if (pass_on) {
 			// not for this tier: goes to the next tier's worklist.  Collected one entry per lane and appended 64 at a time: the
 			// worklist length is ONE counter, and e.g. a dense column of fluid sends most of its cells here.
-#if TNSX_YZ_TICKETS
-			if ((uint32_t)lane == rej_n) rej = make_uint2(yz ? cur_q.x : p0, key);
-#else
 			if ((uint32_t)lane == rej_n) rej = make_uint2(p0, key);
-#endif
 			if (++rej_n == (uint32_t)WAVE) { flush_rejects(); rej_n = 0; }
 		}
-		else if (empty_cell) { /* nothing to do */ }
 		else if (!FAT && RR.total > (uint32_t)(VARIABLE ? TNSX_CULL_FROM_VARIABLE : TNSX_CULL_FROM)) { /* done by the culled path above */ }
 		else if (fat_culled) { /* done by the culled path above */ }
 		else if (RR.total == 0u && a.shared_empty != 0u) {
