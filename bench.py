@@ -785,8 +785,11 @@ def main():
         "steady_state": {"runs_that_reused_the_grid": counts["speculated"], "runs_repeated_after_a_failed_assumption": counts["speculation_redos"],
                          "pool_retries": counts["pool_retries"], "cached_set_builds_skipped": counts["n_cached_sets"],
                          "heavy_tiers_launched_after_the_sync": counts["heavy_catchups"], "one_read_bucket_passes": counts["one_read_builds"]},
-        "cold_run": {"ms": round(cold_ms, 3), "dry_passes": cold_stats["cold_passes"],
-                     "note": "first step of the process: allocations + one count-only pass per pair + the sized pass"},
+        "cold_run": {"ms": round(cold_ms, 3), "dry_passes": cold_stats["cold_passes"], "sampled_count_passes": cold_stats.get("sampled_passes", 0),
+                     "pool_retries": cold_stats["pool_retries"],
+                     "note": "first step of the PROCESS: loading the code objects, allocations, bounds + first grid, per pair a count-only pass that sizes its pool (sets of "
+                             ">= 2^20 points: over every 32nd occupied cell, `sampled_count_passes`; smaller sets: over all cells, `dry_passes`) + the sized pass; a fresh "
+                             "engine in a warm process: profiles/r6_cold.txt"},
     }
     if workload == "c5" and world > 1:
         out["one_gpu_same_workload"] = one_gpu_reference(n_total)

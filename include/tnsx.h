@@ -171,6 +171,8 @@ typedef struct tnsx_stats {
 	int one_read_builds;          /* point sets whose bucket build read the input once in the last run (windows from the previous run) */
 	int heavy_catchups;           /* pool passes whose heavy tiers (cells with > 512 candidates or > 64 query points) were not launched with the first
 	                                 tier -- the previous run of the pair had no such cell -- and had to run after the run's synchronisation */
+	int sampled_passes;           /* count-only passes of the last run that looked at every 32nd occupied cell only (first run of a pair of a set of >= 2^20 points:
+	                                 the pool is sized from the scaled counts; cold_passes counts the full ones) */
 	int nan_fixups;               /* pool passes of the last run after which query points that entered no cell (NaN x: "no point") had their offsets pointed
 	                                 at the pool's empty record (a pass whose records do not add up to neighbours + queries; never in a run without such points) */
 } tnsx_stats;

@@ -613,8 +613,8 @@ def test_torch_csr_out_equals_host_csr_and_golden(name, exact_layout, oracle):
     assert ns.get_stats()["nan_fixups"] == 0
 
 
-@pytest.mark.parametrize("mirror", [False, True])
-def test_nan_points_inside_the_query_range_have_empty_lists(mirror, oracle):
+@pytest.mark.parametrize("mirror,exact", [(False, False), (True, False), (False, True), (True, True)], ids=["pool", "pool-mirror", "exact", "exact-mirror"])
+def test_nan_points_inside_the_query_range_have_empty_lists(mirror, exact, oracle):
     """A NaN x is "no point" (include/tnsx.h): it enters no cell, finds nothing and is found by nobody.  Scattered THROUGH the query range of a set searched in
     itself (round-5 advice: no query kernel ever wrote such a point's offset, and the compaction of the host mirror followed it), every such point must
     read as an EMPTY list -- through the device views, the device CSR and the gap-free host mirror -- and the others as if the NaN points did not exist."""
@@ -636,14 +636,17 @@ def test_nan_points_inside_the_query_range_have_empty_lists(mirror, oracle):
     want_offs = np.zeros(n + 1, np.int64)
     want_offs[1:] = np.cumsum(want_counts)
     want_idx = real[ri].astype(np.int32)              # (ascending inside every list: real is increasing)
-    ns = T.TreeNSearch(mirror_to_host=mirror)
+    ns = T.TreeNSearch(mirror_to_host=mirror, exact_layout=exact)
     ns.set_search_radius(r)
     src = bad if mirror else torch.from_numpy(bad).cuda()
     ns.add_point_set(src)
     ns.set_active_search(0, 0, True)
     for step in range(3):                             # the dry pass + sized pass, then two steady-state runs on the reused grid
         ns.run()
-        assert ns.get_stats()["nan_fixups"] == 1, "the records of the pass do not add up to neighbours + queries: the stray offsets are pointed at the empty record"
+        # pool layout: the records of the pass do not add up to neighbours + queries, so the stray offsets are pointed at the pool's empty record;
+        # exact layout: every such point gets a record of its own (one int: count 0) in the scan
+        assert ns.get_stats()["nan_fixups"] == (0 if exact else 1)
+        assert ns.get_stats()["n_neighbors"] == int(want_offs[-1])
         offs, idx = ns.neighbor_csr(0, 0)
         assert np.array_equal(offs, want_offs) and np.array_equal(idx, want_idx), f"run {step}"
         d_offs, d_idx = ns.neighbor_csr_torch(0, 0, sort_each=True)

@@ -383,3 +383,40 @@ def test_heavy_tiers_are_launched_after_the_sync_when_needed(oracle):
     st = nb.get_stats()
     assert st["speculation_redos"] == 1 and st["heavy_catchups"] == 0, st
     P.assert_same_csr(nb.neighbor_csr(0, 0), oracle.pair_search(pts2, pts2, radius=r, same_set=True), "bucket build, with a clump")
+
+
+def test_first_run_of_a_large_set_sizes_its_pool_from_a_sample(oracle):
+    """Round 6: the count-only pass in front of a pair's FIRST run looks at every 32nd occupied cell of a set of >= 2^20 points (tnsx_stats.sampled_passes) and the
+    pool is sized from the scaled counts; the lists are what they always were (the reference's digest), a pool that falls short is repaired like any other.
+    A uniform cloud (the sample is representative) and a dam break (dense column, thin floor, sparse spray: the regions differ by orders of magnitude)."""
+    import torch
+    import treensearch_amd as T
+    import cases as CS
+    from conftest import load_golden
+    for name in ("uniform_fixed_2000000",):
+        case = CS.by_name(name)
+        ns = P.make_engine(case, 0, device_inputs=True)
+        ns.run()
+        st = ns.get_stats()
+        assert st["sampled_passes"] == 1 and st["cold_passes"] == 0, str({k: st[k] for k in ("sampled_passes", "cold_passes", "pool_retries")})
+        assert st["pool_retries"] == 0, "a uniform cloud: the scaled sample must be enough"
+        P.assert_matches_golden({(0, 0): ns.neighbor_csr(0, 0, sort_each=False)}, load_golden(case.name), 0, oracle, name + " (sampled first run)", lists_sorted=False)
+        ns.run()
+        st = ns.get_stats()
+        assert st["sampled_passes"] == 0 and st["cold_passes"] == 0 and st["pool_retries"] == 0 and st["speculated"] == 1
+    from treensearch_amd import datagen as D
+    n = 5_000_000
+    p, rad, r0 = D.dam_break_cloud(n, 4321)
+    ns = T.TreeNSearch()
+    d_p, d_r = torch.from_numpy(p).cuda(), torch.from_numpy(rad).cuda()
+    ns.add_point_set(d_p, d_r); ns.set_active_search(0, 0, True); ns.set_symmetric_search(True)
+    ns.run()
+    st = ns.get_stats()
+    assert st["sampled_passes"] == 1 and st["cold_passes"] == 0 and st["pool_retries"] <= 1
+    ref = T.TreeNSearch(exact_layout=True)           # the two-pass layout never sizes anything from an estimate
+    ref.add_point_set(d_p, d_r); ref.set_active_search(0, 0, True); ref.set_symmetric_search(True)
+    ref.run()
+    assert st["n_neighbors"] == ref.get_stats()["n_neighbors"]
+    a_offs, a_idx = ns.neighbor_csr_torch(0, 0, sort_each=True)
+    b_offs, b_idx = ref.neighbor_csr_torch(0, 0, sort_each=True)
+    assert torch.equal(a_offs, b_offs) and torch.equal(a_idx, b_idx)

@@ -24,7 +24,7 @@ for k in range(engines):
     t3 = time.perf_counter()
     st2 = ns.get_stats()
     print(f"engine {k}: create {1e3 * (t1 - t0):.2f} ms | cold run {1e3 * (t2 - t1):.2f} ms wall (stages of its last attempt: total {st['ms_total']:.2f} bounds {st['ms_bounds']:.2f} "
-          f"sort {st['ms_sort']:.2f} cells {st['ms_cells']:.2f} fill {st['ms_fill']:.2f}; cold passes {st['cold_passes']}, pool retries {st['pool_retries']}) | "
+          f"sort {st['ms_sort']:.2f} cells {st['ms_cells']:.2f} fill {st['ms_fill']:.2f}; cold passes {st['cold_passes']}, sampled {st['sampled_passes']}, pool retries {st['pool_retries']}) | "
           f"second run {1e3 * (t3 - t2):.2f} ms wall (total {st2['ms_total']:.2f} fill {st2['ms_fill']:.2f}) | neighbours {st['n_neighbors']}")
     t4 = time.perf_counter()
     del ns

@@ -56,7 +56,7 @@ class Stats(C.Structure):
                 ("n_pool_pairs", C.c_int), ("pool_retries", C.c_int), ("cold_passes", C.c_int), ("speculated", C.c_int),
                 ("speculation_redos", C.c_int), ("n_cached_sets", C.c_int), ("n_filtered_cells", C.c_uint32), ("n_devices_used", C.c_int),
                 ("world_bottom", C.c_float * 3), ("world_top", C.c_float * 3), ("world_cells_pow2", C.c_int), ("zsort_cell_size_inv", C.c_float),
-                ("grid_trimmed", C.c_int), ("n_group_pairs", C.c_uint32), ("n_group_passed_cells", C.c_uint32), ("grid_sparse", C.c_int), ("one_read_builds", C.c_int), ("heavy_catchups", C.c_int), ("nan_fixups", C.c_int)]
+                ("grid_trimmed", C.c_int), ("n_group_pairs", C.c_uint32), ("n_group_passed_cells", C.c_uint32), ("grid_sparse", C.c_int), ("one_read_builds", C.c_int), ("heavy_catchups", C.c_int), ("sampled_passes", C.c_int), ("nan_fixups", C.c_int)]
 
     def as_dict(self):
         d = {}

@@ -562,10 +562,17 @@ static ZsPlan zs_plan(int key_bits)
 static int zs_key_grid(int n) { const int t = (n + ZS_KEY_TILE - 1) / ZS_KEY_TILE; return t < ZS_KEY_GRID ? (t < 1 ? 1 : t) : ZS_KEY_GRID; }
 static int zs_tiles(int n) { return (n + ZS_TILE - 1) / ZS_TILE; }
 // temp: [partial histograms: grid x passes x 2^ZS_MAX_BITS][digit bases: passes x 2^ZS_MAX_BITS][tickets: ZS_MAX_PASSES][status: passes x tiles x 2^bits]
-size_t zsort_temp_bytes(int n)
+#ifndef TNSX_ZS_PAIRS_FROM
+#define TNSX_ZS_PAIRS_FROM 25   // keys of this many bits and more take the pair sort; 16 .. 24 bits: one ranked pass + k_morton_place (measured against each other: profiles/r5_zsort.txt)
+#endif
+// the pair sort's look-back status word is {2-bit flag, 30-bit count} and its inclusive per-digit prefixes reach n: sets of 2^30 points and more keep the LSD passes
+static bool zs_uses_pairs(int n, int key_bits) { return n >= (1 << 16) && n < (1 << 30) && key_bits >= TNSX_ZS_PAIRS_FROM && key_bits <= 30; }
+size_t zsort_temp_bytes(int n, int key_bits)
 {
+	if (!zs_uses_pairs(n, key_bits)) return 0;   // (the other paths live in cell_sort_temp_bytes)
 	const size_t R = (size_t)1 << ZS_MAX_BITS;
-	return ((size_t)ZS_KEY_GRID * ZS_MAX_PASSES * R + (size_t)ZS_MAX_PASSES * R + 64 + (size_t)ZS_MAX_PASSES * (size_t)zs_tiles(n > 0 ? n : 1) * R) * sizeof(uint32_t) + 256;
+	// the status words only of the passes this key takes (round-5 advice: four passes' worth was 400 MB at 200 M points, for every key width)
+	return ((size_t)ZS_KEY_GRID * ZS_MAX_PASSES * R + (size_t)ZS_MAX_PASSES * R + 64 + (size_t)zs_plan(key_bits).passes * (size_t)zs_tiles(n) * R) * sizeof(uint32_t) + 256;
 }
 struct ZsPlanDev { int passes; int bits[ZS_MAX_PASSES]; int shift[ZS_MAX_PASSES]; };
 __global__ void __launch_bounds__(ZS_KEY_THREADS) k_zs_keys(const float* __restrict__ xyz, int n, GridParams g, ZsPlanDev plan, uint2* __restrict__ pairs, uint32_t* __restrict__ part)
@@ -774,9 +781,6 @@ static void launch_zsort_pairs(const float* xyz, int n, GridParams g, int key_bi
 	}
 }
 
-#ifndef TNSX_ZS_PAIRS_FROM
-#define TNSX_ZS_PAIRS_FROM 25   // keys of this many bits and more take the pair sort; 16 .. 24 bits: one ranked pass + k_morton_place (measured against each other: profiles/r5_zsort.txt)
-#endif
 int launch_morton_sort(const float* xyz, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, int* order_out, hipStream_t s)
 {
 	if (n >= (1 << 16) && key_bits >= 16 && key_bits <= 24 && key_bits < TNSX_ZS_PAIRS_FROM) {
@@ -796,7 +800,7 @@ int launch_morton_sort(const float* xyz, int n, GridParams g, int key_bits, cons
 		hipLaunchKernelGGL(k_morton_place, dim3(1 << hi_bits), dim3(BP_THREADS), lds, s, b.xyzi[1], order_out, g, lo_bits, totals);
 		return 1;
 	}
-	if (n >= (1 << 16) && key_bits >= TNSX_ZS_PAIRS_FROM && key_bits <= 30) {   // round 5: {key, index} pairs through single-pass digit sorts (above)
+	if (zs_uses_pairs(n, key_bits)) {   // round 5: {key, index} pairs through single-pass digit sorts (above)
 		launch_zsort_pairs(xyz, n, g, key_bits, b, temp, order_out, s);
 		return 1;
 	}

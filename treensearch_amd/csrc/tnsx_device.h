@@ -78,6 +78,22 @@ __device__ __forceinline__ void wave_bbox(float& x0, float& y0, float& z0, float
 	x0 = readlane_f32(x0, 63); y0 = readlane_f32(y0, 63); z0 = readlane_f32(z0, 63);
 	x1 = readlane_f32(x1, 63); y1 = readlane_f32(y1, 63); z1 = readlane_f32(z1, 63);
 }
+// the same over lanes 0..15 only (a cell's query points when there are at most sixteen of them: the usual case): four DPP steps instead of six
+__device__ __forceinline__ void wave_bbox16(float& x0, float& y0, float& z0, float& x1, float& y1, float& z1)
+{
+#define TNSX_DPP_STEP(pre, ctl)                                                                                          \
+	asm volatile(pre "v_min_f32_dpp %0, %0, %0 " ctl "\n\tv_min_f32_dpp %1, %1, %1 " ctl "\n\tv_min_f32_dpp %2, %2, %2 " ctl "\n\t" \
+	                 "v_max_f32_dpp %3, %3, %3 " ctl "\n\tv_max_f32_dpp %4, %4, %4 " ctl "\n\tv_max_f32_dpp %5, %5, %5 " ctl          \
+	             : "+v"(x0), "+v"(y0), "+v"(z0), "+v"(x1), "+v"(y1), "+v"(z1))
+	TNSX_DPP_STEP("s_nop 1\n\t", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+	TNSX_DPP_STEP("", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+	TNSX_DPP_STEP("", "row_half_mirror row_mask:0xf bank_mask:0xf");
+	TNSX_DPP_STEP("", "row_mirror row_mask:0xf bank_mask:0xf");
+#undef TNSX_DPP_STEP
+	asm volatile("s_nop 1" ::: );
+	x0 = readlane_f32(x0, 0); y0 = readlane_f32(y0, 0); z0 = readlane_f32(z0, 0);
+	x1 = readlane_f32(x1, 0); y1 = readlane_f32(y1, 0); z1 = readlane_f32(z1, 0);
+}
 // wave-wide maximum of one value (same scheme; s_nop between the dependent DPP steps)
 __device__ __forceinline__ float wave_max_dpp(float v)
 {

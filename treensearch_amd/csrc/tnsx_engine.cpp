@@ -130,6 +130,7 @@ struct PairResult {
 	bool pooled = false;         // pool layout: int 0 of `records` is THE empty record (count 0), the regions start behind it
 	bool shared_empty = false;   // ... and every offset is pre-set to it, so that cells without a candidate write nothing (pairs of two different sets)
 	bool dry = false;            // this pass only counts (first run of a pair: nothing is known about its size yet)
+	uint32_t sample_stride = 1;  // ... over every sample_stride-th occupied cell only (large sets: the counts are scaled up; the sized pass behind it is repaired if they fell short)
 	uint32_t n_cells_i = 0;      // occupied cells of set i in the previous run
 	bool groups_off = false;     // the group formulation sent too much of this pair to its leftover kernel: cell kernels from now on
 	bool groups_now = false;     // this attempt runs the group formulation
@@ -1237,6 +1238,11 @@ static tnsx::QueryArgs make_query_args(RunAttempt& run, const RunJob& jb, PairRe
 		a.occ_i = pr.filtered.as<uint2>();
 		a.n_occ_i = ctrl_slot(k, tnsx::CTRL_NFILTERED);
 	}
+	else if (pr.dry && pr.sample_stride > 1) {
+		// a count-only pass over a SAMPLE of the occupied cells (launch_pool_pass; the list and its length share buffer and counter with the presence filter)
+		a.occ_i = pr.filtered.as<uint2>();
+		a.n_occ_i = ctrl_slot(k, tnsx::CTRL_NFILTERED);
+	}
 	return a;
 }
 
@@ -1274,6 +1280,18 @@ static tnsx_status launch_pool_pass(RunAttempt& run, size_t k, int tiers, bool f
 			tnsx::launch_mark_cells(B.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.j, g, map, 0, max_cells_j, st);
 		}
 	}
+	// Round 6: the count-only pass that sizes the pool of a pair's first run looks at every 32nd occupied cell of a large set (C2: 25 k of 804 k cells, 1/32 of the
+	// 1.45 ms a full count costs).  The list is in key order and an XCD works on a fixed eighth of it, so the sample of an eighth is the sample of that XCD's region;
+	// the counts are scaled by the stride (collect_pair) and the sized pass keeps its margins (a quarter / a half more than counted) and its repair.
+	pr.sample_stride = 1;
+	if (pr.dry && (tiers & 1) && !pr.shared_empty && !sparse && pr.n_i >= (1 << 20) && !(c->opt.query_formulation == 1 && tnsx_query_formulation_available(1) != 0)) {
+		const PointSet& A = c->sets[jb.i];
+		pr.sample_stride = 32;
+		const size_t max_cells = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pr.n_i, n_cells));
+		HIPCHK(c, pr.filtered.reserve((max_cells / pr.sample_stride + 2) * sizeof(uint2)));
+		tnsx::launch_sample_cells(A.occ.as<uint2>(), c->n_occ.as<uint32_t>() + jb.i, pr.sample_stride, pr.filtered.as<uint2>(), ctrl_slot(k, tnsx::CTRL_NFILTERED),
+		                          max_cells / pr.sample_stride + 1, st);
+	}
 	if (pr.n_i > 0) {
 		qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_POOL;
 		// opt-in (tnsx_options.query_formulation = 1), fixed radius, a set searched in itself: the group formulation (tools/ubench/tnsx_query_group.hip, variant builds only)
@@ -1297,8 +1315,10 @@ static tnsx_status launch_pool_pass(RunAttempt& run, size_t k, int tiers, bool f
 		rj.d_heavy = ctrl_slot(k, tnsx::CTRL_NHEAVY); rj.h_heavy = h_heavy + k;
 		return TNSX_OK;
 	}
-	HIPCHK(c, hipMemcpy2DAsync(h_ctrl + HC * k, tnsx::POOL_CTRL_WORDS * sizeof(uint64_t), ctrl_slot(k, tnsx::CTRL_CURSOR), tnsx::CTRL_STRIDE_U32 * sizeof(uint32_t),
-	                           tnsx::POOL_CTRL_WORDS * sizeof(uint64_t), PairResult::NR, hipMemcpyDeviceToHost, st));
+	// (one plain copy per region: the first hipMemcpy2DAsync of a process costs 6.7 ms -- it loads the runtime's blit kernels -- and this is the cold run's path)
+	for (int r = 0; r < PairResult::NR; r++)
+		HIPCHK(c, hipMemcpyAsync(h_ctrl + HC * k + (size_t)r * tnsx::POOL_CTRL_WORDS, ctrl_slot(k, tnsx::CTRL_CURSOR) + (size_t)r * tnsx::CTRL_STRIDE_U32,
+		                         tnsx::POOL_CTRL_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
 	if (h_count) HIPCHK(c, hipMemcpyAsync(h_count, ctrl_slot(k, tnsx::CTRL_NFILTERED), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 	HIPCHK(c, hipMemcpyAsync(h_heavy + k, ctrl_slot(k, tnsx::CTRL_NHEAVY), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 	return TNSX_OK;
@@ -1332,7 +1352,9 @@ static tnsx_status launch_queries(RunAttempt& run)
 			const int t0 = tm.mark();
 			if (n_i > 0) {
 				qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_COUNT;
-				tnsx::launch_query(make_query_args(run, jb, pr, k), qc, c->n_cus, st);
+				const tnsx::QueryArgs qa = make_query_args(run, jb, pr, k);
+				tnsx::launch_exact_nan(qa.xyzi_i, qa.orig_i, n_i, qa.query_limit, qa.counts, nullptr, nullptr, nullptr, 0, st);   // (points that enter no cell: NaN x)
+				tnsx::launch_query(qa, qc, c->n_cus, st);
 			}
 			const int t1 = tm.mark();
 			tnsx::exclusive_scan_u32_to_u64(pr.counts.as<uint32_t>(), pr.offs_sorted.as<uint64_t>(), (size_t)n_i, c->scan_temp.p, st);
@@ -1418,7 +1440,16 @@ static tnsx_status collect_pair(RunAttempt& run, size_t k)
 		for (int attempt = 0; !c->debug_nostore && (pr.dry || hc[(size_t)tnsx::POOL_OVERFLOW * tnsx::POOL_CTRL_WORDS] > pr.region_cap[tnsx::POOL_OVERFLOW]); attempt++) {
 			if (attempt >= 5) TNSX_FAIL(c, TNSX_ERR_HIP, "neighbour pool kept overflowing (%llu neighbours)", (unsigned long long)n_neighbors);
 			const bool was_dry = pr.dry;
-			if (pr.dry) { pr.dry = false; S.cold_passes++; }   // the dry pass counted everything: the real pass is sized exactly
+			if (pr.dry) {
+				pr.dry = false;
+				if (pr.sample_stride > 1) {
+					// the pass looked at every sample_stride-th cell: scale what it counted (the margins of a pool sized after a dry pass cover the sampling error)
+					for (int r = 0; r < PairResult::NR; r++) payload[r] *= pr.sample_stride;
+					S.sampled_passes++;
+					pr.sample_stride = 1;
+				}
+				else S.cold_passes++;   // the dry pass counted everything: the real pass is sized exactly
+			}
 			else {
 #ifdef TNSX_BUILD_DEBUG_POOL
 				fprintf(stderr, "[tnsx] pool overflow pair %zu: overflow region asked %llu of %llu, slab %u n_i %d\n", k,
@@ -1463,7 +1494,9 @@ static tnsx_status collect_pair(RunAttempt& run, size_t k)
 		const int t0 = tm.mark();
 		if (pr.n_i > 0) {
 			qc.self = jb.i == jb.j; qc.mode = tnsx::QUERY_FILL;
-			tnsx::launch_query(make_query_args(run, jb, pr, k), qc, c->n_cus, st);
+			const tnsx::QueryArgs qa = make_query_args(run, jb, pr, k);
+			tnsx::launch_query(qa, qc, c->n_cus, st);
+			tnsx::launch_exact_nan(qa.xyzi_i, qa.orig_i, pr.n_i, qa.query_limit, nullptr, qa.offs_sorted, qa.records, qa.offs_by_orig, 1, st);
 		}
 		const int t1 = tm.mark();
 		span(ST_FILL, t0, t1);
@@ -1744,7 +1777,7 @@ tnsx_status tnsx_prepare_zsort(tnsx_context* c)
 		s.zsort_ready = true;
 		if (s.n == 0) continue;
 		for (int k = 0; k < 2; k++) HIPCHK(c, s.xyzi[k].reserve((size_t)s.n * sizeof(float4)));
-		HIPCHK(c, c->sort_temp.reserve(std::max(tnsx::cell_sort_temp_bytes(s.n), tnsx::zsort_temp_bytes(s.n))));
+		HIPCHK(c, c->sort_temp.reserve(std::max(tnsx::cell_sort_temp_bytes(s.n), tnsx::zsort_temp_bytes(s.n, key_bits))));
 		HIPCHK(c, s.zsort_dev.reserve((size_t)s.n * sizeof(int)));
 		// Morton key of the point's cell on the reference grid (cell-level order, stable => deterministic): the same
 		// point-moving radix sort as the search structure, the order is the index column of the sorted points

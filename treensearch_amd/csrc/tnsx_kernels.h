@@ -79,7 +79,7 @@ void launch_set_checksum(const float* xyz, const float* radii, int n, unsigned l
 // order; prepare_zsort): g.ox/oy/oz = world bottom, g.inv_h = 1 / cell size, g.nx = cells per axis (a power of two), 3 * log2(nx)
 // key bits.  order_out[p] = original index of the p-th point in z-order.
 int launch_morton_sort(const float* xyz, int n, GridParams g, int key_bits, const CellSortBuffers& b, void* temp, int* order_out, hipStream_t s);
-size_t zsort_temp_bytes(int n);   // temp of launch_morton_sort: max(cell_sort_temp_bytes(n), this)
+size_t zsort_temp_bytes(int n, int key_bits);   // temp of launch_morton_sort: max(cell_sort_temp_bytes(n), this)
 // Cell table: table[key] = (first sorted position, one past last); occ = {first sorted position, key} of every occupied cell
 // (order of blocks of 4096 points is arbitrary), *n_occ = their number (must be zeroed before)
 void launch_cell_table(const float4* xyzi_sorted, int n, GridParams g, uint2* table, uint2* occ, uint32_t* n_occ, hipStream_t s);
@@ -189,8 +189,14 @@ void launch_slab_rows_to_points(const float* rows, size_t n_rows, int W, float* 
 //      n_shared_empty > 0 (a pair of two different sets): offs[0..n) = 0 and records[0] = 0, the shared empty record at int 0 of the pool.
 //      (On its own only for the repeat of a pass and for runs with more pool passes than launch_run_begin takes.)
 void launch_pool_begin(const unsigned long long* regions, uint32_t* ctrl, uint64_t* offs, size_t n_shared_empty, int* records, hipStream_t s);
+// dst[i] = src[i * stride + stride / 2] for i < ceil(*n_src / stride), *n_dst = that number (the worklist of a count-only pass over a sample of the occupied cells)
+void launch_sample_cells(const uint2* src, const uint32_t* n_src, uint32_t stride, uint2* dst, uint32_t* n_dst, size_t max_dst, hipStream_t s);
 // offs[p] = 0 (the pool's empty record) for every p < n whose x is NaN ("no point": it entered no cell and no query wrote its offset); xyz: 3 floats per point
 void launch_point_nan_offsets(const float* xyz, int n, uint64_t* offs, hipStream_t s);
+// the same for the exact layout (NaN-x points: the tail of the sorted array): phase 0 before the count pass (counts[p] = 1 for a query, 0 otherwise), phase 1 after the
+// fill pass (count word 0 + offset of such a query)
+void launch_exact_nan(const float4* xyzi_sorted, const uint32_t* orig_sorted, int n, uint32_t query_limit, uint32_t* counts, const uint64_t* offs_sorted, int* records,
+                      uint64_t* offs_by_orig, int phase, hipStream_t s);
 // ---- start of a run, ONE launch (round 4; every kernel of a step costs ~5 us of dispatch whatever it does):
 //      words[0..n_words) = 0 (guard flag, partial checksums), n_occ[si] = 0 for every set si whose bit is set in `sets` (si < 64),
 //      zero[k][0..n_zero[k]) = 0 (the cursors of the one-read bucket pass),

@@ -652,6 +652,42 @@ void launch_point_nan_offsets(const float* xyz, int n, uint64_t* offs, hipStream
 {
 	if (n > 0) hipLaunchKernelGGL(k_point_nan_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xyz, n, offs);
 }
+// The same in the exact (two-pass) layout.  There the NaN-x points sit behind all cells of the SORTED array (the stable sort keys them behind everything) and no
+// query kernel visits them: phase 0 (before the count pass) gives each of them that is a query a record of one int -- its count word -- in the scan, phase 1 (after
+// the fill pass) writes that count word (0) and the offset.
+__global__ void __launch_bounds__(256) k_exact_nan(const float4* __restrict__ xyzi, const uint32_t* __restrict__ orig_sorted, int n, uint32_t query_limit, uint32_t* __restrict__ counts,
+                                                   const uint64_t* __restrict__ offs_sorted, int* __restrict__ records, uint64_t* __restrict__ offs_by_orig, int phase)
+{
+	const int p = blockIdx.x * 256 + threadIdx.x;
+	if (p >= n) return;
+	const float x = xyzi[p].x;
+	if (x == x) return;
+	const uint32_t orig = orig_sorted ? orig_sorted[p] : __float_as_uint(xyzi[p].w);
+	const bool is_query = orig < query_limit;
+	if (phase == 0) counts[p] = is_query ? 1u : 0u;
+	else if (is_query) { const uint64_t o = offs_sorted[p]; records[o] = 0; offs_by_orig[orig] = o; }
+}
+void launch_exact_nan(const float4* xyzi, const uint32_t* orig_sorted, int n, uint32_t query_limit, uint32_t* counts, const uint64_t* offs_sorted, int* records,
+                      uint64_t* offs_by_orig, int phase, hipStream_t s)
+{
+	if (n > 0) hipLaunchKernelGGL(k_exact_nan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xyzi, orig_sorted, n, query_limit, counts, offs_sorted, records, offs_by_orig, phase);
+}
+// every stride-th entry of a cell list (the middle one of each group) -> dst, *n_dst = their number: the worklist of a sampled count-only pass
+__global__ void __launch_bounds__(256) k_sample_cells(const uint2* __restrict__ src, const uint32_t* __restrict__ n_src_p, uint32_t stride, uint2* __restrict__ dst, uint32_t* __restrict__ n_dst)
+{
+	const uint32_t n_src = *n_src_p, n = (n_src + stride - 1u) / stride;
+	if (blockIdx.x == 0 && threadIdx.x == 0) *n_dst = n;
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+		const uint32_t j = i * stride + stride / 2u;
+		dst[i] = src[j < n_src ? j : n_src - 1u];
+	}
+}
+void launch_sample_cells(const uint2* src, const uint32_t* n_src, uint32_t stride, uint2* dst, uint32_t* n_dst, size_t max_dst, hipStream_t s)
+{
+	size_t blocks = (max_dst + 255) / 256;
+	blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+	hipLaunchKernelGGL(k_sample_cells, dim3((unsigned)blocks), dim3(256), 0, s, src, n_src, stride, dst, n_dst);
+}
 void launch_pool_begin(const unsigned long long* regions, uint32_t* ctrl, uint64_t* offs, size_t n_shared_empty, int* records, hipStream_t s)
 {
 	static_assert(CTRL_SLOTS <= 256, "one thread per slot");

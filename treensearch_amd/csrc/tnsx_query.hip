@@ -30,6 +30,7 @@ namespace tnsx {
 // the query
 // =====================================================================================================
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 #ifndef TNSX_CULL_FROM
 #define TNSX_CULL_FROM 448   // fixed radius: cells with more candidates than this are culled first (measured: 512 / 448 / 384 -> C2 1.775 / 1.766 / 2.003 ms,
@@ -946,11 +947,212 @@ __device__ __forceinline__ bool fast_cell_culled(const QueryArgs& a, const RunRe
 	return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: bounding-box cull IN REGISTERS for cells that fit the first tier's loop anyway (5..7 chunks: C2, C3, C5), survivors compacted through the
+// wave's LDS staging area.  The cull above (fast_cell_culled) was measured to LOSE on such cells (C2 1.58 -> 1.86 ms): it loads the coordinates, stages the
+// survivors' SLOT NUMBERS and loads the survivors a second time from global memory through two dependent LDS reads -- a second memory round trip per cell.
+// Here the candidates are loaded ONCE, as always; the bound is evaluated on the registers; the surviving float4s are written to the staging area in slot
+// order (ds_write_b128; the area holds the deal table before and the cell's records after, it is empty in between) and read back as 4.2 chunks instead of
+// 6.4 for the query loop.  Own cell first: the centre run [own | x + 1] is kept whole and the compaction preserves the slot order, so query t still is
+// candidate slot t.  Fixed radius and per-point radii without symmetry (the symmetric predicate needs r_j^2 beside the point: five words per survivor).
+// Exactness: b = c - med3(c, lo, hi) is 0 inside [lo, hi], fl(c - lo) below, fl(c - hi) above; |fl(q - c)| >= |b| for every query coordinate q in [lo, hi]
+// (rounding is monotone), squares, sums and fmas preserve the order, so d2(q, c) >= d2lb(c) in the predicate's own arithmetic for all queries of the cell.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef TNSX_REG_CULL
+#define TNSX_REG_CULL 1
+#endif
+#ifndef TNSX_REG_CULL_FROM
+#define TNSX_REG_CULL_FROM 4   // chunks: below, the cull's per-cell cost exceeds what the shorter loop saves (profiles/r6_reg_cull.txt)
+#endif
+#ifndef TNSX_REG_CULL_SYM
+#define TNSX_REG_CULL_SYM 0    // 1: also for the symmetric predicate of per-point radii (r_j^2 travels through the staging area beside the point).  Measured at C4: +2.3 % (five
+                               // words per survivor, 16 bytes of scratch in those instantiations): off (profiles/r6_reg_cull.txt)
+#endif
+// lanes [0, min(n, 64)) as a scalar mask (n wave-uniform)
+__device__ __forceinline__ uint64_t low_lanes(uint32_t n)
+{
+	uint64_t m;
+	const uint32_t ns = readfirstlane_u32(n);   // (an "s" operand the compiler holds in a vector register is not moved for us)
+	asm("s_bfm_b64 %0, %1, 0\n\ts_cmp_gt_u32 %1, 63\n\ts_cselect_b64 %0, -1, %0" : "=s"(m) : "s"(ns) : "scc");
+	return m;
+}
+// survivors the staging area holds: float4 per survivor, + its r_j^2 behind the float4s when the predicate is symmetric
+template <bool SYM> struct RegCull {
+	static constexpr uint32_t cap = SYM ? StageSize<8>::ints / 5u : StageSize<8>::ints / 4u;   // 307 / 384
+	static constexpr uint32_t r2_word = cap * 4u;                                              // first word of the r^2 column
+};
+// squared lower bound of the distance of candidate (cx, cy, cz) to the box [lo, hi], in the predicate's arithmetic.  Spelled out: left to itself the compiler pairs
+// the three axes of two chunks into packed instructions and spends as many v_mov on the pairing as the packing saves.
+template <int ARITH>
+__device__ __forceinline__ float box_d2lb(float cx, float cy, float cz, float lox, float loy, float loz, float hxv, float hyv, float hzv)
+{
+	float t0, t1, t2;
+	if (ARITH == 0) {
+		asm("v_med3_f32 %0, %3, %6, %9\n\tv_med3_f32 %1, %4, %7, %10\n\tv_med3_f32 %2, %5, %8, %11\n\t"
+		    "v_sub_f32 %0, %3, %0\n\tv_sub_f32 %1, %4, %1\n\tv_sub_f32 %2, %5, %2\n\t"
+		    "v_mul_f32 %0, %0, %0\n\tv_mul_f32 %1, %1, %1\n\tv_mul_f32 %2, %2, %2\n\t"
+		    "v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2"
+		    : "=&v"(t0), "=&v"(t1), "=&v"(t2) : "v"(cx), "v"(cy), "v"(cz), "s"(lox), "s"(loy), "s"(loz), "v"(hxv), "v"(hyv), "v"(hzv));
+	}
+	else {
+		asm("v_med3_f32 %0, %3, %6, %9\n\tv_med3_f32 %1, %4, %7, %10\n\tv_med3_f32 %2, %5, %8, %11\n\t"
+		    "v_sub_f32 %0, %3, %0\n\tv_sub_f32 %1, %4, %1\n\tv_sub_f32 %2, %5, %2\n\t"
+		    "v_mul_f32 %1, %1, %1\n\tv_fmac_f32 %1, %0, %0\n\tv_fmac_f32 %1, %2, %2\n\tv_mov_b32 %0, %1"
+		    : "=&v"(t0), "=&v"(t1), "=&v"(t2) : "v"(cx), "v"(cy), "v"(cz), "s"(lox), "s"(loy), "s"(loz), "v"(hxv), "v"(hyv), "v"(hzv));
+	}
+	return t0;
+}
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int NC>
+__device__ __forceinline__ uint32_t cull_cell_to_stage(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, float4& qv, float& qr2, uint32_t& qorig)
+{
+	constexpr bool OWN_FIRST = SELF;
+	constexpr uint32_t CAP = RegCull<SYM>::cap;
+	const uint32_t nq = cur_q.y - cur_q.x;
+	const Runs R = extract_runs_t<OWN_FIRST>(RR.run_start, RR.run_len, cur_q.x);
+	uint32_t* const tbl = record_stage<(int)StageSize<8>::ints>();
+	deal_table<OWN_FIRST>(readfirstlane_u32((uint32_t)(uintptr_t)tbl), R, (uint32_t)lane);
+	float4 craw[NC];
+	float r2raw[NC];
+	#pragma unroll
+	for (int k = 0; k < NC; k++) {
+		const uint32_t slot = (uint32_t)(k * WAVE + lane);
+		const uint32_t src = (k < NC - 1 || slot < R.total) ? tbl[slot] : R.d0;
+		craw[k] = a.xyzi_j[src];
+		if (SYM) r2raw[k] = a.r2_j[src];
+	}
+	const uint32_t qsrc = cur_q.x + ((uint32_t)lane < nq ? (uint32_t)lane : 0u);   // (lanes beyond nq repeat the first point: harmless for the box)
+	qv = a.xyzi_i[qsrc];
+	qorig = a.orig_i ? a.orig_i[qsrc] : __float_as_uint(qv.w);
+	qr2 = a.r2_fixed;
+	if (VARIABLE) qr2 = a.r2_i[qsrc];
+	float lox = qv.x, loy = qv.y, loz = qv.z, hix = qv.x, hiy = qv.y, hiz = qv.z;
+	if (nq <= 16u) wave_bbox16(lox, loy, loz, hix, hiy, hiz);
+	else wave_bbox(lox, loy, loz, hix, hiy, hiz);
+	const float lim = VARIABLE ? wave_max_dpp(qr2) : a.r2_fixed;
+	// (v_med3_f32 may read ONE scalar register: the upper corner of the box lives in three vector registers for the whole cull)
+	float hxv = hix, hyv = hiy, hzv = hiz;
+	asm volatile("" : "+v"(hxv), "+v"(hyv), "+v"(hzv));
+	lox = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lox)));   // ("s" operands of box_d2lb: the compiler does not move one out of a vector register for us)
+	loy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(loy)));
+	loz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(loz)));
+	const uint32_t stage_base = readfirstlane_u32((uint32_t)(uintptr_t)tbl);
+	uint32_t kept = 0;
+	bool fits = true;
+	#pragma unroll
+	for (int k = 0; k < NC; k++) {
+		const float4 c = craw[k];
+		const float d2lb = box_d2lb<ARITH>(c.x, c.y, c.z, lox, loy, loz, hxv, hyv, hzv);
+		// survivors of this chunk: the bound, OR the slots of the centre run (kept whole: scalar mask), AND the chunk's valid slots (scalar mask)
+		uint64_t m = __builtin_amdgcn_ballot_w64(d2lb <= (SYM ? max_raw(lim, r2raw[k]) : lim));
+		const uint32_t first = (uint32_t)(k * WAVE);
+		const uint32_t own = R.p1 > first ? R.p1 - first : 0u;
+		if (k <= 1) m |= low_lanes(own);            // (a centre run of more than 128 slots would be a cell of the heavy tiers)
+		else if (own != 0u) { fits = false; break; }
+		if (k == NC - 1) m &= low_lanes(R.total - first);
+		const uint32_t n = (uint32_t)__popcll(m);
+		if (kept + n > CAP) { fits = false; break; }   // (rare: the caller takes the plain path)
+		// lane l of the mask -> slot kept + (set bits below l); one ds_write_b128 (and one ds_write_b32 for r_j^2) under the mask
+		uint32_t pos = mbcnt64(m);
+		const v4f cv = { c.x, c.y, c.z, c.w };
+		if (SYM) {
+			uint32_t ad2;
+			asm volatile("v_lshl_add_u32 %[a2], %[ad], 2, %[base2]\n\t"
+			             "v_lshl_add_u32 %[ad], %[ad], 4, %[base]\n\t"
+			             "s_mov_b64 exec, %[m]\n\t"
+			             "ds_write_b128 %[ad], %[v]\n\t"
+			             "ds_write_b32 %[a2], %[r]\n\t"
+			             "s_mov_b64 exec, -1"
+			             : [ad] "+v"(pos), [a2] "=&v"(ad2)
+			             : [base] "s"(readfirstlane_u32(stage_base + (kept << 4))), [base2] "s"(readfirstlane_u32(stage_base + 4u * RegCull<SYM>::r2_word + (kept << 2))), [m] "s"(m),
+			               [v] "v"(cv), [r] "v"(r2raw[k]) : "memory");
+		}
+		else {
+			asm volatile("v_lshl_add_u32 %[ad], %[ad], 4, %[base]\n\t"
+			             "s_mov_b64 exec, %[m]\n\t"
+			             "ds_write_b128 %[ad], %[v]\n\t"
+			             "s_mov_b64 exec, -1"
+			             : [ad] "+v"(pos) : [base] "s"(readfirstlane_u32(stage_base + (kept << 4))), [m] "s"(m), [v] "v"(cv) : "memory");
+		}
+		kept += n;
+	}
+	if (!fits) return CAP + 1u;
+	return kept;
+}
+// the query loop on the `kept` survivors in the staging area
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF, int NC>
+__device__ __forceinline__ void fast_cell_from_stage(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits, uint32_t kept,
+                                                     const float4 qv, const float qr2, const uint32_t qorig)
+{
+	constexpr int NP = (NC + 1) / 2;
+	const uint32_t* const stw = record_stage<(int)StageSize<8>::ints>();
+	const float4* const st = reinterpret_cast<const float4*>(stw);
+	const float* const st_r2 = reinterpret_cast<const float*>(stw + RegCull<SYM>::r2_word);
+	v2f cx[NP], cy[NP], cz[NP];
+	uint32_t cid[2 * NP];
+	float cr2[2 * NP];
+	float4 craw[NC];
+	float r2raw[NC];
+	#pragma unroll
+	for (int k = 0; k < NC; k++) {   // (slots past `kept` hold stale words of this wave's own area: masked below)
+		craw[k] = st[k * WAVE + lane];
+		if (SYM) r2raw[k] = st_r2[k * WAVE + lane];
+	}
+	#pragma unroll
+	for (int k = 0; k < 2 * NP; k++) {
+		float4 c = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, __uint_as_float(0xffffffffu));
+		float r2c = -1.0f;
+		if (k < NC) {
+			c = craw[k];
+			if (SYM) r2c = r2raw[k];
+			if (k == NC - 1) {
+				const bool valid = (uint32_t)(k * WAVE + lane) < kept;
+				c.x = valid ? c.x : FLT_MAX; c.y = valid ? c.y : FLT_MAX; c.z = valid ? c.z : FLT_MAX;
+				c.w = valid ? c.w : __uint_as_float(0xffffffffu);
+				if (SYM) r2c = valid ? r2c : -1.0f;
+			}
+		}
+		cx[k >> 1][k & 1] = c.x; cy[k >> 1][k & 1] = c.y; cz[k >> 1][k & 1] = c.z;
+		cid[k] = __float_as_uint(c.w);
+		cr2[k] = r2c;
+	}
+	fast_query_loop<ARITH, VARIABLE, SYM, SELF, NC>(a, RR, lane, cur_q, ps, wave_hits, cx, cy, cz, cid, cr2, qv, qr2, qorig);
+}
+template <int ARITH, bool VARIABLE, bool SYM, bool SELF>
+__device__ __forceinline__ bool fast_cell_reg_culled(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits, uint32_t nc)
+{
+	float4 qv; float qr2; uint32_t qorig, kept;
+	static_assert(TNSX_REG_CULL_FROM >= 3, "the chunk counts below");
+	switch (nc) {   // (the chunk count is exact: only the last chunk of a body may be partial)
+	case 3: kept = cull_cell_to_stage<ARITH, VARIABLE, SYM, SELF, 3>(a, RR, lane, cur_q, qv, qr2, qorig); break;
+	case 4: kept = cull_cell_to_stage<ARITH, VARIABLE, SYM, SELF, 4>(a, RR, lane, cur_q, qv, qr2, qorig); break;
+	case 5: kept = cull_cell_to_stage<ARITH, VARIABLE, SYM, SELF, 5>(a, RR, lane, cur_q, qv, qr2, qorig); break;
+	case 6: kept = cull_cell_to_stage<ARITH, VARIABLE, SYM, SELF, 6>(a, RR, lane, cur_q, qv, qr2, qorig); break;
+	default: kept = cull_cell_to_stage<ARITH, VARIABLE, SYM, SELF, 7>(a, RR, lane, cur_q, qv, qr2, qorig); break;
+	}
+	kept = readfirstlane_u32(kept);
+	if (kept > RegCull<SYM>::cap) return false;   // (more survivors than the staging area holds: the caller takes the plain path, which loads the candidates again)
+#define TNSX_FROM_STAGE(N) fast_cell_from_stage<ARITH, VARIABLE, SYM, SELF, N>(a, RR, lane, cur_q, ps, wave_hits, kept, qv, qr2, qorig)
+	switch ((kept + WAVE - 1) / WAVE) {
+	case 0:
+	case 1: TNSX_FROM_STAGE(1); break;
+	case 2: TNSX_FROM_STAGE(2); break;
+	case 3: TNSX_FROM_STAGE(3); break;
+	case 4: TNSX_FROM_STAGE(4); break;
+	case 5: TNSX_FROM_STAGE(5); break;
+	default: TNSX_FROM_STAGE(6); break;
+	}
+#undef TNSX_FROM_STAGE
+	return true;
+}
+
 template <int ARITH, bool VARIABLE, bool SYM, bool SELF, bool FAT>
 __device__ __forceinline__ void fast_cell_nc(const QueryArgs& a, const RunRef RR, int lane, const uint2 cur_q, PoolState& ps, uint32_t& wave_hits)
 {
 	const uint32_t nc = (RR.total + WAVE - 1) / WAVE;
 	if (!FAT) {
+		if (TNSX_REG_CULL && (!SYM || TNSX_REG_CULL_SYM) && nc >= (uint32_t)TNSX_REG_CULL_FROM && nc <= 7u) {
+			if (fast_cell_reg_culled<ARITH, VARIABLE, SYM, SELF>(a, RR, lane, cur_q, ps, wave_hits, nc)) return;
+		}
 		switch (nc) {
 		case 1: fast_cell<ARITH, VARIABLE, SYM, SELF, 1>(a, RR, lane, cur_q, ps, wave_hits); break;
 		case 2: fast_cell<ARITH, VARIABLE, SYM, SELF, 2>(a, RR, lane, cur_q, ps, wave_hits); break;
