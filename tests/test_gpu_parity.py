@@ -426,3 +426,27 @@ def test_an_unavailable_formulation_falls_back_to_the_cell_kernels(oracle):
     ns.run(); ns.run()
     assert ns.get_stats()["n_group_pairs"] == 0
     P.assert_matches_golden({(0, 0): ns.neighbor_csr(0, 0)}, load_golden(case.name), 0, oracle, case.name + " (formulation 1 asked of a library without it)")
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["strict", "contracted"])
+def test_register_cull_keeps_candidates_on_the_radius(mode, oracle):
+    """Round 6: cells of 4..7 candidate chunks are culled against the bounding box of their query points before the query loop (tnsx_query.hip,
+    cull_cell_to_stage); the bound is a lower bound of the squared distance IN THE PREDICATE'S OWN ARITHMETIC, so a candidate at exactly d == r of a query
+    must survive it.  A lattice of spacing r / 2 (eight points per cell: 216 candidates per cell, four chunks -- the path is taken), moved off the origin so
+    that the coordinates round: every point has six neighbours at exactly d == r and many more one ulp either side."""
+    import treensearch_amd as T
+    r = np.float32(0.0625)
+    g = np.arange(32, dtype=np.float32) * (r / np.float32(2))
+    pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) + np.float32([0.7, 1.3, 2.9])
+    pts = np.ascontiguousarray(pts.astype(np.float32))
+    rng = np.random.default_rng(3)
+    pts = pts[rng.permutation(len(pts))]
+    ns = T.TreeNSearch(arith=mode)
+    ns.set_search_radius(float(r)); ns.add_point_set(pts); ns.set_active_search(0, 0, True)
+    want = oracle.pair_search(pts, pts, radius=float(r), same_set=True, mode=mode)
+    assert int(want[0][-1]) >= 30 * len(pts) * 0.8          # (32 neighbours within r on the lattice, fewer at the faces)
+    for step in range(2):
+        ns.run()
+        P.assert_same_csr(ns.neighbor_csr(0, 0), want, f"lattice of spacing r / 2, run {step}")
+    st = ns.get_stats()
+    assert st["n_occupied_cells"] > 0 and len(pts) / st["n_occupied_cells"] >= 6.0, "the cells must be dense enough for the culled path (>= 4 chunks of candidates)"
