@@ -2,13 +2,13 @@
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats + PMC passes (each in its own run) of bench.py.
 # usage: tools/prof_gpu.sh <label> [kernel-regex] [extra bench args]
 set -u
-LABEL=${1:-run}; REGEX=${2:-"k_query|k_cs_|k_cell|k_table|k_set_checksum|k_sort_records"}
+LABEL=${1:-run}; REGEX=${2:-"k_query|k_cs_|k_cell|k_table|k_set_checksum|k_sort_records|k_bucket|k_occ|k_run_begin"}
 if [ $# -ge 2 ]; then shift 2; else shift $#; fi
 OUT=gpurun_out/prof_$LABEL
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-pmc $*"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $BENCH > $OUT/kt.log 2>&1 < /dev/null
+BENCH="python bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-pmc --no-secondary --no-stage-pass $*"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-secondary --no-stage-pass $* > $OUT/kt.log 2>&1 < /dev/null
 pass() {  # name counters...
   local name=$1; shift
   timeout 300 rocprofv3 --pmc "$@" --kernel-include-regex "$REGEX" --output-format csv -d $OUT/pmc_$name -o pmc -- $BENCH > $OUT/pmc_$name.log 2>&1 < /dev/null
