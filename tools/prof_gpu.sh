@@ -7,6 +7,7 @@ if [ $# -ge 2 ]; then shift 2; else shift $#; fi
 OUT=gpurun_out/prof_$LABEL
 mkdir -p $OUT
 export TMPDIR=/tmp
+export TNSX_BENCH_INNER=1   # the bench run under the profiler is the timed loop only: no copy-ceiling measurement, no random-order variant behind it
 BENCH="python bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-pmc --no-secondary --no-stage-pass $*"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-secondary --no-stage-pass $* > $OUT/kt.log 2>&1 < /dev/null
 pass() {  # name counters...
