@@ -627,13 +627,19 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 	const uint32_t stage_base = readfirstlane_u32((uint32_t)(uintptr_t)stage);   // (the low half of a generic LDS address is the LDS offset)
 	const uint32_t max_len = RR.total + 1u;   // no record of this cell is longer (<= STAGE / 2 by the tiers' limits)
 
-	uint32_t spos = 0;      // ints staged: the block so far
-	uint32_t t0 = 0;        // first query of the block
-	uint32_t v_pos = 0;     // lane t: where record t starts inside its block
+	// Round 6: the bookkeeping of the loop is in LDS BYTE ADDRESSES -- `rec` = where the current record starts, lane 63's final address = where it ends -- and what
+	// a record needs beyond its hits (its count word, its position in the block) is parked in two vector registers, one lane per query, and written when the block
+	// leaves: per query two scalar instructions (end - rec, end + 4) instead of eight and no LDS store for the count word (C2 query -1.9 %, then another -0.4 % and C3 -3.3 %:
+	// profiles/r6_reg_cull.txt; the scalar unit is shared by the four SIMDs of a CU and this kernel issues ~45 scalar instructions per query).
+	uint32_t rec = stage_base;   // LDS byte address of the next record
+	uint32_t t0 = 0;             // first query of the block
+	uint32_t v_rec = 0;          // lane t: LDS byte address of record t
+	uint32_t v_len = 0;          // lane t: 4 x the number of neighbours of query t
 	uint32_t hits = 0;
-	// the block [0, spos) = the records of queries [t0, t1) -> the pool
+	// the block [stage_base, rec) = the records of queries [t0, t1) -> the pool
 	auto flush = [&](uint32_t t1) {
-		const uint32_t block = spos;
+		const uint32_t block = (rec - stage_base) >> 2;
+		const uint32_t v_pos = (v_rec - stage_base) >> 2;   // lane t: where record t starts inside its block (ints)
 		uint64_t dst = base;        // where this block goes
 		uint32_t dst_ok = ok;
 		bool from_slab = true;
@@ -651,6 +657,8 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 			if (exact) { dst = got_ok ? got : 0; dst_ok = got_ok; from_slab = false; }
 			else { base = got_ok ? got : 0; ok = got_ok; left = sz; dst = base; dst_ok = ok; }
 		}
+		if ((uint32_t)lane >= t0 && (uint32_t)lane < t1) stage[v_pos] = v_len >> 2;   // the count words of the block's records (LDS operations of a wave execute in order)
+		asm volatile("" ::: "memory");
 		if (dst_ok != 0u) {
 			v4i rsrc = record_rsrc(a.records + dst);
 			rsrc.z = (int)block;   // NUM_RECORDS: the hardware drops the lanes of the last store that lie beyond the block
@@ -677,11 +685,12 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 		hits += block - (t1 - t0);
 		if (from_slab) { base += block; left -= block; }
 		t0 = t1;
-		spos = 0;
+		rec = stage_base;
 	};
+	const uint32_t rec_limit = stage_base + 4u * (STAGE - max_len);   // a record that starts behind this address may not fit the staging area
 
 	for (uint32_t t = 0; t < nq; t++) {
-		if (spos + max_len > STAGE) flush(t);   // (cells with many query points: the block leaves in pieces)
+		if (rec > rec_limit) flush(t);   // (cells with many query points: the block leaves in pieces)
 		// (three v_readlane, 4.3 cycles each.  The point through a scalar load instead: -0.5 %; through the LDS -- parked once per cell,
 		//  one broadcast ds_read per query -- +8 %: the 4 KB per workgroup it needs take the staging area to the LDS limit of five
 		//  workgroups per CU.  profiles/r3_query_ab_micro.txt)
@@ -704,7 +713,6 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 			asm("s_bitset0_b64 %0, %1" : "+s"(m[0]) : "s"(t));
 		}
 		// hits -> the staging area, lane-major behind the count word: lane l writes at rec + 4 + 4 * (hits of all chunks in lower lanes)
-		const uint32_t rec = stage_base + (spos << 2);
 		uint32_t addr;
 		{
 			uint32_t P = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[0] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[0], 0u));
@@ -714,17 +722,11 @@ __device__ __forceinline__ void fast_query_loop(const QueryArgs& a, const RunRef
 			asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(addr) : "v"(P), "s"(rec));
 		}
 		stage_all4<NC>(addr, m, cid);
-		const uint32_t cnt = (readlane_u32(addr, WAVE - 1) - rec) >> 2;
-		{
-			// the count word, by lane 0 through M0 (address = M0 + 4 * lane; m0 is reserved: the compiler reloads it before its own uses)
-			uint32_t tmp;
-			asm volatile("s_mov_b32 m0, %[rec]\n\ts_mov_b64 exec, 1\n\tv_mov_b32 %[t], %[c]\n\tds_write_addtid_b32 %[t]\n\ts_mov_b64 exec, -1"
-			             : [t] "=&v"(tmp) : [rec] "s"(rec), [c] "s"(cnt) : "memory");
-		}
-		asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v_pos) : "s"(spos), "s"(t));
-		spos += cnt + 1u;
+		const uint32_t end = readlane_u32(addr, WAVE - 1);   // rec + 4 * hits
+		asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(v_rec), "+v"(v_len) : "s"(rec), "s"(end - rec), "s"(t));
+		rec = end + 4u;
 	}
-	if (spos != 0u) flush(nq);
+	if (rec != stage_base) flush(nq);
 	wave_hits += hits;
 	ps.cur_lo = (uint32_t)base; ps.cur_hi = (uint32_t)(base >> 32);
 	ps.left = left;
