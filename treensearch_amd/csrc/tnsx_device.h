@@ -94,6 +94,18 @@ __device__ __forceinline__ void wave_bbox16(float& x0, float& y0, float& z0, flo
 	x0 = readlane_f32(x0, 0); y0 = readlane_f32(y0, 0); z0 = readlane_f32(z0, 0);
 	x1 = readlane_f32(x1, 0); y1 = readlane_f32(y1, 0); z1 = readlane_f32(z1, 0);
 }
+// sum of v over the lanes 0..31 whose bit is set in `lanes` (wave-uniform result): one select, four DPP steps inside the rows of 16, two readlanes
+__device__ __forceinline__ uint32_t wave_sum32_masked(uint32_t v, uint64_t lanes)
+{
+	uint32_t t;
+	asm volatile("v_cndmask_b32 %0, 0, %1, %2\n\ts_nop 1\n\t"
+	             "v_add_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_add_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_add_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_add_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+	             : "=&v"(t) : "v"(v), "s"(lanes));
+	return readlane_u32(t, 0) + readlane_u32(t, 16);
+}
 // wave-wide maximum of one value (same scheme; s_nop between the dependent DPP steps)
 __device__ __forceinline__ float wave_max_dpp(float v)
 {

@@ -46,6 +46,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #ifndef TNSX_LANE_OPAQUE
 #define TNSX_LANE_OPAQUE 1   // round 5: lane-derived constants of the cell bodies are recomputed per cell instead of living in (and spilling from) a dozen VGPRs
 #endif
+#ifndef TNSX_TOTAL_BY_DPP
+#define TNSX_TOTAL_BY_DPP 1
+#endif
 #ifndef TNSX_CULL
 #define TNSX_CULL 1   // first tier: cells with 513..1024 candidates are culled against the bounding box of their query points (fast_cell_culled)
 #endif
@@ -1286,10 +1289,16 @@ __global__ void __launch_bounds__(Q_THREADS) k_query_pool_fast(const QueryArgs a
 		RR.run_start = (e > s) ? s : ((e1 > s1) ? s1 : s2);
 		const uint32_t run_end = (e2 > s2) ? e2 : ((e1 > s1) ? e1 : e);
 		RR.run_len = ((e > s) || (e1 > s1) || (e2 > s2)) ? run_end - RR.run_start : 0u;   // empty entries may hold any (s,s)
+#if TNSX_TOTAL_BY_DPP
+		// (the number of candidates = the lengths of the nine runs, which sit in lanes 0, 3, ..., 24: a masked sum over two rows of lanes instead of
+		//  eighteen v_readlane and as many scalar instructions -- the cell bodies extract the runs themselves)
+		RR.total = wave_sum32_masked(RR.run_len, 0x1249249ull);
+#else
 		{
 			const Runs R0 = extract_runs(RR.run_start, RR.run_len);
 			RR.total = R0.total;
 		}
+#endif
 		const uint2 cur_q = qrange;
 		// ---- lookups of the next cell: in flight while this one is processed
 		{
