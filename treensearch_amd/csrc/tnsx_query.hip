@@ -175,14 +175,14 @@ __device__ __forceinline__ void deal_run(uint32_t tbl, uint32_t p0, uint32_t p1,
 	if (n - 1u < 64u) {     // the usual case, without the loop's bookkeeping: one piece (a run is three cells of the grid)
 		const uint32_t v = lane + (pos + d);
 		asm volatile("s_mov_b32 m0, %[b]\n\ts_lshr_b64 exec, -1, %[sh]\n\tds_write_addtid_b32 %[v]\n\ts_mov_b64 exec, -1"
-		             : : [b] "s"(tbl + 4u * pos), [sh] "s"(64u - n), [v] "v"(v) : "memory");
+		             : : [b] "s"(tbl + 4u * pos), [sh] "s"(64u - n), [v] "v"(v) : "memory", "scc");   // (s_lshr_b64 writes SCC: round 6 found the clobber missing)
 		return;
 	}
 	while (n != 0u) {
 		const uint32_t c = n < 64u ? n : 64u;
 		const uint32_t v = lane + (pos + d);
 		asm volatile("s_mov_b32 m0, %[b]\n\ts_lshr_b64 exec, -1, %[sh]\n\tds_write_addtid_b32 %[v]\n\ts_mov_b64 exec, -1"
-		             : : [b] "s"(tbl + 4u * pos), [sh] "s"(64u - c), [v] "v"(v) : "memory");
+		             : : [b] "s"(tbl + 4u * pos), [sh] "s"(64u - c), [v] "v"(v) : "memory", "scc");
 		n -= c; pos += c;
 	}
 }
@@ -199,6 +199,49 @@ __device__ __forceinline__ void deal_table(uint32_t tbl, const Runs R, uint32_t 
 	deal_run(tbl, R.p7, R.p8, R.d7, lane);
 	deal_run(tbl, R.p8, R.p9, R.d8, lane);
 	if (OWN_FIRST) deal_run(tbl, R.p9, R.total, R.d9, lane);
+}
+
+// Round 6: extraction of the runs and dealing in ONE pass for the first tier (the scalar unit is shared by the four SIMDs of a CU and this kernel issues ~40 scalar
+// instructions per query; extract_runs_t + deal_table above were ~170 of a cell's ~500).  A run's table entries are `first sorted position of the run + lane`, its
+// slots are consecutive: M0 walks through the table (s_lshl2_add_u32 m0, n, m0), the run's extent is the exec mask (s_bfm_b64), one v_add and one
+// ds_write_addtid_b32 per run -- four scalar instructions per run instead of fourteen.  Runs of 64 slots and more (three cells of a row holding > 63 points: a few
+// cells in a thousand at C2) make the caller take the general way.  -> p1 = slots of run 0 (the centre run: kept whole by the cull), d0 = sorted position of slot 0.
+#ifndef TNSX_DEAL_DIRECT
+#define TNSX_DEAL_DIRECT 1
+#endif
+template <bool OWN_FIRST>
+__device__ __forceinline__ bool deal_runs_direct(uint32_t tbl, const RunRef RR, uint32_t q_first, uint32_t lane, uint32_t& p1, uint32_t& d0)
+{
+	// (lanes 0, 3, ..., 24 hold the nine rows; every other lane's run_len is not a run)
+	const uint64_t long_run = __builtin_amdgcn_ballot_w64(RR.run_len > 63u) & 0x1249249ull;
+	if (long_run != 0ull) return false;
+	uint32_t rs[10], rn[10];
+	const uint32_t cs = readlane_u32(RR.run_start, 12), cn = readlane_u32(RR.run_len, 12);   // the centre row
+	if (OWN_FIRST) {
+		rs[0] = q_first; rn[0] = cs + cn - q_first;      // [own | x + 1]
+		rs[1] = cs; rn[1] = q_first - cs;                // [x - 1]
+	}
+	else { rs[0] = cs; rn[0] = cn; rs[1] = cs; rn[1] = 0u; }
+	#pragma unroll
+	for (int r = 0; r < 8; r++) {
+		const int src = r < 4 ? r : r + 1;               // rows 0..3, 5..8
+		rs[2 + r] = readlane_u32(RR.run_start, 3 * src); rn[2 + r] = readlane_u32(RR.run_len, 3 * src);
+	}
+	p1 = rn[0]; d0 = rs[0];
+	uint32_t t0, t1;
+#define TNSX_DEAL_PIECE(K, T) "s_bfm_b64 exec, %[n" #K "], 0\n\tv_add_u32 %[" #T "], %[s" #K "], %[lane]\n\tds_write_addtid_b32 %[" #T "]\n\ts_lshl2_add_u32 m0, %[n" #K "], m0\n\t"
+	asm volatile("s_mov_b32 m0, %[tbl]\n\t"
+	             TNSX_DEAL_PIECE(0, t0) TNSX_DEAL_PIECE(1, t1) TNSX_DEAL_PIECE(2, t0) TNSX_DEAL_PIECE(3, t1) TNSX_DEAL_PIECE(4, t0)
+	             TNSX_DEAL_PIECE(5, t1) TNSX_DEAL_PIECE(6, t0) TNSX_DEAL_PIECE(7, t1) TNSX_DEAL_PIECE(8, t0) TNSX_DEAL_PIECE(9, t1)
+	             "s_mov_b64 exec, -1"
+	             : [t0] "=&v"(t0), [t1] "=&v"(t1)
+	             : [tbl] "s"(tbl), [lane] "v"(lane),
+	               [s0] "s"(rs[0]), [n0] "s"(rn[0]), [s1] "s"(rs[1]), [n1] "s"(rn[1]), [s2] "s"(rs[2]), [n2] "s"(rn[2]), [s3] "s"(rs[3]), [n3] "s"(rn[3]),
+	               [s4] "s"(rs[4]), [n4] "s"(rn[4]), [s5] "s"(rs[5]), [n5] "s"(rn[5]), [s6] "s"(rs[6]), [n6] "s"(rn[6]), [s7] "s"(rs[7]), [n7] "s"(rn[7]),
+	               [s8] "s"(rs[8]), [n8] "s"(rn[8]), [s9] "s"(rs[9]), [n9] "s"(rn[9])
+	             : "memory", "scc");   // (s_lshl2_add_u32 writes SCC)
+#undef TNSX_DEAL_PIECE
+	return true;
 }
 
 // 27 neighbour lookups of the cell with this key (lanes 0..26), wave-uniform key
@@ -742,9 +785,17 @@ __device__ __forceinline__ void fast_cell(const QueryArgs& a, const RunRef RR, i
 	constexpr int NP = (NC + 1) / 2;
 	constexpr bool OWN_FIRST = SELF;
 	const uint32_t nq = cur_q.y - cur_q.x;
-	const Runs R = extract_runs_t<OWN_FIRST>(RR.run_start, RR.run_len, cur_q.x);
 	const uint32_t* const tbl = record_stage<(int)StageSize<NC>::ints>();
-	deal_table<OWN_FIRST>(readfirstlane_u32((uint32_t)(uintptr_t)tbl), R, (uint32_t)lane);
+	struct { uint32_t total, d0; } R;
+	R.total = RR.total;
+	{
+		uint32_t p1_unused;
+		if (!TNSX_DEAL_DIRECT || NC > 8 || !deal_runs_direct<OWN_FIRST>(readfirstlane_u32((uint32_t)(uintptr_t)tbl), RR, cur_q.x, (uint32_t)lane, p1_unused, R.d0)) {
+			const Runs RF = extract_runs_t<OWN_FIRST>(RR.run_start, RR.run_len, cur_q.x);
+			deal_table<OWN_FIRST>(readfirstlane_u32((uint32_t)(uintptr_t)tbl), RF, (uint32_t)lane);
+			R.d0 = RF.d0;
+		}
+	}
 	// ---- candidates -> registers (branch-free, see process_batch)
 	v2f cx[NP], cy[NP], cz[NP];
 	uint32_t cid[2 * NP];
@@ -978,7 +1029,8 @@ __device__ __forceinline__ uint64_t low_lanes(uint32_t n)
 {
 	uint64_t m;
 	const uint32_t ns = readfirstlane_u32(n);   // (an "s" operand the compiler holds in a vector register is not moved for us)
-	asm("s_bfm_b64 %0, %1, 0\n\ts_cmp_gt_u32 %1, 63\n\ts_cselect_b64 %0, -1, %0" : "=s"(m) : "s"(ns) : "scc");
+	// ("=&s": the mask is written before n is read for the last time -- without the early-clobber mark the two may share a register, and did in one build of round 6)
+	asm("s_bfm_b64 %0, %1, 0\n\ts_cmp_gt_u32 %1, 63\n\ts_cselect_b64 %0, -1, %0" : "=&s"(m) : "s"(ns) : "scc");
 	return m;
 }
 // survivors the staging area holds: float4 per survivor, + its r_j^2 behind the float4s when the predicate is symmetric
@@ -1013,9 +1065,14 @@ __device__ __forceinline__ uint32_t cull_cell_to_stage(const QueryArgs& a, const
 	constexpr bool OWN_FIRST = SELF;
 	constexpr uint32_t CAP = RegCull<SYM>::cap;
 	const uint32_t nq = cur_q.y - cur_q.x;
-	const Runs R = extract_runs_t<OWN_FIRST>(RR.run_start, RR.run_len, cur_q.x);
 	uint32_t* const tbl = record_stage<(int)StageSize<8>::ints>();
-	deal_table<OWN_FIRST>(readfirstlane_u32((uint32_t)(uintptr_t)tbl), R, (uint32_t)lane);
+	struct { uint32_t total, p1, d0; } R;
+	R.total = RR.total;
+	if (!TNSX_DEAL_DIRECT || !deal_runs_direct<OWN_FIRST>(readfirstlane_u32((uint32_t)(uintptr_t)tbl), RR, cur_q.x, (uint32_t)lane, R.p1, R.d0)) {
+		const Runs RF = extract_runs_t<OWN_FIRST>(RR.run_start, RR.run_len, cur_q.x);
+		deal_table<OWN_FIRST>(readfirstlane_u32((uint32_t)(uintptr_t)tbl), RF, (uint32_t)lane);
+		R.p1 = RF.p1; R.d0 = RF.d0;
+	}
 	float4 craw[NC];
 	float r2raw[NC];
 	#pragma unroll
